@@ -1,0 +1,129 @@
+/*
+ * todhip.h -- C ABI of the MI355X-native textured-object-detection hot path.
+ *
+ * This is the drop-in boundary for wg-perception/tod's detection cells: a thin C++ adapter
+ * (adapter/ecto_cells.hpp) keeps the ecto cell, parameter and tendril names of
+ * src/detection/DescriptorMatcher.cpp and src/detection/GuessGenerator.cpp and converts the
+ * tendril types to the flat buffers below. Citations are file:line in the reference tree.
+ *
+ * Conventions: every function returns a todhip_status (0 = ok, negative = error); nothing throws,
+ * nothing prints; all buffers are caller-owned with explicit sizes; one call in flight per
+ * context; a context is bound to one HIP device and one HIP stream. Pointers named d_* are device
+ * pointers on the context's device, everything else is host memory.
+ */
+#ifndef TODHIP_H_
+#define TODHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TODHIP_VERSION 1
+
+typedef enum {
+  TODHIP_OK = 0,
+  TODHIP_EINVAL = -1,      /* bad argument (null pointer, k == 0, radius == 0, unsupported descriptor size ...) */
+  TODHIP_ENODB = -2,       /* no descriptors loaded: DescriptorMatcher.cpp:204-208 logs and returns            */
+  TODHIP_EHIP = -3,        /* a HIP runtime call failed; todhip_last_hip_error() has the code                   */
+  TODHIP_ECAPACITY = -4,   /* caller-provided output capacity too small                                         */
+  TODHIP_ERANGE = -5,      /* keypoint outside the cloud / imgIdx outside the object table                      */
+  TODHIP_ENOMEM = -6,
+  TODHIP_ESCRATCH = -7     /* verifier scratch budget exceeded (never silently wrong)                           */
+} todhip_status;
+
+typedef struct todhip_ctx todhip_ctx;
+
+/* One trained object as the DB hands it over (DescriptorMatcher.cpp:72-86):
+ * `descriptors` attachment = n x desc_bytes CV_8U, `points` attachment = n x 3 f32 (object frame). */
+typedef struct { const uint8_t* desc; const float* pts_xyz; uint32_t n; } todhip_object;
+
+/* Same layout as cv::DMatch: the adapter reinterprets, no conversion. */
+typedef struct { int32_t queryIdx, trainIdx, imgIdx; float distance; } todhip_dmatch;
+
+/* glibc rand() state (random_r TYPE_3). The reference calls the process-global, never-seeded
+ * rand() (sac_model_registration_graph.h:111, sac.h:71); here the stream is explicit (decision D4). */
+typedef struct { uint32_t s[31]; uint32_t f, b; uint64_t draws; } todhip_rng;
+
+/* GuessGenerator parameters, GuessGenerator.cpp:71-81 (defaults 15 / 1000 / 0.01). */
+typedef struct { uint32_t min_inliers, n_ransac_iterations; float sensor_error; } todhip_verify_params;
+
+/* One PoseResult (GuessGenerator.cpp:223-230): R row-major, pose maps object -> camera frame. */
+typedef struct { uint32_t object; float R[9]; float t[3]; uint32_t inlier_begin, inlier_end; } todhip_pose;
+
+/* Counters a cell would have printed to stdout (DescriptorMatcher.cpp:68-122, GuessGenerator.cpp:177-243). */
+typedef struct {
+  uint64_t db_rows, db_objects;
+  uint32_t last_nq, last_k, last_matches;
+  uint32_t last_objects_verified, last_rounds, last_hypotheses, last_gate_calls, last_poses;
+  double   last_match_kernel_ms;      /* HIP-event time of the dominant matcher kernel (if timing enabled) */
+  double   sum_match_kernel_ms;
+  uint64_t n_match_kernel_launches;
+} todhip_counters;
+
+/* ---- lifetime ---------------------------------------------------------------------------------- */
+int  todhip_version(void);
+/* stream == NULL: the context creates and owns a non-blocking stream. */
+int  todhip_create(int device, void* hip_stream, todhip_ctx** out);
+void todhip_destroy(todhip_ctx*);
+void* todhip_stream(todhip_ctx*);
+int  todhip_last_hip_error(const todhip_ctx*);
+int  todhip_synchronize(todhip_ctx*);
+int  todhip_get_counters(todhip_ctx*, todhip_counters* out);
+int  todhip_set_kernel_timing(todhip_ctx*, int enable);   /* bracket the matcher kernel with HIP events */
+
+/* ---- stage B: DescriptorMatcher ---------------------------------------------------------------- */
+/* Replaces DescriptorMatcher::parameter_callback (DescriptorMatcher.cpp:60-129): ingest every object,
+ * compute spans (:104-121), build the device-resident DB. With shard_count > 1 the descriptor rows are
+ * split into object-aligned contiguous shards and only shard `shard_rank` is kept on this device; model
+ * points and the object table are always complete. spans_out (n_objs floats) may be NULL. */
+int todhip_db_load(todhip_ctx*, const todhip_object* objs, uint32_t n_objs, uint32_t desc_bytes,
+                   uint32_t shard_rank, uint32_t shard_count, float* spans_out);
+int todhip_db_info(const todhip_ctx*, uint64_t* total_rows, uint64_t* shard_first_row, uint64_t* shard_rows,
+                   uint32_t* n_objs);
+
+/* Replaces DescriptorMatcher::process (DescriptorMatcher.cpp:195-252): exact Hamming k-NN (decision D1,
+ * instead of FLANN-LSH knnMatch(k=5) at :211), radius truncation (:212-220; radius is the reference's
+ * `unsigned int radius_`, 0 is rejected because the reference then indexes an empty vector at :237) and
+ * the match -> 3D gather (:231-244). Outputs in CSR form: row_ptr[nq+1], matches/matches_xyz capacity nq*k. */
+int todhip_match(todhip_ctx*, const uint8_t* q_desc, uint32_t nq, uint32_t k, uint32_t radius,
+                 uint32_t* row_ptr, todhip_dmatch* matches, float* matches_xyz);
+
+/* Device-resident form of the same call (inputs already in HBM, outputs stay in HBM):
+ * d_counts[nq] (matches kept per query), d_matches[nq*k], d_matches_xyz[nq*k*3], fixed stride k. */
+int todhip_match_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t k, uint32_t radius,
+                        void* d_counts, void* d_matches, void* d_matches_xyz);
+
+/* Sharded form, step 1: this shard's top-k per query as keys (distance << 32 | global_row), ascending,
+ * UINT64_MAX padded; d_keys[nq*k]. The ranks exchange these with one RCCL all-gather. */
+int todhip_match_shard_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t k, void* d_keys);
+/* Sharded form, step 2: merge n_shards key sets (layout [shard][nq][k]) with the total order
+ * (distance asc, global row asc), apply the radius cut, resolve (imgIdx, trainIdx), gather 3D. */
+int todhip_merge_shards_device(todhip_ctx*, const void* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
+                               uint32_t radius, void* d_counts, void* d_matches, void* d_matches_xyz);
+
+/* ---- stage C: GuessGenerator ------------------------------------------------------------------- */
+void todhip_rng_seed(todhip_rng*, uint32_t seed);   /* srand(seed); the reference never seeds => seed 1 */
+/* Replaces GuessGenerator::process (GuessGenerator.cpp:127-250) and everything under src/common.
+ * kp_xy: nq x 2 keypoint pixels (cv::KeyPoint::pt); cloud_xyz: H x W x 3 f32 organised cloud (NaN = no depth);
+ * matches in CSR form as produced by todhip_match; spans: per object index (imgIdx).
+ * poses: capacity *n_poses in, count out. inlier_kp: capacity *n_inlier_kp in, count out. */
+int todhip_verify(todhip_ctx*, const float* kp_xy, uint32_t nq, const float* cloud_xyz, uint32_t H, uint32_t W,
+                  const uint32_t* row_ptr, const todhip_dmatch* matches, const float* matches_xyz,
+                  const float* spans, uint32_t n_objs, const todhip_verify_params*, todhip_rng* rng,
+                  todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp);
+
+/* ---- stage A: ORB features (ecto_opencv FeatureDescriptor -> cv::ORB; detector.py:10,27) --------- */
+/* gray: H x W u8, row stride `stride`. Outputs up to n_features keypoints: kp_xy (x,y level-0 pixels),
+ * kp_aux (size, angle_deg, response, octave) and 32-byte rBRIEF descriptors. *n_out: capacity in, count out.
+ * pattern: 256 x 4 int8 (x0,y0,x1,y1) test pairs, or NULL for the built-in seeded pattern. */
+int todhip_orb(todhip_ctx*, const uint8_t* gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
+               uint32_t n_levels, float scale_factor, const int8_t* pattern, float* kp_xy, float* kp_aux,
+               uint8_t* desc, uint32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TODHIP_H_ */

@@ -1,0 +1,186 @@
+"""GPU parity of stage B (DescriptorMatcher) through the C ABI, against the CPU oracle.
+Bit-exact: match indices, distances, radius truncation, gathered 3D points, spans."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from tod_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _assert_same(ctx, desc, pts, off, q, k, radius):
+    sp = ctx.db_load(desc, pts, off)
+    assert np.array_equal(sp, O.spans(pts, off))
+    row_ptr, m, xyz = ctx.match(q, k, radius)
+    rc, o_row_ptr, o_m, o_xyz = O.match(desc, off, pts, q, k, radius)
+    assert rc == 0
+    assert np.array_equal(row_ptr, o_row_ptr)
+    for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
+        assert np.array_equal(m[f], o_m[f]), f
+    assert np.array_equal(xyz, o_xyz)
+    return len(m)
+
+
+def test_c1_single_object_orb500(ctx):
+    """BASELINE configs[0]: ORB-500 frame vs a 1-object (5k) DB, k=5, radius 35 (conf/detection.ork:32-37)."""
+    desc, pts, off = synth.make_db(1)
+    fr = synth.make_frame(desc, pts, off, 500)
+    n = _assert_same(ctx, desc, pts, off, fr["q_desc"], 5, 35)
+    assert n > 100
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_all_k(ctx, k):
+    desc, pts, off = synth.make_db_ragged([700, 1, 0, 333, 2049], seed=5)
+    fr = synth.make_frame(desc, pts, off, 300, frame=k, visible_object=4)
+    _assert_same(ctx, desc, pts, off, fr["q_desc"], k, 255)   # radius 255: nothing is cut for 256-bit rows
+
+
+@pytest.mark.parametrize("nq", [1, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_query_counts(ctx, nq):
+    desc, pts, off = synth.make_db(4, per_object=777)
+    fr = synth.make_frame(desc, pts, off, nq, frame=nq, visible_object=2)
+    _assert_same(ctx, desc, pts, off, fr["q_desc"], 2, 55)
+
+
+@pytest.mark.parametrize("n_rows", [1, 2, 3, 4, 5, 7, 63, 64, 65, 257, 4099])
+def test_tiny_and_odd_databases(ctx, n_rows):
+    """fewer rows than k, tails that are not a multiple of the 4-row group, single tiles"""
+    desc, pts, off = synth.make_db_ragged([n_rows], seed=n_rows)
+    rng = np.random.Generator(np.random.PCG64(n_rows))
+    q = rng.integers(0, 256, (70, 32), dtype=np.uint8)
+    q[:min(70, n_rows)] = desc[:min(70, n_rows)]
+    _assert_same(ctx, desc, pts, off, q, 5, 200)
+
+
+def test_ties_resolve_by_ascending_row(ctx):
+    """duplicated DB rows give equal distances: order must be (distance asc, global row asc) -- decision D1"""
+    desc, pts, off = synth.make_db_ragged([5000, 5000, 5000], seed=21)
+    for dup in (17, 4000, 5001, 9999, 14999):
+        desc[dup] = desc[3]
+    q = np.repeat(desc[3:4], 10, axis=0)
+    q[1:, 0] ^= np.arange(1, 10, dtype=np.uint8)
+    _assert_same(ctx, desc, pts, off, q, 8, 255)
+    row_ptr, m, _ = ctx.match(q[:1], 6, 255)
+    rows = off[m["imgIdx"]].astype(np.int64) + m["trainIdx"]
+    assert rows.tolist() == [3, 17, 4000, 5001, 9999, 14999] and (m["distance"] == 0).all()
+
+
+def test_radius_truncation_edges(ctx):
+    desc, pts, off = synth.make_db(2, per_object=3000)
+    fr = synth.make_frame(desc, pts, off, 200, frame=9, visible_object=1, flip_p=0.12)
+    for radius in (1, 20, 30, 31, 35, 55, 100, 128, 255, 256, 1000):
+        _assert_same(ctx, desc, pts, off, fr["q_desc"], 5, radius)
+
+
+def test_error_statuses(ctx):
+    desc, pts, off = synth.make_db(1, per_object=100)
+    ctx.db_load(desc, pts, off)
+    q = desc[:4]
+    with pytest.raises(capi.TodError) as e:
+        ctx.match(q, 5, 0)          # radius 0: the reference indexes an empty vector (DescriptorMatcher.cpp:237)
+    assert e.value.status == capi.EINVAL
+    with pytest.raises(capi.TodError):
+        ctx.match(q, 0, 35)
+    with pytest.raises(capi.TodError):
+        ctx.match(q, 9, 35)
+    empty = capi.Context(0)
+    with pytest.raises(capi.TodError) as e:
+        empty.match(q, 5, 35)       # "No descriptors loaded" (DescriptorMatcher.cpp:204-208)
+    assert e.value.status == capi.ENODB
+    empty.close()
+    row_ptr, m, xyz = ctx.match(np.zeros((0, 32), np.uint8), 5, 35)
+    assert row_ptr.tolist() == [0] and len(m) == 0
+
+
+def test_c2_100k_database(ctx):
+    """BASELINE configs[1]: ORB-1000 vs 100k-descriptor DB, Hamming BF k=2."""
+    desc, pts, off = synth.make_db(20)
+    fr = synth.make_frame(desc, pts, off, 1000, frame=1, visible_object=7)
+    n = _assert_same(ctx, desc, pts, off, fr["q_desc"], 2, 35)
+    assert 250 <= n <= 330
+
+
+def _shard_merge(desc, pts, off, q, k, radius, n_shards):
+    import torch
+    nq = q.shape[0]
+    d_q = torch.from_numpy(q).cuda()
+    keys_all = torch.empty((n_shards, nq, k), dtype=torch.int64, device="cuda")
+    ctxs = []
+    for s in range(n_shards):
+        c = capi.Context(0)
+        c.db_load(desc, pts, off, shard_rank=s, shard_count=n_shards)
+        c.match_shard_device(d_q.data_ptr(), nq, k, keys_all[s].data_ptr())
+        c.synchronize()
+        ctxs.append(c)
+    counts = torch.empty(nq, dtype=torch.int32, device="cuda")
+    m = torch.empty((nq * k, 4), dtype=torch.int32, device="cuda")
+    xyz = torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")
+    ctxs[0].merge_shards_device(keys_all.data_ptr(), n_shards, nq, k, radius, counts.data_ptr(), m.data_ptr(),
+                                xyz.data_ptr())
+    ctxs[0].synchronize()
+    infos = [c.db_info() for c in ctxs]
+    for c in ctxs:
+        c.close()
+    counts = counts.cpu().numpy()
+    m = m.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(nq, k)
+    xyz = xyz.cpu().numpy().reshape(nq, k, 3)
+    keep = np.arange(k)[None, :] < counts[:, None]
+    return counts, m[keep], xyz[keep], infos
+
+
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_sharded_equals_unsharded(ctx, n_shards):
+    """8(e): object-aligned shards + merge with the order (distance asc, global row asc) == 1-GPU result"""
+    desc, pts, off = synth.make_db_ragged([900, 50, 0, 1200, 700, 5, 333, 2000, 41, 800], seed=77)
+    desc[4000] = desc[100]          # a tie that straddles shards
+    fr = synth.make_frame(desc, pts, off, 500, frame=5, visible_object=3)
+    q = fr["q_desc"]
+    q[0] = desc[100]
+    counts, m, xyz, infos = _shard_merge(desc, pts, off, q, 3, 60, n_shards)
+    rc, o_row_ptr, o_m, o_xyz = O.match(desc, off, pts, q, 3, 60)
+    assert np.array_equal(np.diff(o_row_ptr.astype(np.int64)), counts)
+    for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
+        assert np.array_equal(m[f], o_m[f]), f
+    assert np.array_equal(xyz, o_xyz)
+    # shards are contiguous, object aligned and cover the DB exactly once
+    assert sum(i["shard_rows"] for i in infos) == off[-1]
+    starts = [i["shard_first"] for i in infos]
+    assert starts == sorted(starts) and all(s in set(off.tolist()) for s in starts)
+
+
+def test_c3_full_size_properties(ctx):
+    """BASELINE configs[2] on one GPU: ORB-1000 vs the 1M-descriptor DB. The oracle needs ~1e9 distances
+    (seconds) for a subset; the rest is checked through properties that do not depend on size."""
+    desc, pts, off = synth.make_db(200)
+    fr = synth.make_frame(desc, pts, off, 1000, frame=2, visible_object=123)
+    ctx.db_load(desc, pts, off)
+    row_ptr, m, xyz = ctx.match(fr["q_desc"], 2, 255)
+    assert np.array_equal(np.diff(row_ptr.astype(np.int64)), np.full(1000, 2))
+    rows = off[m["imgIdx"]].astype(np.int64) + m["trainIdx"]
+    # (1) every reported distance is the true Hamming distance of that pair
+    lut = np.array([bin(i).count("1") for i in range(256)], np.uint32)
+    true_d = lut[np.bitwise_xor(desc[rows], fr["q_desc"][m["queryIdx"]])].sum(axis=1)
+    assert np.array_equal(true_d.astype(np.float32), m["distance"])
+    # (2) lists ascend in (distance, row)
+    d2 = m["distance"].reshape(1000, 2)
+    r2 = rows.reshape(1000, 2)
+    assert ((d2[:, 0] < d2[:, 1]) | ((d2[:, 0] == d2[:, 1]) & (r2[:, 0] < r2[:, 1]))).all()
+    # (3) planted queries find their source row first
+    planted = fr["truth_rows"] >= 0
+    assert np.array_equal(r2[planted, 0], fr["truth_rows"][planted])
+    # (4) gather is the model point of the row
+    assert np.array_equal(xyz, pts[rows])
+    # (5) bit-exact against the oracle on a 64-query subset
+    sub = np.arange(0, 1000, 16)
+    keys = O.knn_keys(desc, fr["q_desc"][sub], 2)
+    assert np.array_equal(keys >> np.uint64(32), d2[sub].astype(np.uint64))
+    assert np.array_equal(keys & np.uint64(0xFFFFFFFF), r2[sub].astype(np.uint64))

@@ -1,0 +1,229 @@
+"""ctypes binding of libtodhip.so (include/todhip.h).
+
+The shared library is the product; this module only loads it and marshals numpy / torch
+buffers to plain pointers. There is no CPU fallback: if the library or the GPU is missing,
+loading or context creation raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtodhip.so")
+
+OK, EINVAL, ENODB, EHIP, ECAPACITY, ERANGE, ENOMEM, ESCRATCH = 0, -1, -2, -3, -4, -5, -6, -7
+
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+
+
+class TodObject(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("pts_xyz", C.c_void_p), ("n", C.c_uint32)]
+
+
+class Rng(C.Structure):
+    _fields_ = [("s", C.c_uint32 * 31), ("f", C.c_uint32), ("b", C.c_uint32), ("draws", C.c_uint64)]
+
+
+class VerifyParams(C.Structure):
+    _fields_ = [("min_inliers", C.c_uint32), ("n_ransac_iterations", C.c_uint32), ("sensor_error", C.c_float)]
+
+
+class Pose(C.Structure):
+    _fields_ = [("object", C.c_uint32), ("R", C.c_float * 9), ("t", C.c_float * 3),
+                ("inlier_begin", C.c_uint32), ("inlier_end", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("db_rows", C.c_uint64), ("db_objects", C.c_uint64), ("last_nq", C.c_uint32), ("last_k", C.c_uint32),
+                ("last_matches", C.c_uint32), ("last_objects_verified", C.c_uint32), ("last_rounds", C.c_uint32),
+                ("last_hypotheses", C.c_uint32), ("last_gate_calls", C.c_uint32), ("last_poses", C.c_uint32),
+                ("last_match_kernel_ms", C.c_double), ("sum_match_kernel_ms", C.c_double),
+                ("n_match_kernel_launches", C.c_uint64)]
+
+
+# every symbol include/todhip.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = [
+    "todhip_version", "todhip_create", "todhip_destroy", "todhip_stream", "todhip_last_hip_error",
+    "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_db_load", "todhip_db_info",
+    "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device",
+    "todhip_rng_seed", "todhip_verify", "todhip_orb",
+]
+
+_lib = None
+
+
+def build():
+    """Compile libtodhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_PKG, "csrc"), "-s", "-j4"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libtodhip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.todhip_stream.restype = C.c_void_p
+        L.todhip_destroy.restype = None
+        L.todhip_rng_seed.restype = None
+        _lib = L
+    return _lib
+
+
+class TodError(RuntimeError):
+    def __init__(self, status, what):
+        super().__init__("%s failed with todhip_status %d" % (what, status))
+        self.status = status
+
+
+def _check(rc, what):
+    if rc != OK:
+        raise TodError(rc, what)
+
+
+def _np_ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One HIP device + stream (todhip_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        _check(lib().todhip_create(C.c_int(device), C.c_void_p(stream), C.byref(self._h)), "todhip_create")
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            lib().todhip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return lib().todhip_stream(self._h)
+
+    def synchronize(self):
+        _check(lib().todhip_synchronize(self._h), "todhip_synchronize")
+
+    def counters(self):
+        c = Counters()
+        _check(lib().todhip_get_counters(self._h, C.byref(c)), "todhip_get_counters")
+        return c
+
+    def set_kernel_timing(self, enable):
+        _check(lib().todhip_set_kernel_timing(self._h, C.c_int(1 if enable else 0)), "todhip_set_kernel_timing")
+
+    # ---------------------------------------------------------------- stage B
+    def db_load(self, desc, pts, obj_off, shard_rank=0, shard_count=1):
+        """desc u8[N,B], pts f32[N,3], obj_off u32[n_obj+1] (rows of object o are obj_off[o]:obj_off[o+1])."""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        pts = np.ascontiguousarray(pts, np.float32)
+        obj_off = np.asarray(obj_off, np.int64)
+        n_obj = len(obj_off) - 1
+        objs = (TodObject * max(n_obj, 1))()
+        B = desc.shape[1] if desc.ndim == 2 else 32
+        for o in range(n_obj):
+            lo, hi = int(obj_off[o]), int(obj_off[o + 1])
+            objs[o].desc = desc.ctypes.data + lo * B
+            objs[o].pts_xyz = pts.ctypes.data + lo * 12
+            objs[o].n = hi - lo
+        spans = np.zeros(max(n_obj, 1), np.float32)
+        rc = lib().todhip_db_load(self._h, objs, C.c_uint32(n_obj), C.c_uint32(B), C.c_uint32(shard_rank),
+                                  C.c_uint32(shard_count), _np_ptr(spans))
+        _check(rc, "todhip_db_load")
+        return spans[:n_obj]
+
+    def db_info(self):
+        tot, first, rows, nobj = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        _check(lib().todhip_db_info(self._h, C.byref(tot), C.byref(first), C.byref(rows), C.byref(nobj)),
+               "todhip_db_info")
+        return dict(total_rows=tot.value, shard_first=first.value, shard_rows=rows.value, n_objs=nobj.value)
+
+    def match(self, q_desc, k, radius):
+        """Host-buffer form. Returns (row_ptr u32[nq+1], matches DMATCH[n], xyz f32[n,3])."""
+        q = np.ascontiguousarray(q_desc, np.uint8)
+        nq = q.shape[0]
+        row_ptr = np.zeros(nq + 1, np.uint32)
+        m = np.zeros(max(nq * k, 1), DMATCH_DTYPE)
+        xyz = np.zeros((max(nq * k, 1), 3), np.float32)
+        rc = lib().todhip_match(self._h, _np_ptr(q), C.c_uint32(nq), C.c_uint32(k), C.c_uint32(radius),
+                                _np_ptr(row_ptr), _np_ptr(m), _np_ptr(xyz))
+        _check(rc, "todhip_match")
+        n = int(row_ptr[nq])
+        return row_ptr, m[:n].copy(), xyz[:n].copy()
+
+    def match_device(self, d_q, nq, k, radius, d_counts, d_matches, d_xyz):
+        """Device-pointer form (ints from tensor.data_ptr())."""
+        rc = lib().todhip_match_device(self._h, C.c_void_p(d_q), C.c_uint32(nq), C.c_uint32(k), C.c_uint32(radius),
+                                       C.c_void_p(d_counts), C.c_void_p(d_matches), C.c_void_p(d_xyz))
+        _check(rc, "todhip_match_device")
+
+    def match_shard_device(self, d_q, nq, k, d_keys):
+        rc = lib().todhip_match_shard_device(self._h, C.c_void_p(d_q), C.c_uint32(nq), C.c_uint32(k),
+                                             C.c_void_p(d_keys))
+        _check(rc, "todhip_match_shard_device")
+
+    def merge_shards_device(self, d_keys_all, n_shards, nq, k, radius, d_counts, d_matches, d_xyz):
+        rc = lib().todhip_merge_shards_device(self._h, C.c_void_p(d_keys_all), C.c_uint32(n_shards), C.c_uint32(nq),
+                                              C.c_uint32(k), C.c_uint32(radius), C.c_void_p(d_counts),
+                                              C.c_void_p(d_matches), C.c_void_p(d_xyz))
+        _check(rc, "todhip_merge_shards_device")
+
+    # ---------------------------------------------------------------- stage C
+    def verify(self, kp_xy, cloud, row_ptr, matches, matches_xyz, spans, min_inliers, n_iter, err, rng,
+               max_poses=64):
+        kp = np.ascontiguousarray(kp_xy, np.float32)
+        cloud = np.ascontiguousarray(cloud, np.float32)
+        H, W = (cloud.shape[0], cloud.shape[1]) if cloud.ndim == 3 else (0, 0)
+        row_ptr = np.ascontiguousarray(row_ptr, np.uint32)
+        matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        mxyz = np.ascontiguousarray(matches_xyz, np.float32)
+        sp = np.ascontiguousarray(spans, np.float32)
+        prm = VerifyParams(min_inliers, n_iter, err)
+        poses = (Pose * max_poses)()
+        n_poses = C.c_uint32(max_poses)
+        cap = max(len(kp), 1) * max_poses
+        inl = np.zeros(cap, np.uint32)
+        n_inl = C.c_uint32(cap)
+        rc = lib().todhip_verify(self._h, _np_ptr(kp), C.c_uint32(len(kp)), _np_ptr(cloud), C.c_uint32(H),
+                                 C.c_uint32(W), _np_ptr(row_ptr), _np_ptr(matches), _np_ptr(mxyz), _np_ptr(sp),
+                                 C.c_uint32(len(sp)), C.byref(prm), C.byref(rng), poses, C.byref(n_poses),
+                                 _np_ptr(inl), C.byref(n_inl))
+        _check(rc, "todhip_verify")
+        out = []
+        for i in range(n_poses.value):
+            p = poses[i]
+            out.append(dict(object=int(p.object), R=np.array(p.R[:], np.float32).reshape(3, 3),
+                            t=np.array(p.t[:], np.float32), inliers=inl[p.inlier_begin:p.inlier_end].copy()))
+        return out
+
+    # ---------------------------------------------------------------- stage A
+    def orb(self, gray, n_features=1000, n_levels=3, scale_factor=1.2, pattern=None):
+        g = np.ascontiguousarray(gray, np.uint8)
+        H, W = g.shape
+        kp = np.zeros((n_features, 2), np.float32)
+        aux = np.zeros((n_features, 4), np.float32)
+        desc = np.zeros((n_features, 32), np.uint8)
+        n_out = C.c_uint32(n_features)
+        pat = None if pattern is None else np.ascontiguousarray(pattern, np.int8)
+        rc = lib().todhip_orb(self._h, _np_ptr(g), C.c_uint32(H), C.c_uint32(W), C.c_uint32(W),
+                              C.c_uint32(n_features), C.c_uint32(n_levels), C.c_float(scale_factor),
+                              None if pat is None else _np_ptr(pat), _np_ptr(kp), _np_ptr(aux), _np_ptr(desc),
+                              C.byref(n_out))
+        _check(rc, "todhip_orb")
+        n = n_out.value
+        return kp[:n].copy(), aux[:n].copy(), desc[:n].copy()
+
+
+def rng_new(seed=1):
+    r = Rng()
+    lib().todhip_rng_seed(C.byref(r), C.c_uint32(seed))
+    return r

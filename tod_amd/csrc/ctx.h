@@ -1,0 +1,107 @@
+// Internal context of libtodhip (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/todhip.h"
+
+#define TOD_HIP(call)                                  \
+  do {                                                 \
+    hipError_t e_ = (call);                            \
+    if (e_ != hipSuccess) {                            \
+      ctx->last_hip_error = (int)e_;                   \
+      return TODHIP_EHIP;                              \
+    }                                                  \
+  } while (0)
+
+// Growable device buffer: the hot path never calls hipMalloc once sizes have been seen.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Pinned host staging buffer.
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct todhip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int last_hip_error = 0;
+  int n_cu = 256;
+
+  // ---- object database (stage B1). Rows of this shard only; points + object table complete.
+  uint32_t desc_bytes = 0;
+  uint64_t total_rows = 0, shard_first = 0, shard_rows = 0;
+  uint32_t n_objs = 0;
+  DevBuf db_desc;          // shard_rows (+pad) x desc_bytes
+  DevBuf db_pts;           // total_rows x 3 f32
+  DevBuf db_obj_off;       // n_objs + 1 u32
+  std::vector<uint32_t> h_obj_off;
+  std::vector<float> h_spans;
+
+  // ---- matcher workspaces
+  DevBuf m_q, m_part, m_keys, m_counts, m_matches, m_xyz;
+  HostBuf h_stage;
+  // optional HIP-event bracketing of the dominant matcher kernel: a ring of event pairs that is
+  // drained lazily, so timing never adds a host sync inside the timed region
+  bool time_kernels = false;
+  static constexpr int kEvPairs = 64;
+  hipEvent_t evp[2 * kEvPairs] = {};
+  uint64_t ev_head = 0, ev_tail = 0;   // pairs [ev_tail, ev_head) are recorded and not yet read
+  todhip_counters counters = {};
+
+  // ---- verifier / ORB workspaces live in their own translation units
+  void* verify_ws = nullptr;
+  void* orb_ws = nullptr;
+};
+
+// match.hip
+int tod_timing_begin(todhip_ctx* ctx, int* slot);
+int tod_timing_end(todhip_ctx* ctx, int slot);
+int tod_timing_drain(todhip_ctx* ctx, uint64_t keep);
+int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_keys);
+int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
+                       uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz);
+// verify.hip / orb.hip
+void tod_verify_ws_free(todhip_ctx* ctx);
+void tod_orb_ws_free(todhip_ctx* ctx);

@@ -1,0 +1,303 @@
+// Stage B on gfx950: exact brute-force Hamming k-NN of the frame descriptors against the
+// device-resident object database, radius truncation, (imgIdx, trainIdx) resolution and the
+// match -> 3D gather.  Replaces DescriptorMatcher::process (reference
+// src/detection/DescriptorMatcher.cpp:195-252; the k-NN call at :211 is FLANN-LSH there,
+// an exact search with the order (distance asc, global row asc) here -- decision D1).
+//
+// K4  hamming_topk_tiles   one lane = one query descriptor held in 8 VGPRs; the DB rows of the
+//                          block's tile are wave-uniform, so they are fetched with scalar loads
+//                          (s_load_dwordx8 through the scalar cache) and every xor takes its DB
+//                          word straight from an SGPR: 8 v_xor + 8 accumulating v_bcnt per pair,
+//                          no LDS traffic and no cross-lane work in the inner loop. Each lane keeps
+//                          its k best (distance, row) keys in registers; four rows share one
+//                          min3/min/compare so the top-k test costs 0.75 VALU op per pair.
+// K4m merge_tiles_kernel   per query: merge the per-tile lists into k global keys.
+// K4f finalize_kernel      per query: merge shard lists, radius cut, object lookup, 3D gather.
+#include "ctx.h"
+
+namespace {
+
+constexpr int kWords = 8;          // 256-bit descriptors (ORB / rBRIEF), 32 bytes per row
+constexpr int kRowsPerIter = 4;
+constexpr int kLocalBits = 22;     // tile-local row index bits in a partial key (tile <= 4M rows)
+constexpr uint32_t kLocalMask = (1u << kLocalBits) - 1u;
+constexpr int kBlock = 256;
+
+template <int K>
+__device__ __forceinline__ void topk_insert(uint32_t (&best)[K], uint32_t key) {
+  // branch-free sorted insertion: key falls through the list, each slot keeps the smaller one
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    uint32_t lo = min(best[j], key);
+    key = max(best[j], key);
+    best[j] = lo;
+  }
+}
+
+// popcount with accumulate: v_bcnt_u32_b32 D = countbits(S0) + S1. Written as asm because the compiler
+// otherwise re-associates the chain into bcnt(x, 0) + v_add3 trees (3 extra VALU ops per row).
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+  uint32_t d;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+  return d;
+}
+
+struct RowGroup { uint32_t w[kRowsPerIter * kWords]; };
+
+// wave-uniform address -> s_load_dwordx16 x2 into SGPRs
+__device__ __forceinline__ RowGroup load_rows(const uint32_t* __restrict__ p) {
+  RowGroup g;
+#pragma unroll
+  for (int i = 0; i < kRowsPerIter * kWords; ++i) g.w[i] = p[i];
+  return g;
+}
+
+__device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[kWords], const uint32_t* row) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int w = 0; w < kWords; ++w) d = bcnt_acc(q[w] ^ row[w], d);
+  return d;
+}
+
+// grid.x = 8 * ceil(n_tiles/8) * q_blocks, XCD-aware decode (blocks b and b+8 share an XCD/L2):
+// consecutive slots of one XCD walk the query blocks of one DB tile, so a tile is pulled into one L2.
+template <int K>
+__global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __restrict__ db,
+                                                             const uint32_t* __restrict__ q, uint32_t n_rows,
+                                                             uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
+                                                             uint32_t n_tiles, uint32_t q_blocks,
+                                                             uint32_t* __restrict__ part) {
+  const uint32_t lin = blockIdx.x;
+  const uint32_t xcd = lin & 7u, slot = lin >> 3;
+  const uint32_t tile = (slot / q_blocks) * 8u + xcd;
+  const uint32_t qb = slot % q_blocks;
+  if (tile >= n_tiles) return;
+  const uint32_t qi = qb * kBlock + threadIdx.x;
+  const uint32_t qi_ld = qi < nq ? qi : (nq - 1);
+
+  uint32_t qd[kWords];
+  {
+    const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi_ld * kWords);
+    uint4 a = qp[0], b = qp[1];
+    qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w;
+    qd[4] = b.x; qd[5] = b.y; qd[6] = b.z; qd[7] = b.w;
+  }
+  uint32_t best[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) best[j] = 0xFFFFFFFFu;
+  uint32_t worst_d = 0xFFFFFFFFu >> kLocalBits;
+
+  const uint32_t row0 = tile * rows_per_tile;
+  const uint32_t row_end = min(n_rows, row0 + rows_per_tile);
+  const uint32_t n_local = row_end > row0 ? row_end - row0 : 0u;
+  const uint32_t* __restrict__ base = db + (size_t)row0 * kWords;
+
+  uint32_t r = 0;
+  const uint32_t n_groups = n_local / kRowsPerIter;
+  if (n_groups > 0) {
+    RowGroup cur = load_rows(base);
+    for (uint32_t g = 0; g < n_groups; ++g, r += kRowsPerIter) {
+      // prefetch the next group into a second SGPR set while this one is consumed (the last
+      // iteration re-reads its own group: always in bounds, result unused)
+      const uint32_t gn = (g + 1 < n_groups) ? g + 1 : g;
+      RowGroup nxt = load_rows(base + (size_t)gn * (kRowsPerIter * kWords));
+      uint32_t d0 = hamming256(qd, cur.w);
+      uint32_t d1 = hamming256(qd, cur.w + kWords);
+      uint32_t d2 = hamming256(qd, cur.w + 2 * kWords);
+      uint32_t d3 = hamming256(qd, cur.w + 3 * kWords);
+      uint32_t dmin = min(min(d0, d1), min(d2, d3));
+      if (__builtin_amdgcn_ballot_w64(dmin < worst_d) != 0ull) {
+        // rows are visited in ascending order, so a later row never displaces an equal distance:
+        // "key < best[K-1]" is exactly "d < worst_d" and insertion order inside the group is free.
+        topk_insert<K>(best, (d0 << kLocalBits) | r);
+        topk_insert<K>(best, (d1 << kLocalBits) | (r + 1));
+        topk_insert<K>(best, (d2 << kLocalBits) | (r + 2));
+        topk_insert<K>(best, (d3 << kLocalBits) | (r + 3));
+        worst_d = best[K - 1] >> kLocalBits;
+      }
+      cur = nxt;
+    }
+  }
+  for (; r < n_local; ++r) {
+    uint32_t d = hamming256(qd, base + (size_t)r * kWords);
+    topk_insert<K>(best, (d << kLocalBits) | r);
+  }
+  if (qi < nq) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) part[((size_t)tile * K + j) * nq_pad + qi] = best[j];
+  }
+}
+
+// K4m: one thread per query walks the tiles in ascending row order; keys become
+// (distance << 32 | global_row) so that shards can be merged by plain integer comparison.
+template <int K>
+__global__ __launch_bounds__(kBlock) void merge_tiles_kernel(const uint32_t* __restrict__ part, uint32_t nq,
+                                                             uint32_t nq_pad, uint32_t n_tiles,
+                                                             uint32_t rows_per_tile, uint64_t first_global_row,
+                                                             uint64_t* __restrict__ keys) {
+  const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
+  if (qi >= nq) return;
+  uint64_t best[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) best[j] = ~0ull;
+  for (uint32_t t = 0; t < n_tiles; ++t) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      uint32_t pk = part[((size_t)t * K + j) * nq_pad + qi];
+      if (pk == 0xFFFFFFFFu) break;
+      uint64_t key = ((uint64_t)(pk >> kLocalBits) << 32) |
+                     (first_global_row + (uint64_t)t * rows_per_tile + (pk & kLocalMask));
+      if (key >= best[K - 1]) break;    // the tile's list is ascending
+#pragma unroll
+      for (int s = 0; s < K; ++s) {
+        uint64_t lo = key < best[s] ? key : best[s];
+        key = key < best[s] ? best[s] : key;
+        best[s] = lo;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) keys[(size_t)qi * K + j] = best[j];
+}
+
+// K4f: merge the shard lists (layout [shard][nq][k]), truncate at the first distance > radius
+// (DescriptorMatcher.cpp:212-220), map the global row to (imgIdx, trainIdx) through the object prefix
+// sums (DB load order, :60-129) and gather the model point of every kept match (:231-244).
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __restrict__ keys_all, uint32_t n_shards,
+                                                          uint32_t nq, uint32_t k, uint32_t radius,
+                                                          const uint32_t* __restrict__ obj_off, uint32_t n_objs,
+                                                          const float* __restrict__ pts,
+                                                          uint32_t* __restrict__ counts,
+                                                          todhip_dmatch* __restrict__ matches,
+                                                          float* __restrict__ xyz) {
+  const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
+  if (qi >= nq) return;
+  uint32_t kept = 0;
+  uint64_t last = 0;
+  bool have_last = false;
+  for (uint32_t j = 0; j < k; ++j) {
+    // next key after `last`: every shard list is ascending and keys are unique (the row is part of the key),
+    // so each shard's candidate is its first key greater than `last`
+    uint64_t nxt = ~0ull;
+    for (uint32_t s = 0; s < n_shards; ++s) {
+      const uint64_t* lst = keys_all + ((size_t)s * nq + qi) * k;
+      for (uint32_t i = 0; i < k; ++i) {
+        uint64_t v = lst[i];
+        if (have_last && v <= last) continue;
+        if (v < nxt) nxt = v;
+        break;
+      }
+    }
+    if (nxt == ~0ull) break;
+    last = nxt;
+    have_last = true;
+    const uint32_t d = (uint32_t)(nxt >> 32);
+    if ((float)d > (float)radius) break;
+    const uint32_t row = (uint32_t)nxt;
+    uint32_t lo = 0, hi = n_objs;            // last object whose first row is <= row
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (obj_off[mid] <= row) lo = mid; else hi = mid;
+    }
+    todhip_dmatch m;
+    m.queryIdx = (int32_t)qi;
+    m.trainIdx = (int32_t)(row - obj_off[lo]);
+    m.imgIdx = (int32_t)lo;
+    m.distance = (float)d;
+    matches[(size_t)qi * k + kept] = m;
+    float* o = xyz + ((size_t)qi * k + kept) * 3;
+    o[0] = pts[(size_t)row * 3 + 0];
+    o[1] = pts[(size_t)row * 3 + 1];
+    o[2] = pts[(size_t)row * 3 + 2];
+    ++kept;
+  }
+  counts[qi] = kept;
+}
+
+template <int K>
+int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint64_t* d_keys) {
+  const uint32_t n_rows = (uint32_t)ctx->shard_rows;
+  const uint32_t q_blocks = (nq + kBlock - 1) / kBlock;
+  const uint32_t nq_pad = q_blocks * kBlock;
+  // enough blocks to fill 256 CUs x 8 resident 256-thread blocks in one pass
+  const uint32_t target_blocks = (uint32_t)ctx->n_cu * 8u;
+  uint32_t n_tiles = target_blocks / q_blocks;
+  if (n_tiles < 1) n_tiles = 1;
+  uint32_t rows_per_tile = (n_rows + n_tiles - 1) / n_tiles;
+  rows_per_tile = ((rows_per_tile + kRowsPerIter - 1) / kRowsPerIter) * kRowsPerIter;
+  if (rows_per_tile < 64) rows_per_tile = 64;
+  if (rows_per_tile > kLocalMask) return TODHIP_EINVAL;
+  n_tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
+  const uint32_t tiles8 = (n_tiles + 7u) / 8u;
+  TOD_HIP(ctx->m_part.reserve((size_t)n_tiles * K * nq_pad * sizeof(uint32_t)));
+  const uint32_t grid = tiles8 * 8u * q_blocks;
+  int slot = -1;
+  if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
+  hipLaunchKernelGGL(hamming_topk_tiles<K>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->db_desc.as<uint32_t>(),
+                     d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, q_blocks, ctx->m_part.as<uint32_t>());
+  if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
+  hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3(q_blocks), dim3(kBlock), 0, ctx->stream,
+                     ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, d_keys);
+  TOD_HIP(hipGetLastError());
+  return TODHIP_OK;
+}
+
+}  // namespace
+
+int tod_timing_drain(todhip_ctx* ctx, uint64_t keep) {
+  while (ctx->ev_head - ctx->ev_tail > keep) {
+    const int i = (int)(ctx->ev_tail % todhip_ctx::kEvPairs);
+    TOD_HIP(hipEventSynchronize(ctx->evp[2 * i + 1]));
+    float ms = 0.f;
+    TOD_HIP(hipEventElapsedTime(&ms, ctx->evp[2 * i], ctx->evp[2 * i + 1]));
+    ctx->counters.last_match_kernel_ms = ms;
+    ctx->counters.sum_match_kernel_ms += ms;
+    ctx->counters.n_match_kernel_launches += 1;
+    ++ctx->ev_tail;
+  }
+  return TODHIP_OK;
+}
+int tod_timing_begin(todhip_ctx* ctx, int* slot) {
+  int rc = tod_timing_drain(ctx, todhip_ctx::kEvPairs - 1);
+  if (rc != TODHIP_OK) return rc;
+  *slot = (int)(ctx->ev_head % todhip_ctx::kEvPairs);
+  TOD_HIP(hipEventRecord(ctx->evp[2 * *slot], ctx->stream));
+  return TODHIP_OK;
+}
+int tod_timing_end(todhip_ctx* ctx, int slot) {
+  TOD_HIP(hipEventRecord(ctx->evp[2 * slot + 1], ctx->stream));
+  ++ctx->ev_head;
+  return TODHIP_OK;
+}
+
+int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_keys) {
+  if (ctx->desc_bytes != 32) return TODHIP_EINVAL;
+  if (nq == 0) return TODHIP_OK;
+  if (ctx->shard_rows == 0) {   // an empty shard contributes only padding keys
+    TOD_HIP(hipMemsetAsync(d_keys, 0xFF, (size_t)nq * k * sizeof(uint64_t), ctx->stream));
+    return TODHIP_OK;
+  }
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(d_q);
+  switch (k) {
+    case 1: return launch_topk<1>(ctx, q, nq, d_keys);
+    case 2: return launch_topk<2>(ctx, q, nq, d_keys);
+    case 3: return launch_topk<3>(ctx, q, nq, d_keys);
+    case 4: return launch_topk<4>(ctx, q, nq, d_keys);
+    case 5: return launch_topk<5>(ctx, q, nq, d_keys);
+    case 6: return launch_topk<6>(ctx, q, nq, d_keys);
+    case 7: return launch_topk<7>(ctx, q, nq, d_keys);
+    case 8: return launch_topk<8>(ctx, q, nq, d_keys);
+    default: return TODHIP_EINVAL;
+  }
+}
+
+int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
+                       uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz) {
+  if (nq == 0) return TODHIP_OK;
+  const uint32_t blocks = (nq + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_keys_all, n_shards, nq, k, radius,
+                     ctx->db_obj_off.as<uint32_t>(), ctx->n_objs, ctx->db_pts.as<float>(), d_counts, d_matches,
+                     d_xyz);
+  TOD_HIP(hipGetLastError());
+  return TODHIP_OK;
+}

@@ -1,0 +1,91 @@
+"""Seeded synthetic workloads for the detection hot path.
+
+There is no dataset on the machines this runs on, so every test and bench input is generated
+here: an object database (descriptors + model points), camera frames (keypoints, descriptors,
+organised point cloud) with one visible object at a known pose, and grey images for stage A.
+All generators are numpy.random.Generator(PCG64(seed)) so results are reproducible anywhere.
+"""
+import numpy as np
+
+DB_SEED = 1001
+FRAME_SEED = 2000
+IMAGE_SEED = 3000
+
+POSE_RZ = 0.7
+POSE_T = np.array([0.05, -0.02, 0.8], np.float32)
+
+
+def pose_R():
+    c, s = np.cos(POSE_RZ), np.sin(POSE_RZ)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], np.float32)
+
+
+def make_db(n_objects, per_object=5000, desc_bytes=32, seed=DB_SEED):
+    """Returns (desc u8[N,desc_bytes], pts f32[N,3], obj_off u32[n_objects+1])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = n_objects * per_object
+    desc = rng.integers(0, 256, size=(n, desc_bytes), dtype=np.uint8)
+    pts = (rng.random((n, 3), dtype=np.float32) - 0.5) * np.array([0.20, 0.15, 0.10], np.float32)
+    obj_off = (np.arange(n_objects + 1, dtype=np.uint64) * per_object).astype(np.uint32)
+    return desc, pts.astype(np.float32), obj_off
+
+
+def make_db_ragged(sizes, desc_bytes=32, seed=DB_SEED):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = int(np.sum(sizes))
+    desc = rng.integers(0, 256, size=(n, desc_bytes), dtype=np.uint8)
+    pts = (rng.random((n, 3), dtype=np.float32) - 0.5) * np.array([0.20, 0.15, 0.10], np.float32)
+    obj_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    return desc, pts.astype(np.float32), obj_off
+
+
+def make_frame(desc, pts, obj_off, n_kp, frame=0, visible_object=0, H=480, W=640, f=525.0,
+               on_object=0.30, flip_p=0.08, noise=0.002, nan_frac=0.10):
+    """One camera frame. Returns dict(kp_xy f32[Q,2], q_desc u8[Q,B], cloud f32[H,W,3], truth_rows i64[Q])."""
+    rng = np.random.Generator(np.random.PCG64(FRAME_SEED + frame))
+    B = desc.shape[1]
+    n_on = int(round(n_kp * on_object))
+    lo, hi = int(obj_off[visible_object]), int(obj_off[visible_object + 1])
+    rows = rng.choice(np.arange(lo, hi), size=min(n_on, hi - lo), replace=False)
+    n_on = len(rows)
+    q_desc = rng.integers(0, 256, size=(n_kp, B), dtype=np.uint8)
+    flips = np.packbits(rng.random((n_on, B * 8)) < flip_p, axis=1, bitorder="little")
+    q_desc[:n_on] = desc[rows] ^ flips
+    R = pose_R()
+    xyz = np.empty((n_kp, 3), np.float32)
+    xyz[:n_on] = (pts[rows] @ R.T + POSE_T + rng.normal(0, noise, (n_on, 3))).astype(np.float32)
+    n_cl = n_kp - n_on
+    xyz[n_on:] = (rng.random((n_cl, 3)) * np.array([1.0, 0.8, 0.8]) + np.array([-0.5, -0.4, 0.6])).astype(np.float32)
+    u = np.clip(f * xyz[:, 0] / xyz[:, 2] + W / 2.0, 0, W - 1.001).astype(np.float32)
+    v = np.clip(f * xyz[:, 1] / xyz[:, 2] + H / 2.0, 0, H - 1.001).astype(np.float32)
+    perm = rng.permutation(n_kp)
+    u, v, xyz, q_desc = u[perm], v[perm], xyz[perm], q_desc[perm]
+    truth = np.full(n_kp, -1, np.int64)
+    truth[:n_on] = rows
+    truth = truth[perm]
+    cloud = np.full((H, W, 3), np.nan, np.float32)
+    nan_kp = rng.random(n_kp) < nan_frac
+    ok = ~nan_kp
+    cloud[v[ok].astype(np.int64), u[ok].astype(np.int64)] = xyz[ok]
+    kp_xy = np.stack([u, v], axis=1).astype(np.float32)
+    return dict(kp_xy=kp_xy, q_desc=q_desc, cloud=cloud, truth_rows=truth)
+
+
+def make_image(frame=0, H=480, W=640, n_rect=2000):
+    """Grey test image for stage A: mid-grey, random-contrast rectangles, sigma=2 Gaussian noise."""
+    rng = np.random.Generator(np.random.PCG64(IMAGE_SEED + frame))
+    img = np.full((H, W), 128.0, np.float32)
+    x0 = rng.integers(0, W, n_rect); y0 = rng.integers(0, H, n_rect)
+    w = rng.integers(4, 60, n_rect); h = rng.integers(4, 60, n_rect)
+    val = rng.integers(0, 256, n_rect)
+    for i in range(n_rect):
+        img[y0[i]:y0[i] + h[i], x0[i]:x0[i] + w[i]] = val[i]
+    img += rng.normal(0, 2.0, (H, W))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def random_graph_edges(n, p, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    iu = np.triu_indices(n, 1)
+    keep = rng.random(len(iu[0])) < p
+    return np.stack([iu[0][keep], iu[1][keep]], axis=1).astype(np.uint32)
