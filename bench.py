@@ -23,7 +23,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9            # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+# 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) issue at 16 lanes/clk/SIMD on gfx950: 4 cycles per
+# wave64 instruction, measured with tools/valu_peak.hip (profiles/r01_valu_peak_microbench.txt: 38-40 T lane-op/s).
+# Only f32 FMA is dual-rate, so SURVEY F11's 78.6 T figure does not apply to this kernel.
+VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9            # 39.3 T lane-op/s
 LANEOPS_PER_DISTANCE = 16                           # 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 per 256-bit pair
 
 

@@ -64,6 +64,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libtodhip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # PyTorch ships its own HIP runtime; when both live in one process (tests, bench) torch must bring
+        # the runtime up first, otherwise its later initialisation finds no device.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.todhip_stream.restype = C.c_void_p
         L.todhip_destroy.restype = None

@@ -192,11 +192,15 @@ int todhip_match_device(todhip_ctx* ctx, const void* d_q_desc, uint32_t nq, uint
   if (k == 0 || k > 8 || radius == 0) return TODHIP_EINVAL;   // radius 0: DescriptorMatcher.cpp:237 is UB there
   if (ctx->total_rows == 0) return TODHIP_ENODB;
   if (ctx->shard_rows != ctx->total_rows) return TODHIP_EINVAL; // sharded DBs use the two-step form
-  TOD_HIP(ctx->m_keys.reserve((size_t)std::max(nq, 1u) * k * sizeof(uint64_t)));
-  int rc = tod_match_shard_keys(ctx, d_q_desc, nq, k, ctx->m_keys.as<uint64_t>());
+  if (nq == 0) return TODHIP_OK;
+  // single device: the stage-1 merge lists go straight into the finalize kernel (lists == "shards")
+  TOD_HIP(ctx->m_keys.reserve(tod_match_lists_bytes(nq, k)));
+  uint32_t n_lists = 0;
+  int rc = tod_match_lists(ctx, d_q_desc, nq, k, ctx->m_keys.as<uint64_t>(), &n_lists);
   if (rc != TODHIP_OK) return rc;
-  rc = tod_match_finalize(ctx, ctx->m_keys.as<uint64_t>(), 1, nq, k, radius, reinterpret_cast<uint32_t*>(d_counts),
-                          reinterpret_cast<todhip_dmatch*>(d_matches), reinterpret_cast<float*>(d_matches_xyz));
+  rc = tod_match_finalize(ctx, ctx->m_keys.as<uint64_t>(), n_lists, nq, k, radius,
+                          reinterpret_cast<uint32_t*>(d_counts), reinterpret_cast<todhip_dmatch*>(d_matches),
+                          reinterpret_cast<float*>(d_matches_xyz));
   if (rc == TODHIP_OK) { ctx->counters.last_nq = nq; ctx->counters.last_k = k; }
   return rc;
 }

@@ -18,10 +18,13 @@
 namespace {
 
 constexpr int kWords = 8;          // 256-bit descriptors (ORB / rBRIEF), 32 bytes per row
-constexpr int kRowsPerIter = 4;
+constexpr int kGroupRows = 4;      // DB rows per SGPR group (two s_load_dwordx16)
 constexpr int kLocalBits = 22;     // tile-local row index bits in a partial key (tile <= 4M rows)
 constexpr uint32_t kLocalMask = (1u << kLocalBits) - 1u;
 constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kWavesPerCU = 16;    // grid is sized to be fully resident: 4 blocks of 4 waves per CU
+constexpr int kMergeGroups = 16;   // stage-1 merge fan-in
 
 template <int K>
 __device__ __forceinline__ void topk_insert(uint32_t (&best)[K], uint32_t key) {
@@ -42,37 +45,73 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
   return d;
 }
 
-struct RowGroup { uint32_t w[kRowsPerIter * kWords]; };
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
-// wave-uniform address -> s_load_dwordx16 x2 into SGPRs
-__device__ __forceinline__ RowGroup load_rows(const uint32_t* __restrict__ p) {
-  RowGroup g;
-#pragma unroll
-  for (int i = 0; i < kRowsPerIter * kWords; ++i) g.w[i] = p[i];
-  return g;
+// One SGPR group = kGroupRows (4) DB rows = two s_load_dwordx16. The loads are issued and waited for by
+// hand (asm): hipcc otherwise sinks a prefetch below its consumer. Scalar loads return out of order, so the
+// only usable wait is lgkmcnt(0); the ping-pong below always has exactly one group in flight when it waits.
+struct RowGroup { u32x16 lo, hi; };
+
+__device__ __forceinline__ void issue_rows(RowGroup& g, const uint32_t* p) {
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40"
+               : "=&s"(g.lo), "=&s"(g.hi) : "s"(p) : "memory");
+  __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the compute it overlaps with
+}
+__device__ __forceinline__ void wait_rows(RowGroup& g) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g.lo), "+s"(g.hi));
 }
 
-__device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[kWords], const uint32_t* row) {
+template <int HALF>
+__device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[kWords], const u32x16& rows) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int w = 0; w < kWords; ++w) d = bcnt_acc(q[w] ^ rows[HALF * kWords + w], d);
+  return d;
+}
+
+__device__ __forceinline__ uint32_t hamming256_mem(const uint32_t (&q)[kWords], const uint32_t* row) {
   uint32_t d = 0;
 #pragma unroll
   for (int w = 0; w < kWords; ++w) d = bcnt_acc(q[w] ^ row[w], d);
   return d;
 }
 
-// grid.x = 8 * ceil(n_tiles/8) * q_blocks, XCD-aware decode (blocks b and b+8 share an XCD/L2):
-// consecutive slots of one XCD walk the query blocks of one DB tile, so a tile is pulled into one L2.
+template <int K>
+__device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], const RowGroup& g, uint32_t r,
+                                              uint32_t (&best)[K], uint32_t& worst_d) {
+  uint32_t d0 = hamming256<0>(qd, g.lo);
+  uint32_t d1 = hamming256<1>(qd, g.lo);
+  uint32_t d2 = hamming256<0>(qd, g.hi);
+  uint32_t d3 = hamming256<1>(qd, g.hi);
+  uint32_t dmin = min(min(d0, d1), min(d2, d3));
+  if (__builtin_amdgcn_ballot_w64(dmin < worst_d) != 0ull) {
+    // rows are visited in ascending order, so a later row never displaces an equal distance:
+    // "key < best[K-1]" is exactly "d < worst_d" and insertion order inside the group is free.
+    topk_insert<K>(best, (d0 << kLocalBits) | r);
+    topk_insert<K>(best, (d1 << kLocalBits) | (r + 1));
+    topk_insert<K>(best, (d2 << kLocalBits) | (r + 2));
+    topk_insert<K>(best, (d3 << kLocalBits) | (r + 3));
+    worst_d = best[K - 1] >> kLocalBits;
+  }
+}
+
+// One WAVE = one work item (DB tile, group of 64 queries). Work items are numbered tile-major so the waves
+// of a block share a tile (scalar-cache / L2 locality); blocks b and b+8 share an XCD, and the decode below
+// gives each XCD a contiguous run of tiles.
 template <int K>
 __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __restrict__ db,
                                                              const uint32_t* __restrict__ q, uint32_t n_rows,
                                                              uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
-                                                             uint32_t n_tiles, uint32_t q_blocks,
+                                                             uint32_t n_tiles, uint32_t n_qw,
+                                                             uint32_t blocks_per_xcd,
                                                              uint32_t* __restrict__ part) {
-  const uint32_t lin = blockIdx.x;
-  const uint32_t xcd = lin & 7u, slot = lin >> 3;
-  const uint32_t tile = (slot / q_blocks) * 8u + xcd;
-  const uint32_t qb = slot % q_blocks;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t vblock = xcd * blocks_per_xcd + slot;                 // XCD-contiguous virtual block id
+  const uint32_t item = __builtin_amdgcn_readfirstlane(vblock * kWavesPerBlock + (threadIdx.x >> 6));
+  const uint32_t tile = item / n_qw, qw = item % n_qw;
   if (tile >= n_tiles) return;
-  const uint32_t qi = qb * kBlock + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t qi = qw * 64u + lane;
   const uint32_t qi_ld = qi < nq ? qi : (nq - 1);
 
   uint32_t qd[kWords];
@@ -92,34 +131,32 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
   const uint32_t n_local = row_end > row0 ? row_end - row0 : 0u;
   const uint32_t* __restrict__ base = db + (size_t)row0 * kWords;
 
+  // ping-pong SGPR groups: the load of group g+1 is in flight while group g is consumed
+  const uint32_t n_groups = n_local / kGroupRows;
   uint32_t r = 0;
-  const uint32_t n_groups = n_local / kRowsPerIter;
   if (n_groups > 0) {
-    RowGroup cur = load_rows(base);
-    for (uint32_t g = 0; g < n_groups; ++g, r += kRowsPerIter) {
-      // prefetch the next group into a second SGPR set while this one is consumed (the last
-      // iteration re-reads its own group: always in bounds, result unused)
-      const uint32_t gn = (g + 1 < n_groups) ? g + 1 : g;
-      RowGroup nxt = load_rows(base + (size_t)gn * (kRowsPerIter * kWords));
-      uint32_t d0 = hamming256(qd, cur.w);
-      uint32_t d1 = hamming256(qd, cur.w + kWords);
-      uint32_t d2 = hamming256(qd, cur.w + 2 * kWords);
-      uint32_t d3 = hamming256(qd, cur.w + 3 * kWords);
-      uint32_t dmin = min(min(d0, d1), min(d2, d3));
-      if (__builtin_amdgcn_ballot_w64(dmin < worst_d) != 0ull) {
-        // rows are visited in ascending order, so a later row never displaces an equal distance:
-        // "key < best[K-1]" is exactly "d < worst_d" and insertion order inside the group is free.
-        topk_insert<K>(best, (d0 << kLocalBits) | r);
-        topk_insert<K>(best, (d1 << kLocalBits) | (r + 1));
-        topk_insert<K>(best, (d2 << kLocalBits) | (r + 2));
-        topk_insert<K>(best, (d3 << kLocalBits) | (r + 3));
-        worst_d = best[K - 1] >> kLocalBits;
-      }
-      cur = nxt;
+    constexpr uint32_t kStride = kGroupRows * kWords;
+    RowGroup ga, gb;
+    issue_rows(ga, base);
+    wait_rows(ga);
+    uint32_t g = 0;
+    for (; g + 2 <= n_groups; g += 2) {
+      issue_rows(gb, base + (size_t)(g + 1) * kStride);
+      consume_group<K>(qd, ga, r, best, worst_d);
+      wait_rows(gb);
+      const uint32_t gn = (g + 2 < n_groups) ? g + 2 : g;      // the last pair re-reads an in-bounds group
+      issue_rows(ga, base + (size_t)gn * kStride);
+      consume_group<K>(qd, gb, r + kGroupRows, best, worst_d);
+      wait_rows(ga);
+      r += 2 * kGroupRows;
+    }
+    if (g < n_groups) {                                         // odd group count: ga holds group g
+      consume_group<K>(qd, ga, r, best, worst_d);
+      r += kGroupRows;
     }
   }
   for (; r < n_local; ++r) {
-    uint32_t d = hamming256(qd, base + (size_t)r * kWords);
+    uint32_t d = hamming256_mem(qd, base + (size_t)r * kWords);
     topk_insert<K>(best, (d << kLocalBits) | r);
   }
   if (qi < nq) {
@@ -128,36 +165,69 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
   }
 }
 
-// K4m: one thread per query walks the tiles in ascending row order; keys become
-// (distance << 32 | global_row) so that shards can be merged by plain integer comparison.
+// K4m: thread (query, group) merges the tiles t = group, group + G, ... ; keys become
+// (distance << 32 | global_row), unique per row, so any merge order gives the same k smallest.
+// Output layout [group][nq][K] == the [shard][nq][k] layout finalize_kernel consumes.
 template <int K>
 __global__ __launch_bounds__(kBlock) void merge_tiles_kernel(const uint32_t* __restrict__ part, uint32_t nq,
                                                              uint32_t nq_pad, uint32_t n_tiles,
                                                              uint32_t rows_per_tile, uint64_t first_global_row,
-                                                             uint64_t* __restrict__ keys) {
+                                                             uint32_t n_groups, uint64_t* __restrict__ keys) {
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
+  const uint32_t grp = blockIdx.y;
   if (qi >= nq) return;
   uint64_t best[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) best[j] = ~0ull;
-  for (uint32_t t = 0; t < n_tiles; ++t) {
+#pragma unroll 4
+  for (uint32_t t = grp; t < n_tiles; t += n_groups) {
+    uint32_t pk[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) pk[j] = part[((size_t)t * K + j) * nq_pad + qi];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      uint32_t pk = part[((size_t)t * K + j) * nq_pad + qi];
-      if (pk == 0xFFFFFFFFu) break;
-      uint64_t key = ((uint64_t)(pk >> kLocalBits) << 32) |
-                     (first_global_row + (uint64_t)t * rows_per_tile + (pk & kLocalMask));
-      if (key >= best[K - 1]) break;    // the tile's list is ascending
+      uint64_t key = pk[j] == 0xFFFFFFFFu
+                         ? ~0ull
+                         : (((uint64_t)(pk[j] >> kLocalBits) << 32) |
+                            (first_global_row + (uint64_t)t * rows_per_tile + (pk[j] & kLocalMask)));
 #pragma unroll
-      for (int s = 0; s < K; ++s) {
-        uint64_t lo = key < best[s] ? key : best[s];
-        key = key < best[s] ? best[s] : key;
-        best[s] = lo;
+      for (int s2 = 0; s2 < K; ++s2) {
+        uint64_t lo = key < best[s2] ? key : best[s2];
+        key = key < best[s2] ? best[s2] : key;
+        best[s2] = lo;
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < K; ++j) keys[(size_t)qi * K + j] = best[j];
+  for (int j = 0; j < K; ++j) keys[((size_t)grp * nq + qi) * K + j] = best[j];
+}
+
+// K4s: per query, the k smallest of n_lists ascending lists (layout [list][nq][k]) -> keys[nq][k].
+__global__ __launch_bounds__(kBlock) void select_keys_kernel(const uint64_t* __restrict__ lists, uint32_t n_lists,
+                                                             uint32_t nq, uint32_t k, uint64_t* __restrict__ keys) {
+  const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
+  if (qi >= nq) return;
+  uint64_t last = 0;
+  bool have_last = false;
+  for (uint32_t j = 0; j < k; ++j) {
+    uint64_t nxt = ~0ull;
+    for (uint32_t s = 0; s < n_lists; ++s) {
+      const uint64_t* lst = lists + ((size_t)s * nq + qi) * k;
+      for (uint32_t i = 0; i < k; ++i) {
+        uint64_t v = lst[i];
+        if (have_last && v <= last) continue;
+        if (v < nxt) nxt = v;
+        break;
+      }
+    }
+    keys[(size_t)qi * k + j] = nxt;
+    if (nxt == ~0ull) {
+      for (uint32_t jj = j + 1; jj < k; ++jj) keys[(size_t)qi * k + jj] = ~0ull;
+      break;
+    }
+    last = nxt;
+    have_last = true;
+  }
 }
 
 // K4f: merge the shard lists (layout [shard][nq][k]), truncate at the first distance > radius
@@ -215,30 +285,35 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __rest
 }
 
 template <int K>
-int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint64_t* d_keys) {
+int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint64_t* d_lists, uint32_t* n_lists) {
   const uint32_t n_rows = (uint32_t)ctx->shard_rows;
-  const uint32_t q_blocks = (nq + kBlock - 1) / kBlock;
-  const uint32_t nq_pad = q_blocks * kBlock;
-  // enough blocks to fill 256 CUs x 8 resident 256-thread blocks in one pass
-  const uint32_t target_blocks = (uint32_t)ctx->n_cu * 8u;
-  uint32_t n_tiles = target_blocks / q_blocks;
+  const uint32_t n_qw = (nq + 63u) / 64u;
+  const uint32_t nq_pad = n_qw * 64u;
+  // a fully resident grid (no second round of blocks): n_cu x kWavesPerCU waves, equal work per wave
+  const uint32_t target_waves = (uint32_t)ctx->n_cu * kWavesPerCU;
+  uint32_t n_tiles = target_waves / n_qw;
   if (n_tiles < 1) n_tiles = 1;
   uint32_t rows_per_tile = (n_rows + n_tiles - 1) / n_tiles;
-  rows_per_tile = ((rows_per_tile + kRowsPerIter - 1) / kRowsPerIter) * kRowsPerIter;
+  rows_per_tile = ((rows_per_tile + 2 * kGroupRows - 1) / (2 * kGroupRows)) * (2 * kGroupRows);
   if (rows_per_tile < 64) rows_per_tile = 64;
   if (rows_per_tile > kLocalMask) return TODHIP_EINVAL;
   n_tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
-  const uint32_t tiles8 = (n_tiles + 7u) / 8u;
+  const uint32_t items = n_tiles * n_qw;
+  const uint32_t blocks = (items + kWavesPerBlock - 1) / kWavesPerBlock;
+  const uint32_t blocks_per_xcd = (blocks + 7u) / 8u;
+  const uint32_t groups = n_tiles < (uint32_t)kMergeGroups ? n_tiles : (uint32_t)kMergeGroups;
   TOD_HIP(ctx->m_part.reserve((size_t)n_tiles * K * nq_pad * sizeof(uint32_t)));
-  const uint32_t grid = tiles8 * 8u * q_blocks;
   int slot = -1;
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
-  hipLaunchKernelGGL(hamming_topk_tiles<K>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->db_desc.as<uint32_t>(),
-                     d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, q_blocks, ctx->m_part.as<uint32_t>());
+  hipLaunchKernelGGL(hamming_topk_tiles<K>, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
+                     ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw,
+                     blocks_per_xcd, ctx->m_part.as<uint32_t>());
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
-  hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3(q_blocks), dim3(kBlock), 0, ctx->stream,
-                     ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, d_keys);
+  hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
+                     ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
+                     d_lists);
   TOD_HIP(hipGetLastError());
+  *n_lists = groups;
   return TODHIP_OK;
 }
 
@@ -270,25 +345,39 @@ int tod_timing_end(todhip_ctx* ctx, int slot) {
   return TODHIP_OK;
 }
 
-int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_keys) {
+// Per-query candidate lists of this shard: d_lists[n_lists][nq][k] (each ascending). n_lists <= kMergeGroups.
+int tod_match_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_lists, uint32_t* n_lists) {
   if (ctx->desc_bytes != 32) return TODHIP_EINVAL;
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(d_q);
+  switch (k) {
+    case 1: return launch_topk<1>(ctx, q, nq, d_lists, n_lists);
+    case 2: return launch_topk<2>(ctx, q, nq, d_lists, n_lists);
+    case 3: return launch_topk<3>(ctx, q, nq, d_lists, n_lists);
+    case 4: return launch_topk<4>(ctx, q, nq, d_lists, n_lists);
+    case 5: return launch_topk<5>(ctx, q, nq, d_lists, n_lists);
+    case 6: return launch_topk<6>(ctx, q, nq, d_lists, n_lists);
+    case 7: return launch_topk<7>(ctx, q, nq, d_lists, n_lists);
+    case 8: return launch_topk<8>(ctx, q, nq, d_lists, n_lists);
+    default: return TODHIP_EINVAL;
+  }
+}
+
+size_t tod_match_lists_bytes(uint32_t nq, uint32_t k) { return (size_t)kMergeGroups * nq * k * sizeof(uint64_t); }
+
+int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_keys) {
   if (nq == 0) return TODHIP_OK;
   if (ctx->shard_rows == 0) {   // an empty shard contributes only padding keys
     TOD_HIP(hipMemsetAsync(d_keys, 0xFF, (size_t)nq * k * sizeof(uint64_t), ctx->stream));
     return TODHIP_OK;
   }
-  const uint32_t* q = reinterpret_cast<const uint32_t*>(d_q);
-  switch (k) {
-    case 1: return launch_topk<1>(ctx, q, nq, d_keys);
-    case 2: return launch_topk<2>(ctx, q, nq, d_keys);
-    case 3: return launch_topk<3>(ctx, q, nq, d_keys);
-    case 4: return launch_topk<4>(ctx, q, nq, d_keys);
-    case 5: return launch_topk<5>(ctx, q, nq, d_keys);
-    case 6: return launch_topk<6>(ctx, q, nq, d_keys);
-    case 7: return launch_topk<7>(ctx, q, nq, d_keys);
-    case 8: return launch_topk<8>(ctx, q, nq, d_keys);
-    default: return TODHIP_EINVAL;
-  }
+  TOD_HIP(ctx->m_keys.reserve(tod_match_lists_bytes(nq, k)));
+  uint32_t n_lists = 0;
+  int rc = tod_match_lists(ctx, d_q, nq, k, ctx->m_keys.as<uint64_t>(), &n_lists);
+  if (rc != TODHIP_OK) return rc;
+  hipLaunchKernelGGL(select_keys_kernel, dim3((nq + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
+                     ctx->m_keys.as<uint64_t>(), n_lists, nq, k, d_keys);
+  TOD_HIP(hipGetLastError());
+  return TODHIP_OK;
 }
 
 int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
