@@ -123,6 +123,34 @@ int todhip_orb(todhip_ctx*, const uint8_t* gray, uint32_t H, uint32_t W, uint32_
                uint32_t n_levels, float scale_factor, const int8_t* pattern, float* kp_xy, float* kp_aux,
                uint8_t* desc, uint32_t* n_out);
 
+/* ---- diagnostics --------------------------------------------------------------------------------- */
+/* Per-RANSAC-round trace of the last todhip_verify call (what GuessGenerator.cpp:202 prints, plus the
+ * rand() stream position): `iterations` = iterations_ at loop exit (ransac.h:95-135). */
+typedef struct {
+  uint32_t object, iterations, best_iteration;
+  int32_t  best_count;
+  uint64_t draws_before, draws_after;
+  uint32_t n_inlier_kp, accepted;
+} todhip_round_trace;
+int todhip_verify_trace(const todhip_ctx*, todhip_round_trace* out, uint32_t* n /* capacity in, count out */);
+/* FillAdjacency (adjacency_ransac.cpp:127-172) alone: n matches (train/query n x 3, per-match keypoint pixel
+ * n x 2) -> physical and sample bit matrices, n rows of ceil(n/64) u64 words each. */
+int todhip_test_adjacency(todhip_ctx*, const float* train_xyz, const float* query_xyz, const float* kp_xy_per_match,
+                          uint32_t n, float span, float sensor_error, uint64_t* phys, uint64_t* samp);
+/* The verifier's clique search (maximum_clique.cpp:343-369, FindClique(minimal_size); 0xFFFFFFFF =
+ * FindMaximumClique) on an explicit graph of m <= 1024 vertices, as the reference's own gtests call it
+ * (test/test_maximum_clique.cpp:7-53). out3 = {clique size, internal error flag, search steps}. */
+int todhip_test_clique(todhip_ctx*, uint32_t m, const uint32_t* edges, uint32_t n_edges, uint32_t minimal_size,
+                       uint32_t* out3);
+
+/* FillAdjacency + selectWithinDistance (sac_model_registration_graph.h:171-269) for given sample triples
+ * (samples_ order): counts[t] = consensus size, 0 when the clique gate rejects. stop_level 1 skips the clique
+ * search (counts[t] = -|F| where it would have run). dbg (optional, dbg_stride u32 per triple): {count, |F|,
+ * then (F member, its degree in the induced graph) pairs}. */
+int todhip_test_consensus(todhip_ctx*, const float* train_xyz, const float* query_xyz, const float* kp_xy_per_match,
+                          uint32_t n, float span, float sensor_error, const uint32_t* triples, uint32_t n_triples,
+                          uint32_t stop_level, int32_t* counts, uint32_t* dbg, uint32_t dbg_stride);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,178 @@
+"""GPU parity of stage C (GuessGenerator + src/common verifier) through the C ABI, against the CPU oracle.
+Integer results (adjacency rows, clique sizes, per-round iteration counts, consensus sizes, rand() stream
+position, inlier keypoint lists) must be bit-exact; poses within 1e-3 (BASELINE.json north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from tod_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POSE_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+# ------------------------------------------------------------------------------------------ clique search
+@pytest.mark.parametrize("name", ["Graph1", "Graph2"])
+def test_clique_reference_gtests_on_gpu(ctx, name):
+    """reference test/test_maximum_clique.cpp:7-53 run on the HIP clique search"""
+    spec = json.load(open(os.path.join(GOLD, "clique_reference_tests.json")))[name]
+    n = spec["n"]
+    add = spec["add_edges"]
+    if add == "complete":
+        add = [(i, j) for i in range(n) for j in range(i + 1, n)]
+    dele = {tuple(sorted(e)) for e in spec["delete_edges"]}
+    edges = [e for e in add if tuple(sorted(e)) not in dele]
+    size, err, steps = ctx.test_clique(n, edges)
+    assert err == 0 and size == spec["expected_maximum_clique_size"]
+
+
+@pytest.mark.parametrize("minimal", [7, 0xFFFFFFFF])
+def test_clique_random_graphs_equal_oracle(ctx, minimal):
+    """sizes and step counts of FindClique on random graphs (sparse to near complete, with and without
+    colour-stack under-runs) must equal the CPU restatement"""
+    bad = []
+    for seed in range(120):
+        n = [8, 12, 20, 33, 64, 65, 100, 130, 200, 257][seed % 10]
+        p = [0.1, 0.3, 0.5, 0.7, 0.9, 0.97][seed % 6]
+        edges = synth.random_graph_edges(n, p, 100 + seed)
+        if len(edges) == 0:
+            continue
+        o_size, _, _, o_steps = O.clique(n, edges, minimal_size=minimal)
+        size, err, steps = ctx.test_clique(n, edges, minimal)
+        if (size, steps, err) != (o_size, o_steps, 0):
+            bad.append((seed, n, p, size, o_size, steps, o_steps, err))
+    assert not bad, bad[:10]
+
+
+# ------------------------------------------------------------------------------------------ FillAdjacency
+def _clusters_of(sc):
+    """ClusterPerObject on the host (plain gather) -> {obj: (train, query, qidx)}"""
+    out = {}
+    kp, cloud = sc["kp_xy"], sc["cloud"]
+    for qi in range(len(kp)):
+        p = cloud[int(kp[qi, 1]), int(kp[qi, 0])]
+        if np.isnan(p[0]):
+            continue
+        for m in range(sc["row_ptr"][qi], sc["row_ptr"][qi + 1]):
+            o = int(sc["matches"][m]["imgIdx"])
+            t, q, i = out.setdefault(o, ([], [], []))
+            t.append(sc["matches_xyz"][m]); q.append(p); i.append(qi)
+    return {o: (np.array(t, np.float32), np.array(q, np.float32), np.array(i, np.uint32)) for o, (t, q, i) in out.items()}
+
+
+@pytest.mark.parametrize("seed,n_kp", [(1, 120), (2, 400), (3, 900)])
+def test_adjacency_rows_bit_exact(ctx, seed, n_kp):
+    sc = synth.make_verify_scene(n_kp, visible=((1, 0.35), (3, 0.15)), seed=seed)
+    for obj, (t, q, qi) in _clusters_of(sc).items():
+        if len(qi) < 2:
+            continue
+        cl = O.Cluster(t, q, qi)
+        cl.fill(sc["kp_xy"], float(sc["spans"][obj]), 0.01)
+        phys, samp = ctx.test_adjacency(t, q, sc["kp_xy"][qi], float(sc["spans"][obj]), 0.01)
+        assert np.array_equal(phys, cl.bits(0)), ("physical", obj)
+        assert np.array_equal(samp, cl.bits(1)), ("sample", obj)
+
+
+def test_adjacency_nan_points_follow_reference_comparisons(ctx):
+    """NaN y/z coordinates pass the reference's `>` rejections (only .x is tested in ClusterPerObject)"""
+    sc = synth.make_verify_scene(200, seed=9)
+    t, q, qi = _clusters_of(sc)[1]
+    q = q.copy(); t = t.copy()
+    q[3, 1] = np.nan; q[10, 2] = np.inf; t[20, 0] = np.nan
+    cl = O.Cluster(t, q, qi)
+    cl.fill(sc["kp_xy"], float(sc["spans"][1]), 0.01)
+    phys, samp = ctx.test_adjacency(t, q, sc["kp_xy"][qi], float(sc["spans"][1]), 0.01)
+    assert np.array_equal(phys, cl.bits(0)) and np.array_equal(samp, cl.bits(1))
+
+
+# ------------------------------------------------------------------------------------------ whole frames
+def _compare_frame(ctx, sc, min_inliers, n_iter, err=0.01, seed=1):
+    rng_o = O.rng_new(seed)
+    rc, o_poses, o_rounds = O.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"],
+                                     sc["spans"], min_inliers, n_iter, err, rng_o)
+    assert rc == 0
+    rng_g = capi.rng_new(seed)
+    g_poses = ctx.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"],
+                         min_inliers, n_iter, err, rng_g)
+    g_rounds = ctx.verify_trace()
+    # the oracle also traces rounds of objects with < 3 matches (no draws, no iterations); the GPU path skips them
+    o_rounds = [r for r in o_rounds if not (r.iterations == 0 and r.draws_after == r.draws_before and r.best_count == 0)]
+    g_rounds = [r for r in g_rounds if not (r.iterations == 0 and r.draws_after == r.draws_before)]
+    assert len(g_rounds) == len(o_rounds)
+    for g, o in zip(g_rounds, o_rounds):
+        assert (g.iterations, g.best_iteration, g.best_count, g.draws_before, g.draws_after) == \
+               (o.iterations, o.best_iteration, o.best_count, o.draws_before, o.draws_after)
+    assert rng_g.draws == rng_o.draws and list(rng_g.s) == list(rng_o.s) and (rng_g.f, rng_g.b) == (rng_o.f, rng_o.b)
+    assert len(g_poses) == len(o_poses)
+    for g, o in zip(g_poses, o_poses):
+        assert g["object"] == o["object"]
+        assert np.array_equal(g["inliers"], o["inliers"])
+        assert np.abs(g["R"] - o["R"]).max() < POSE_TOL and np.abs(g["t"] - o["t"]).max() < POSE_TOL
+    return g_poses, g_rounds
+
+
+def test_frame_single_object(ctx):
+    sc = synth.make_verify_scene(300, visible=((1, 0.30),), seed=300)
+    poses, rounds = _compare_frame(ctx, sc, 8, 500)
+    assert len(poses) == 1 and poses[0]["object"] == 1
+    R, t = sc["poses"][1]
+    assert np.abs(poses[0]["R"] - R).max() < 0.05 and np.abs(poses[0]["t"] - t).max() < 0.02
+
+
+def test_frame_two_objects_many_rounds(ctx):
+    sc = synth.make_verify_scene(500, visible=((1, 0.30), (4, 0.20)), seed=500)
+    poses, rounds = _compare_frame(ctx, sc, 8, 500)
+    assert sorted(p["object"] for p in poses) == [1, 4] and len(rounds) >= 6
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_frame_variants(ctx, seed):
+    cfgs = [dict(n_kp=150, visible=((0, 0.5),), matches_per_kp=2),
+            dict(n_kp=250, visible=((2, 0.2), (5, 0.2), (3, 0.2)), matches_per_kp=3),
+            dict(n_kp=400, visible=((1, 0.4),), matches_per_kp=5, true_match_rank=4),
+            dict(n_kp=80, visible=(), matches_per_kp=5),                 # clutter only: no pose, many failed draws
+            dict(n_kp=600, visible=((1, 0.25),), matches_per_kp=1, n_objects=2),
+            dict(n_kp=350, visible=((1, 0.3),), matches_per_kp=5, noise=0.006)]
+    sc = synth.make_verify_scene(seed=40 + seed, **cfgs[seed])
+    _compare_frame(ctx, sc, [8, 6, 15, 8, 8, 8][seed], [300, 1000, 200, 100, 400, 300][seed])
+
+
+def test_c1_shape_frame_via_matcher(ctx):
+    """BASELINE configs[0] end to end: ORB-500 frame, 1-object DB, k=5, radius 35, iterations 2500, min_inliers 8"""
+    desc, pts, off = synth.make_db(1)
+    fr = synth.make_frame(desc, pts, off, 500)
+    spans = ctx.db_load(desc, pts, off)
+    row_ptr, m, xyz = ctx.match(fr["q_desc"], 5, 35)
+    sc = dict(kp_xy=fr["kp_xy"], cloud=fr["cloud"], row_ptr=row_ptr, matches=m, matches_xyz=xyz, spans=spans)
+    poses, rounds = _compare_frame(ctx, sc, 8, 2500)
+    assert len(poses) == 1
+    assert np.abs(poses[0]["R"] - synth.pose_R()).max() < 0.03 and np.abs(poses[0]["t"] - synth.POSE_T).max() < 0.01
+
+
+def test_empty_and_degenerate_inputs(ctx):
+    sc = synth.make_verify_scene(50, seed=1)
+    rng = capi.rng_new(1)
+    # no point cloud: the 2D-only branch is an empty TODO in the reference (GuessGenerator.cpp:147-152)
+    assert ctx.verify(sc["kp_xy"], np.zeros((0, 0, 3), np.float32), sc["row_ptr"], sc["matches"], sc["matches_xyz"],
+                      sc["spans"], 8, 100, 0.01, rng) == []
+    assert rng.draws == 0
+    # no matches at all
+    rp = np.zeros(51, np.uint32)
+    assert ctx.verify(sc["kp_xy"], sc["cloud"], rp, sc["matches"][:0], sc["matches_xyz"][:0], sc["spans"], 8, 100,
+                      0.01, rng) == []
+    # keypoint outside the cloud
+    kp = sc["kp_xy"].copy(); kp[0, 0] = 10000
+    with pytest.raises(capi.TodError) as e:
+        ctx.verify(kp, sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 100, 0.01, rng)
+    assert e.value.status == capi.ERANGE

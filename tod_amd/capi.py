@@ -35,6 +35,12 @@ class Pose(C.Structure):
                 ("inlier_begin", C.c_uint32), ("inlier_end", C.c_uint32)]
 
 
+class RoundTrace(C.Structure):
+    _fields_ = [("object", C.c_uint32), ("iterations", C.c_uint32), ("best_iteration", C.c_uint32),
+                ("best_count", C.c_int32), ("draws_before", C.c_uint64), ("draws_after", C.c_uint64),
+                ("n_inlier_kp", C.c_uint32), ("accepted", C.c_uint32)]
+
+
 class Counters(C.Structure):
     _fields_ = [("db_rows", C.c_uint64), ("db_objects", C.c_uint64), ("last_nq", C.c_uint32), ("last_k", C.c_uint32),
                 ("last_matches", C.c_uint32), ("last_objects_verified", C.c_uint32), ("last_rounds", C.c_uint32),
@@ -48,7 +54,8 @@ EXPORTS = [
     "todhip_version", "todhip_create", "todhip_destroy", "todhip_stream", "todhip_last_hip_error",
     "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_db_load", "todhip_db_info",
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device",
-    "todhip_rng_seed", "todhip_verify", "todhip_orb",
+    "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
+    "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus",
 ]
 
 _lib = None
@@ -212,6 +219,47 @@ class Context:
             out.append(dict(object=int(p.object), R=np.array(p.R[:], np.float32).reshape(3, 3),
                             t=np.array(p.t[:], np.float32), inliers=inl[p.inlier_begin:p.inlier_end].copy()))
         return out
+
+    def verify_trace(self, cap=4096):
+        arr = (RoundTrace * cap)()
+        n = C.c_uint32(cap)
+        _check(lib().todhip_verify_trace(self._h, arr, C.byref(n)), "todhip_verify_trace")
+        return [arr[i] for i in range(n.value)]
+
+    def test_adjacency(self, train, query, kp_per_match, span, err):
+        t = np.ascontiguousarray(train, np.float32)
+        q = np.ascontiguousarray(query, np.float32)
+        kp = np.ascontiguousarray(kp_per_match, np.float32)
+        n = len(t)
+        W = (n + 63) // 64
+        phys = np.zeros((n, W), np.uint64)
+        samp = np.zeros((n, W), np.uint64)
+        rc = lib().todhip_test_adjacency(self._h, _np_ptr(t), _np_ptr(q), _np_ptr(kp), C.c_uint32(n), C.c_float(span),
+                                         C.c_float(err), _np_ptr(phys), _np_ptr(samp))
+        _check(rc, "todhip_test_adjacency")
+        return phys, samp
+
+    def test_consensus(self, train, query, kp_per_match, span, err, triples, stop_level=0, dbg_stride=0):
+        t = np.ascontiguousarray(train, np.float32)
+        q = np.ascontiguousarray(query, np.float32)
+        kp = np.ascontiguousarray(kp_per_match, np.float32)
+        tr = np.ascontiguousarray(triples, np.uint32).reshape(-1, 3)
+        counts = np.zeros(len(tr), np.int32)
+        dbg = np.zeros((len(tr), dbg_stride), np.uint32) if dbg_stride else None
+        rc = lib().todhip_test_consensus(self._h, _np_ptr(t), _np_ptr(q), _np_ptr(kp), C.c_uint32(len(t)),
+                                         C.c_float(span), C.c_float(err), _np_ptr(tr), C.c_uint32(len(tr)),
+                                         C.c_uint32(stop_level), _np_ptr(counts),
+                                         None if dbg is None else _np_ptr(dbg), C.c_uint32(dbg_stride))
+        _check(rc, "todhip_test_consensus")
+        return counts, dbg
+
+    def test_clique(self, m, edges, minimal_size=0xFFFFFFFF):
+        e = np.ascontiguousarray(np.asarray(edges, np.uint32).reshape(-1, 2))
+        out = np.zeros(3, np.uint32)
+        rc = lib().todhip_test_clique(self._h, C.c_uint32(m), _np_ptr(e), C.c_uint32(len(e)),
+                                      C.c_uint32(minimal_size), _np_ptr(out))
+        _check(rc, "todhip_test_clique")
+        return int(out[0]), int(out[1]), int(out[2])
 
     # ---------------------------------------------------------------- stage A
     def orb(self, gray, n_features=1000, n_levels=3, scale_factor=1.2, pattern=None):

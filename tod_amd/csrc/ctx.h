@@ -90,6 +90,8 @@ struct todhip_ctx {
   uint64_t ev_head = 0, ev_tail = 0;   // pairs [ev_tail, ev_head) are recorded and not yet read
   todhip_counters counters = {};
 
+  std::vector<todhip_round_trace> traces;
+
   // ---- verifier / ORB workspaces live in their own translation units
   void* verify_ws = nullptr;
   void* orb_ws = nullptr;

@@ -1,9 +1,1356 @@
-// placeholder: replaced by the stage C implementation
+// Stage C on gfx950: GuessGenerator::process (reference src/detection/GuessGenerator.cpp:127-250) and the
+// verifier library under src/common (adjacency_ransac.cpp, sac_model_registration_graph.h, ransac.h,
+// maximum_clique.cpp). Decisions D2-D4 of SURVEY.md App. A apply.
+//
+// Kernels
+//   K6  adjacency_kernel     FillAdjacency (adjacency_ransac.cpp:127-172): one wave = 64 pair tests -> one
+//                            64-bit word of the physical and of the sample bit matrix via __ballot
+//   K7a draw_table_kernel    drawIndexSampleHelper (sac_model_registration_graph.h:102-132) evaluated
+//                            speculatively from EVERY position of the rand() stream window, one wave each
+//   K7b chain_kernel         getSamples (:141-168) x iterations: pointer chase through the table
+//   K8  eval_kernel          selectWithinDistance (:171-269): 3-row AND + popcount, degree filter and the
+//                            maximum-clique gate (maximum_clique.cpp:286-369) on an LDS-resident induced graph
+//   K9  growth_kernel        Ransac's refinement loop (adjacency_ransac.cpp:255-308) incl. Kabsch/SVD (:304-347)
+//   K11 invalidate_kernel    InvalidateQueryIndices / InvalidateIndices (:63-123)
+// The RANSAC bookkeeping (ransac.h:95-135: strictly-better test, adaptive k with pow/log) is replayed on the
+// host from the per-iteration consensus counts, so that libm results are those of the CPU reference.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <vector>
+
 #include "ctx.h"
-void tod_verify_ws_free(todhip_ctx*) {}
-extern "C" {
-void todhip_rng_seed(todhip_rng* r, uint32_t) { (void)r; }
-int todhip_verify(todhip_ctx*, const float*, uint32_t, const float*, uint32_t, uint32_t, const uint32_t*,
-                  const todhip_dmatch*, const float*, const float*, uint32_t, const todhip_verify_params*, todhip_rng*,
-                  todhip_pose*, uint32_t*, uint32_t*, uint32_t*) { return TODHIP_EINVAL; }
+#include "verify_kernels.h"
+
+using namespace tod;
+
+namespace {
+
+#define TOD_DBG(...) do { if (getenv("TODHIP_DEBUG")) { fprintf(stderr, "[todhip] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+
+// ------------------------------------------------------------------------------------------------ K6
+__global__ __launch_bounds__(256) void adjacency_kernel(ObjJob job, float span, float err) {
+  const uint32_t i = blockIdx.x;
+  const uint32_t word = blockIdx.y * 4u + (threadIdx.x >> 6);
+  if (word >= job.W) return;
+  const uint32_t j = word * 64u + lane_id();
+  bool phys = false, samp = false;
+  if (j < job.n && j != i) {
+    const uint32_t lo = min(i, j), hi = max(i, j);       // the reference visits each pair once with i < j
+    float dq = dist_sq3(job.query + 3 * lo, job.query + 3 * hi);
+    const float lim = (span + 2 * err) * (span + 2 * err);
+    if (!(dq > lim)) {                                    // adjacency_ransac.cpp:144
+      dq = sqrtf(dq);
+      const float* t1 = job.train + 3 * lo;
+      const float* t2 = job.train + 3 * hi;
+      const float dt = (float)norm3d(t1[0] - t2[0], t1[1] - t2[1], t1[2] - t2[2]);
+      const float a = fabsf(dt - dq);
+      if (!(a > 4 * err)) {                               // :151
+        phys = true;
+        const float* k1 = job.kpxy + 2 * lo;
+        const float* k2 = job.kpxy + 2 * hi;
+        const float px = (k1[0] - k2[0]) * (k1[0] - k2[0]) + (k1[1] - k2[1]) * (k1[1] - k2[1]);
+        samp = (px > 20 * 20) && (a < 2 * err);           // :158-161
+      }
+    }
+  }
+  const u64 pb = __ballot(phys), sb = __ballot(samp);
+  if (lane_id() == 0) {
+    job.phys[(size_t)i * job.W + word] = pb;
+    job.samp[(size_t)i * job.W + word] = sb;
+  }
 }
+
+__global__ __launch_bounds__(256) void finite_kernel(ObjJob job) {
+  const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+  bool f = false;
+  if (v < job.n) {
+    f = true;
+    for (int c = 0; c < 3; ++c) f = f && isfinite(job.train[3 * v + c]) && isfinite(job.query[3 * v + c]);
+  }
+  const u64 b = __ballot(f);
+  const uint32_t word = v >> 6;
+  if (lane_id() == 0 && word < job.W) {
+    job.finite[word] = b;
+    const uint32_t base = word * 64u;
+    job.valid[word] = base + 64u <= job.n ? ~0ull : (base < job.n ? ((1ull << (job.n - base)) - 1ull) : 0ull);
+  }
+}
+
+// per round: sample degree inside the valid set, the ">= 7" filter mask (:211-213), |valid|
+__global__ __launch_bounds__(256) void round_prep_kernel(ObjJob job, uint32_t* nvalid) {
+  const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+  bool isv = false;
+  uint32_t d = 0;
+  if (v < job.n) {
+    isv = (job.valid[v >> 6] >> (v & 63u)) & 1ull;
+    if (isv)
+      for (uint32_t w = 0; w < job.W; ++w) d += (uint32_t)__popcll(job.samp[(size_t)v * job.W + w] & job.valid[w]);
+    job.sampdeg[v] = d;
+  }
+  const u64 b7 = __ballot(isv && d >= kGateMinimal), bv = __ballot(isv);
+  if (lane_id() == 0 && (v >> 6) < job.W) {
+    job.deg7[v >> 6] = b7;
+    if (bv) atomicAdd(nvalid, (uint32_t)__popcll(bv));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K7a
+__global__ __launch_bounds__(256) void draw_table_kernel(ObjJob job, const uint32_t* __restrict__ rnd,
+                                                         uint32_t window_len, uint32_t S, DrawEntry* table) {
+  const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (s >= S) return;
+  const uint32_t W = job.W;
+  WaveBits VA;
+  wb_load(VA, job.valid, W);
+  uint32_t nA = wb_count(VA);
+  uint32_t pos = s, status = DRAW_FAIL, s0 = 0, s1 = 0, s2 = 0;
+  while (nA > 0) {                                        // level "3 samples left"
+    if (pos >= window_len) { status = DRAW_OVERFLOW; break; }
+    const uint32_t a = wb_select(VA, rnd[pos++] % nA);    // valid_samples[rand() % size], :111
+    if (a >= job.n) break;                                // cannot happen; keeps every address in bounds
+    WaveBits VB = VA;
+    wb_and(VB, job.samp + (size_t)a * W, W);              // set_intersection with the sample neighbours, :113-117
+    uint32_t nB = wb_count(VB);
+    bool ok = false;
+    uint32_t b = 0, c = 0;
+    while (nB > 0) {                                      // level "2 samples left"
+      if (pos >= window_len) { status = DRAW_OVERFLOW; break; }
+      b = wb_select(VB, rnd[pos++] % nB);
+      if (b >= job.n) { nB = 0; break; }
+      WaveBits VC = VB;
+      wb_and(VC, job.samp + (size_t)b * W, W);
+      const uint32_t nC = wb_count(VC);
+      if (nC > 0) {                                       // level "1 sample left": any pick succeeds
+        if (pos >= window_len) { status = DRAW_OVERFLOW; break; }
+        c = wb_select(VC, rnd[pos++] % nC);
+        ok = true;
+        break;
+      }
+      wb_clear(VB, b);                                    // std::remove of the failed pick, :125-128
+      --nB;
+    }
+    if (status == DRAW_OVERFLOW) break;
+    if (ok) { status = DRAW_OK; s0 = c; s1 = b; s2 = a; break; }   // samples_ is deepest-first, :118-121
+    wb_clear(VA, a);
+    --nA;
+  }
+  if (lane_id() == 0) {
+    DrawEntry e;
+    e.status = status; e.consumed = pos - s; e.s0 = s0; e.s1 = s1; e.s2 = s2; e.pad = 0;
+    table[s] = e;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K7b
+__global__ void chain_kernel(const DrawEntry* __restrict__ table, uint32_t S, uint32_t n_req, uint32_t attempts0,
+                             uint32_t out_base, uint32_t* iter_samples, uint32_t* iter_pos_after, ChainOut* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  uint32_t p = 0, done = 0, attempts = attempts0, flag = 0;
+  while (done < n_req) {
+    bool got = false;
+    while (true) {
+      if (p >= S) { flag = 1; break; }
+      const DrawEntry e = table[p];
+      if (e.status == DRAW_OVERFLOW) { flag = 1; break; }
+      p += e.consumed;
+      if (e.status == DRAW_OK) {
+        iter_samples[3 * (out_base + done) + 0] = e.s0;
+        iter_samples[3 * (out_base + done) + 1] = e.s1;
+        iter_samples[3 * (out_base + done) + 2] = e.s2;
+        iter_pos_after[out_base + done] = p;
+        got = true;
+        break;
+      }
+      if (++attempts >= kMaxSampleChecks) { flag = 2; break; }   // getSamples gives up: samples.clear(), :167
+    }
+    if (!got) break;
+    attempts = 0;
+    ++done;
+  }
+  out->n_done = done; out->pos_end = p; out->attempts = attempts; out->flag = flag;
+}
+
+// ------------------------------------------------------------------------------------------------ K8
+struct GateLds {
+  u64* adjc;                                   // m x MW induced sample adjacency, graph index = rank in F
+  u64* mask;                                   // MW
+  uint16_t *flist, *cur, *nxt, *tmp;           // m each
+  uint32_t *C, *deg, *keys;                    // m each
+  uint32_t *S, *SOld, *lbase, *lsize, *lcap;   // m + 2 each
+};
+__host__ __device__ inline uint32_t gate_lds_bytes(uint32_t m) {
+  const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;      // ma >= m + 2
+  return 8u * m * MW + 8u * MW + 8u * 4u * ma + 4u * 2u * ma + 64u;
+}
+__device__ inline GateLds gate_carve(unsigned char* base, uint32_t m) {
+  const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;
+  GateLds L;
+  L.adjc = reinterpret_cast<u64*>(base); base += 8u * m * MW;
+  L.mask = reinterpret_cast<u64*>(base); base += 8u * MW;
+  L.C = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
+  L.deg = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
+  L.keys = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
+  L.S = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
+  L.SOld = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
+  L.lbase = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
+  L.lsize = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
+  L.lcap = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
+  L.flist = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
+  L.cur = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
+  L.nxt = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
+  L.tmp = reinterpret_cast<uint16_t*>(base);
+  return L;
+}
+
+__device__ __forceinline__ bool row_test(u64 roww, uint32_t h) {   // roww: lane l holds word l of the row
+  const u64 wv = shfl64(roww, h >> 6);
+  return (wv >> (h & 63u)) & 1ull;
+}
+
+// DegreeSort (maximum_clique.cpp:263-284): (degree inside the list, vertex) ascending, then reversed.
+// deg[] must hold the degree of list[i] at position i. Rank by counting; keys are unique.
+__device__ void rank_sort_desc(uint16_t* list, uint16_t* tmp, const uint32_t* deg, uint32_t r, uint32_t* keys) {
+  const uint32_t l = lane_id();
+  for (uint32_t i = l; i < r; i += 64u) keys[i] = (deg[i] << 16) | list[i];
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < r; i0 += 64u) {
+    const uint32_t i = i0 + l;
+    const uint32_t mine = i < r ? keys[i] : 0u;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < r; ++j) rank += keys[j] > mine;
+    if (i < r) tmp[rank] = (uint16_t)(mine & 0xFFFFu);
+  }
+  __syncthreads();
+  for (uint32_t i = l; i < r; i += 64u) list[i] = tmp[i];
+  __syncthreads();
+}
+
+// degrees of the members of list[0..r) inside the list, into L.deg[0..r)
+__device__ void degrees_in_list(const GateLds& L, const uint16_t* list, uint32_t r, uint32_t MW) {
+  const uint32_t l = lane_id();
+  if (l < MW) L.mask[l] = 0ull;
+  __syncthreads();
+  for (uint32_t i = l; i < r; i += 64u) atomicOr(&L.mask[list[i] >> 6], 1ull << (list[i] & 63u));
+  __syncthreads();
+  for (uint32_t i = l; i < r; i += 64u) {
+    const u64* row = L.adjc + (size_t)list[i] * MW;
+    uint32_t d = 0;
+    for (uint32_t w = 0; w < MW; ++w) d += (uint32_t)__popcll(row[w] & L.mask[w]);
+    L.deg[i] = d;
+  }
+  __syncthreads();
+}
+
+// ColorSort (maximum_clique.cpp:219-261) on list[0..r), writing colours into the shared array C by absolute
+// position (decision D3). With min_k == 1 every vertex joins a class and first-fit colouring in list order
+// equals colouring class by class (each class = greedy independent set in list order), which is what the
+// bit-parallel loop below does. With min_k >= 2 class 1 is never filled (:242-245), so every vertex gets
+// k = 1 < min_k, the order is unchanged and only C[r-1] = 0 is written (:247-248).
+__device__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW, uint32_t qmax, uint32_t qsz) {
+  const uint32_t l = lane_id();
+  const int min_k = max(1, (int)qmax - (int)qsz + 1);
+  if (min_k >= 2) {
+    if (l == 0) L.C[r - 1] = 0u;
+    __syncthreads();
+    return;
+  }
+  const uint32_t nchunks = (r + 63u) / 64u;
+  u64 uncol = 0ull;                                        // lane c holds positions [64c, 64c + 64)
+  if (l < nchunks) uncol = (l * 64u + 64u <= r) ? ~0ull : ((1ull << (r - l * 64u)) - 1ull);
+  uint32_t k = 1, outpos = 0;
+  while (__ballot(uncol != 0ull) != 0ull) {
+    u64 Q = uncol;
+    while (true) {
+      const u64 balQ = __ballot(Q != 0ull);
+      if (balQ == 0ull) break;
+      const uint32_t ll = (uint32_t)__ffsll((long long)balQ) - 1u;
+      const u64 wq = shfl64(Q, ll);
+      const uint32_t bit = uni((uint32_t)__ffsll((long long)wq) - 1u);
+      const uint32_t g = uni(list[ll * 64u + bit]);
+      if (l == 0) { L.tmp[outpos] = (uint16_t)g; L.C[outpos] = k; }
+      ++outpos;
+      if (l == ll) { uncol &= ~(1ull << bit); Q &= ~(1ull << bit); }
+      const u64 roww = l < MW ? L.adjc[(size_t)g * MW + l] : 0ull;
+      for (uint32_t c = 0; c < nchunks; ++c) {
+        if (!((balQ >> c) & 1ull)) continue;               // wave-uniform
+        const uint32_t pos = c * 64u + l;
+        const uint32_t h = pos < r ? list[pos] : 0u;
+        const bool adj = row_test(roww, h) && pos < r;
+        const u64 bal = __ballot(adj);
+        if (l == c) Q &= ~bal;                             // neighbours cannot join this class
+      }
+    }
+    ++k;
+  }
+  __syncthreads();
+  for (uint32_t i = l; i < r; i += 64u) list[i] = L.tmp[i];
+  __syncthreads();
+}
+
+// FindClique + MaxCliqueDyn (maximum_clique.cpp:286-369) as an explicit state machine over one wave.
+// Returns QMax.size(); *err != 0 when the per-wave stack is too small.
+__device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, uint16_t* stack, uint32_t stack_cap,
+                                  int* err, uint32_t* steps_out) {
+  const uint32_t l = lane_id();
+  const uint32_t MW = (m + 63u) / 64u;
+  // R = all vertices, DegreeSort(R); L.deg holds the degree of graph vertex g at index g
+  for (uint32_t i = l; i < m; i += 64u) L.cur[i] = (uint16_t)i;
+  __syncthreads();
+  rank_sort_desc(L.cur, L.tmp, L.deg, m, L.keys);
+  const uint32_t max_degree = uni(L.deg[L.cur[0]]);
+  __syncthreads();
+  for (uint32_t i = l; i < m; i += 64u) L.C[i] = i < max_degree ? i + 1u : max_degree + 1u;     // :356-361
+  for (uint32_t i = l; i < m + 2u; i += 64u) { L.S[i] = 0u; L.SOld[i] = 0u; }
+  for (uint32_t i = l; i < m; i += 64u) stack[i] = L.cur[i];
+  if (l == 0) { L.lbase[1] = 0u; L.lsize[1] = m; L.lcap[1] = m; }
+  __syncthreads();
+
+  uint32_t level = 1, qsz = 0, qmax = 0, top = m;
+  int all_steps = 1;
+  uint16_t* cur = L.cur;
+  uint16_t* nxt = L.nxt;
+  bool reload = false;
+  // entry of level 1: QMax is empty; S[1] = S[1] + S[0] - SOld[1] = 0, SOld[1] = S[0] = 0  (:300-301)
+  while (true) {
+    const uint32_t sz = uni(L.lsize[level]);
+    if (reload) {
+      const uint32_t b = uni(L.lbase[level]);
+      for (uint32_t i = l; i < sz; i += 64u) cur[i] = stack[b + i];
+      __syncthreads();
+      reload = false;
+    }
+    bool ret = false;
+    if (sz == 0u) {
+      ret = true;                                          // while (!R.empty()) falls through, function returns
+    } else {
+      const uint32_t p = uni(cur[sz - 1u]);
+      const uint32_t c = uni(top > 0u ? L.C[top - 1u] : 0u);   // C.back(), decision D3
+      if (qsz + c > qmax) {                                // :307
+        ++qsz;                                             // Q.push_back(p)
+        // Intersection(p, R, Rp), :209-217 -- order preserving compaction
+        const u64 roww = l < MW ? L.adjc[(size_t)p * MW + l] : 0ull;
+        uint32_t rp = 0;
+        for (uint32_t i0 = 0; i0 < sz; i0 += 64u) {
+          const uint32_t i = i0 + l;
+          const uint32_t h = i < sz ? cur[i] : 0u;
+          const bool adj = row_test(roww, h) && i < sz;
+          const u64 bal = __ballot(adj);
+          if (adj) nxt[rp + (uint32_t)__popcll(bal & ((1ull << l) - 1ull))] = (uint16_t)h;
+          rp += (uint32_t)__popcll(bal);
+        }
+        rp = uni(rp);
+        __syncthreads();
+        if (rp > 0u) {
+          if ((double)uni(L.S[level]) / (double)all_steps < 0.025) {   // :313
+            degrees_in_list(L, nxt, rp, MW);
+            rank_sort_desc(nxt, L.tmp, L.deg, rp, L.keys);
+          }
+          colour_sort(L, nxt, rp, MW, qmax, qsz);
+          if (l == 0) L.S[level] += 1u;
+          ++all_steps;
+          __syncthreads();
+          if (all_steps > kStepCap) {
+            ret = true;                                    // :318-319: returns without popping Q
+          } else {
+            const uint32_t nb = uni(L.lbase[level]) + uni(L.lcap[level]);
+            if (nb + rp > stack_cap) { *err = 1; break; }
+            for (uint32_t i = l; i < rp; i += 64u) stack[nb + i] = nxt[i];
+            ++level;
+            if (l == 0) { L.lbase[level] = nb; L.lsize[level] = rp; L.lcap[level] = rp; }
+            uint16_t* t = cur; cur = nxt; nxt = t;
+            __syncthreads();
+            if (qmax >= minimal_size) {                    // :290-291 at the entry of the child
+              ret = true;
+            } else {
+              if (l == 0) {                                // :300-301
+                const uint32_t sprev = L.S[level - 1u];
+                L.S[level] = L.S[level] + sprev - L.SOld[level];
+                L.SOld[level] = sprev;
+              }
+              __syncthreads();
+              continue;
+            }
+          }
+        } else {
+          if (qsz > qmax) {                                // :322-326
+            qmax = qsz;
+            if (qmax >= minimal_size) ret = true;
+          }
+          if (!ret) --qsz;                                 // Q.pop_back(), :329
+        }
+      } else {
+        ret = true;                                        // :331-332
+      }
+      if (!ret) {                                          // R.pop_back(); C.pop_back(), :333-334
+        if (l == 0) L.lsize[level] = sz - 1u;
+        if (top > 0u) --top;
+        __syncthreads();
+        continue;
+      }
+    }
+    // the current level's function returns; its caller continues after the recursive call (:320)
+    if (level == 1u) break;
+    --level;
+    reload = true;
+    --qsz;                                                 // Q.pop_back()
+    if (l == 0) L.lsize[level] -= 1u;                      // R.pop_back()
+    if (top > 0u) --top;                                   // C.pop_back()
+    __syncthreads();
+  }
+  if (steps_out) *steps_out = (uint32_t)all_steps;
+  return qmax;
+}
+
+struct EvalArgs {
+  ObjJob job;
+  const uint32_t* iter_samples;   // 3 per iteration
+  uint32_t it_begin, it_end;      // iterations of this batch
+  int32_t* counts;                // consensus size per iteration (0 = rejected by the gate)
+  uint32_t* gate_m;               // per iteration: |F| when the gate ran (diagnostics), else 0
+  uint32_t* work;                 // atomic work counter (zeroed by the host)
+  uint32_t* status;               // [0] error flag, [1] gate calls, [2] deferred count
+  uint32_t* deferred;             // iteration indices that need the big-LDS pass
+  uint16_t* stacks;               // per resident wave: stack_cap entries
+  uint32_t stack_cap;
+  uint32_t lds_bytes;
+  uint32_t from_deferred;         // 1: the work list is `deferred`
+  uint32_t n_deferred;
+  uint32_t* dbg;                  // optional: per iteration dbg_stride words {cnt, m, F members...}
+  uint32_t dbg_stride;
+  uint32_t stop_level;            // 0 = full evaluation, 1 = stop before the clique search (diagnostics)
+};
+
+// launched with 64 threads; the bound is deliberately larger so that hipcc keeps __syncthreads() as a real,
+// convergent s_barrier (with a 64-thread bound it drops the barrier and may split the lanes of the wave)
+__global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const uint32_t l = lane_id();
+  const ObjJob& job = A.job;
+  const uint32_t W = job.W;
+  uint16_t* stack = A.stacks + (size_t)blockIdx.x * A.stack_cap;
+  const uint32_t n_items = A.from_deferred ? A.n_deferred : (A.it_end - A.it_begin);
+  {                                                        // one block = one hypothesis
+    const uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    const uint32_t it = uni(A.from_deferred ? A.deferred[item] : (A.it_begin + item));
+    const uint32_t s0 = uni(A.iter_samples[3 * it]), s1 = uni(A.iter_samples[3 * it + 1]),
+                   s2 = uni(A.iter_samples[3 * it + 2]);
+    if (s0 >= job.n || s1 >= job.n || s2 >= job.n) {       // corrupt draw table: report, never dereference
+      if (l == 0) { atomicExch(&A.status[0], 3u); A.counts[it] = INT_MIN; }
+      return;
+    }
+    // common physical neighbours of the three samples (:178-184); the geometric test of :197 is
+    // `finite < +inf` because threshold_ is DBL_MAX (D2), i.e. a finiteness test
+    WaveBits P;
+    wb_load(P, job.phys + (size_t)s0 * W, W);
+    wb_and(P, job.phys + (size_t)s1 * W, W);
+    wb_and(P, job.phys + (size_t)s2 * W, W);
+    wb_and(P, job.valid, W);
+    wb_and(P, job.finite, W);
+    const uint32_t cnt = wb_count(P) + 3u;                 // + the samples themselves (:185-186)
+    int32_t result = (int32_t)cnt;
+    uint32_t m_diag = 0;
+    if (cnt > kGateMinimal && A.stop_level != 2u) {        // :203-205
+      WaveBits F = P;
+      wb_set(F, s0); wb_set(F, s1); wb_set(F, s2);
+      wb_and(F, job.deg7, W);                              // :211-213
+      const uint32_t m = wb_count(F);
+      m_diag = m;
+      if (m <= kGateMinimal) {
+        result = 0;                                        // :214-218
+      } else if (gate_lds_bytes(m) > A.lds_bytes) {
+        if (A.from_deferred) {
+          if (l == 0) atomicExch(&A.status[0], 2u);        // graph too large even for the big-LDS pass
+          result = INT_MIN;
+        } else {
+          if (l == 0) A.deferred[atomicAdd(&A.status[2], 1u)] = it;
+          result = INT_MIN + 1;                            // filled in by the second pass
+        }
+      } else {
+        GateLds L = gate_carve(lds_raw, m);
+        const uint32_t MW = (m + 63u) / 64u;
+        // F in ascending order (:219) -> graph index = rank (:241-243)
+        uint32_t base = 0;
+#pragma unroll
+        for (int j = 0; j < kWPL; ++j) {
+          const uint32_t c = (uint32_t)__popcll(F.w[j]);
+          const uint32_t incl = wave_incl_scan(c);
+          u64 w = F.w[j];
+          uint32_t o = base + incl - c;
+          while (w) {
+            const uint32_t bit = (uint32_t)__ffsll((long long)w) - 1u;
+            L.flist[o++] = (uint16_t)((j * 64u + l) * 64u + bit);
+            w &= w - 1ull;
+          }
+          base += uni(__shfl(incl, 63));
+        }
+        __syncthreads();
+        // induced sample sub-graph (:245-256) as an m x MW bit matrix in LDS, plus vertex degrees
+        bool bad_index = false;
+        for (uint32_t g = 0; g < m && A.stop_level != 3u; ++g) {
+          const uint32_t vg = uni(L.flist[g]);
+          if (vg >= job.n) {                               // never dereference an unchecked index
+            if (l == 0) { atomicExch(&A.status[0], 4u); A.status[4] = g; A.status[5] = vg; A.status[6] = m; A.status[7] = it; }
+            bad_index = true;
+            break;
+          }
+          const u64* row = job.samp + (size_t)vg * W;
+          uint32_t d = 0;
+          for (uint32_t c = 0; c < MW; ++c) {
+            const uint32_t pos = c * 64u + l;
+            bool adj = false;
+            if (pos < m) {
+              const uint32_t h = L.flist[pos];
+              adj = (row[h >> 6] >> (h & 63u)) & 1ull;
+            }
+            const u64 bal = __ballot(adj);
+            if (l == 0) L.adjc[(size_t)g * MW + c] = bal;
+            d += (uint32_t)__popcll(bal);
+          }
+          if (l == 0) L.deg[g] = d;
+        }
+        __syncthreads();
+        if (A.dbg) {
+          uint32_t* d = A.dbg + (size_t)it * A.dbg_stride;
+          if (l == 0) { d[0] = cnt; d[1] = m; }
+          for (uint32_t g = l; g < m && 2u + 2u * g + 1u < A.dbg_stride; g += 64u) { d[2 + 2 * g] = L.flist[g]; d[3 + 2 * g] = L.deg[g]; }
+        }
+        // "make sure that those inliers have enough neighbors within the inliers themselves" (:221-238)
+        bool any = false;
+        for (uint32_t g = l; g < m; g += 64u) any = any || L.deg[g] > kGateMinimal;
+        if (bad_index) {
+          result = INT_MIN;
+        } else if (A.stop_level != 0u) {
+          result = -(int32_t)m;
+        } else if (__ballot(any) == 0ull) {
+          result = 0;
+        } else {
+          int err = 0;
+          const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, nullptr);
+          if (err) {
+            if (l == 0) atomicExch(&A.status[0], 1u);
+            result = INT_MIN;
+          } else if (q <= kGateMinimal) {
+            result = 0;                                    // :260-265
+          }
+          if (l == 0) atomicAdd(&A.status[1], 1u);
+        }
+        __syncthreads();
+      }
+    }
+    if (l == 0) {
+      if (result != INT_MIN + 1) A.counts[it] = result;
+      if (A.gate_m) A.gate_m[it] = m_diag;
+    }
+  }
+}
+
+// stand-alone clique search on an explicit graph (the reference's test/test_maximum_clique.cpp shape):
+// adj = m x MW bit matrix in global memory. One block of 64 threads.
+__global__ __launch_bounds__(128) void clique_test_kernel(const u64* adj, uint32_t m, uint32_t minimal_size,
+                                                         uint16_t* stack, uint32_t stack_cap, uint32_t* out) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const uint32_t l = lane_id();
+  GateLds L = gate_carve(lds_raw, m);
+  const uint32_t MW = (m + 63u) / 64u;
+  for (uint32_t i = l; i < m * MW; i += 64u) L.adjc[i] = adj[i];
+  __syncthreads();
+  for (uint32_t g = l; g < m; g += 64u) {
+    uint32_t d = 0;
+    for (uint32_t w = 0; w < MW; ++w) d += (uint32_t)__popcll(L.adjc[(size_t)g * MW + w]);
+    L.deg[g] = d;
+  }
+  __syncthreads();
+  int err = 0;
+  uint32_t steps = 0;
+  const uint32_t q = clique_search(L, m, minimal_size, stack, stack_cap, &err, &steps);
+  if (l == 0) { out[0] = q; out[1] = (uint32_t)err; out[2] = steps; }
+}
+
+// ------------------------------------------------------------------------------------------------ K9
+// 3x3 one-sided Jacobi SVD in float, A = U diag(w) Vt, w descending. cv::SVD on a CV_32F 3x3
+// (sac_model_registration_graph.h:333) is third-party arithmetic that the reference tree does not contain.
+__device__ void svd3(const float Ain[3][3], float U[3][3], float w[3], float Vt[3][3]) {
+  float A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = Ain[i][j];
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        float alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < 3; ++i) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
+        if (fabsf(gamma) <= 1.1920929e-07f * sqrtf(alpha * beta) || gamma == 0.f) continue;
+        rotated = true;
+        const float zeta = (beta - alpha) / (2.f * gamma);
+        const float t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+        const float c = 1.f / sqrtf(1.f + t * t), s = c * t;
+        for (int i = 0; i < 3; ++i) {
+          const float ap = A[i][p], aq = A[i][q];
+          A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
+          const float vp = V[i][p], vq = V[i][q];
+          V[i][p] = c * vp - s * vq; V[i][q] = s * vp + c * vq;
+        }
+      }
+    if (!rotated) break;
+  }
+  float nrm[3];
+  int order[3] = {0, 1, 2};
+  for (int j = 0; j < 3; ++j) nrm[j] = sqrtf(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2 - a; ++b)
+      if (nrm[order[b]] < nrm[order[b + 1]]) { int t = order[b]; order[b] = order[b + 1]; order[b + 1] = t; }
+  for (int jj = 0; jj < 3; ++jj) {
+    const int j = order[jj];
+    w[jj] = nrm[j];
+    for (int i = 0; i < 3; ++i) { Vt[jj][i] = V[i][j]; U[i][jj] = nrm[j] > 0.f ? A[i][j] / nrm[j] : 0.f; }
+  }
+  const float tiny = 1.1920929e-07f * (w[0] > 0.f ? w[0] : 1.f);
+  if (w[0] <= 0.f) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.f : 0.f; return; }
+  if (w[1] <= tiny) {
+    int ax = 0;
+    for (int i = 1; i < 3; ++i) if (fabsf(U[i][0]) < fabsf(U[ax][0])) ax = i;
+    float e[3] = {0, 0, 0};
+    e[ax] = 1.f;
+    float c1[3] = {U[1][0] * e[2] - U[2][0] * e[1], U[2][0] * e[0] - U[0][0] * e[2], U[0][0] * e[1] - U[1][0] * e[0]};
+    const float n1 = sqrtf(c1[0] * c1[0] + c1[1] * c1[1] + c1[2] * c1[2]);
+    for (int i = 0; i < 3; ++i) U[i][1] = c1[i] / n1;
+  }
+  if (w[2] <= tiny) {
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+  }
+}
+__device__ inline float det3f(const float m[3][3]) {
+  return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+         m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+
+constexpr uint32_t kGrowthLdsPoints = 2048;   // inlier points staged in LDS per Kabsch pass (48 KB)
+
+struct GrowthOut {
+  float R[9], T[3];             // inverted pose (training -> camera), adjacency_ransac.cpp:304-305
+  uint32_t n_match_inliers;     // match indices in the grown set
+  uint32_t n_kp_inliers;        // unique keypoint indices (:306-308)
+  uint32_t passes;
+  uint32_t n_model_inliers;
+};
+
+// One block. inl/rest/extra are W-word bitsets in global scratch. Sums that the reference accumulates
+// sequentially (centroids in float, the correlation matrix in double) are accumulated sequentially here too,
+// each by one lane, so that the admitted sets are reproducible against the CPU oracle bit for bit.
+__global__ __launch_bounds__(256) void growth_kernel(ObjJob job, uint32_t s0, uint32_t s1, uint32_t s2, float err,
+                                                     u64* inl, u64* rest, u64* extra, uint32_t* kp_list,
+                                                     u64* kp_bits, uint32_t kp_words, GrowthOut* out) {
+  __shared__ float sR[9], sT[3];
+  __shared__ double sAcc[16];
+  __shared__ float sC[6];
+  __shared__ uint32_t sFlag, sCount;
+  __shared__ uint32_t sPre[kMaxWords];
+  __shared__ float sPts[kGrowthLdsPoints * 6];
+  const uint32_t tid = threadIdx.x, W = job.W, n = job.n;
+  // consensus set of the winning iteration: common physical neighbours + the samples
+  for (uint32_t w = tid; w < W; w += 256u) {
+    u64 v = job.phys[(size_t)s0 * W + w] & job.phys[(size_t)s1 * W + w] & job.phys[(size_t)s2 * W + w] &
+            job.valid[w] & job.finite[w];
+    if ((s0 >> 6) == w) v |= 1ull << (s0 & 63u);
+    if ((s1 >> 6) == w) v |= 1ull << (s1 & 63u);
+    if ((s2 >> 6) == w) v |= 1ull << (s2 & 63u);
+    inl[w] = v;
+    rest[w] = job.valid[w] & ~v;                           // :260-264
+  }
+  for (uint32_t w = tid; w < kp_words; w += 256u) kp_bits[w] = 0ull;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t c = 0;
+    for (uint32_t w = 0; w < W; ++w) c += (uint32_t)__popcll(inl[w]);
+    out->n_model_inliers = c;
+  }
+  bool do_final = false;
+  double thresh = (double)(err * err);                     // float product widened, :267
+  uint32_t passes = 0;
+  while (true) {
+    // ---- estimateRigidTransformationSVD (sac_model_registration_graph.h:304-347) on the current inliers
+    // ordered compaction of the inlier points into LDS (ascending match index = the reference's list order)
+    if (tid < W) sPre[tid] = (uint32_t)__popcll(inl[tid]);
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (uint32_t w = 0; w < W; ++w) { const uint32_t c = sPre[w]; sPre[w] = acc; acc += c; }
+      sCount = acc;
+    }
+    __syncthreads();
+    const uint32_t cnt = sCount;
+    const bool staged = cnt <= kGrowthLdsPoints;
+    if (staged && tid < W) {
+      u64 bits = inl[tid];
+      uint32_t o = sPre[tid];
+      while (bits) {
+        const uint32_t v = tid * 64u + (uint32_t)__ffsll((long long)bits) - 1u;
+        for (int c = 0; c < 3; ++c) { sPts[o * 6u + c] = job.train[3 * v + c]; sPts[o * 6u + 3 + c] = job.query[3 * v + c]; }
+        ++o;
+        bits &= bits - 1ull;
+      }
+    }
+    __syncthreads();
+    if (tid < 6) {                                         // 6 sequential float sums: centroids
+      float s = 0.f;
+      if (staged) {
+        for (uint32_t i = 0; i < cnt; ++i) s += sPts[i * 6u + tid];
+      } else {
+        const float* src = tid < 3 ? job.train : job.query;
+        const uint32_t c = tid % 3u;
+        for (uint32_t w = 0; w < W; ++w) {
+          u64 bits = inl[w];
+          while (bits) {
+            const uint32_t v = w * 64u + (uint32_t)__ffsll((long long)bits) - 1u;
+            s += src[3 * v + c];
+            bits &= bits - 1ull;
+          }
+        }
+      }
+      const double inv = 1. / (float)cnt;                  // Vec /= float: times the double reciprocal
+      sC[tid] = (float)(s * inv);
+    }
+    __syncthreads();
+    if (tid < 9) {                                         // H = sub_training^T * sub_query, double accumulation
+      const uint32_t r = tid / 3u, c = tid % 3u;
+      const float ct = sC[r], cq = sC[3 + c];
+      double h = 0.0;
+      if (staged) {
+        for (uint32_t i = 0; i < cnt; ++i) {
+          const float a = sPts[i * 6u + r] - ct, b = sPts[i * 6u + 3 + c] - cq;
+          h += (double)a * (double)b;
+        }
+      } else {
+        for (uint32_t w = 0; w < W; ++w) {
+          u64 bits = inl[w];
+          while (bits) {
+            const uint32_t v = w * 64u + (uint32_t)__ffsll((long long)bits) - 1u;
+            const float a = job.train[3 * v + r] - ct, b = job.query[3 * v + c] - cq;
+            h += (double)a * (double)b;
+            bits &= bits - 1ull;
+          }
+        }
+      }
+      sAcc[tid] = h;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float H[3][3], U[3][3], wv[3], Vt[3][3], Rm[3][3];
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] = (float)sAcc[3 * r + c];
+      svd3(H, U, wv, Vt);
+      if (det3f(U) * det3f(Vt) < 0)
+        for (int x = 0; x < 3; ++x) Vt[2][x] *= -1;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          double s = 0;
+          for (int k = 0; k < 3; ++k) s += (double)U[r][k] * (double)Vt[k][c];
+          Rm[r][c] = (float)s;
+        }
+      for (int r = 0; r < 3; ++r) {
+        float s = 0;
+        for (int k = 0; k < 3; ++k) s += Rm[r][k] * sC[3 + k];
+        sT[r] = sC[r] - s;
+        for (int c = 0; c < 3; ++c) sR[3 * r + c] = Rm[r][c];
+      }
+      sFlag = 0u;
+    }
+    __syncthreads();
+    ++passes;
+    // ---- admit every valid non-inlier within thresh (adjacency_ransac.cpp:275-283)
+    for (uint32_t w0 = 0; w0 < W; w0 += 4u) {
+      const uint32_t w = w0 + (tid >> 6);
+      bool pass = false;
+      if (w < W) {
+        const uint32_t v = w * 64u + (tid & 63u);
+        if (v < n && ((rest[w] >> (v & 63u)) & 1ull)) {
+          const float* q = job.query + 3 * v;
+          const float* t = job.train + 3 * v;
+          float p[3];
+          for (int r = 0; r < 3; ++r) {
+            float s = 0;
+            for (int k = 0; k < 3; ++k) s += sR[3 * r + k] * q[k];
+            p[r] = s + sT[r];
+          }
+          const double nn = norm3d(p[0] - t[0], p[1] - t[1], p[2] - t[2]);
+          pass = nn * nn < thresh;
+        }
+      }
+      const u64 bal = __ballot(pass);
+      if ((tid & 63u) == 0 && w < W) {
+        extra[w] = bal;
+        if (bal) atomicOr(&sFlag, 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t w = tid; w < W; w += 256u) { inl[w] |= extra[w]; rest[w] &= ~extra[w]; }
+    const bool any_extra = sFlag != 0u;
+    __syncthreads();
+    if (do_final) break;
+    if (!any_extra) { do_final = true; thresh *= 4; }      // :295-301
+  }
+  // ---- pose inversion (:304-305) and unique keypoint indices (:306-308)
+  if (tid == 0) {
+    float Rt[3][3];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rt[r][c] = sR[3 * c + r];
+    for (int r = 0; r < 3; ++r) {
+      float s = 0;
+      for (int k = 0; k < 3; ++k) s += (-Rt[r][k]) * sT[k];
+      out->T[r] = s;
+      for (int c = 0; c < 3; ++c) out->R[3 * r + c] = Rt[r][c];
+    }
+    uint32_t nm = 0, nk = 0, last = 0xFFFFFFFFu;
+    for (uint32_t w = 0; w < W; ++w) {
+      u64 bits = inl[w];
+      while (bits) {
+        const uint32_t v = w * 64u + (uint32_t)__ffsll((long long)bits) - 1u;
+        const uint32_t qi = job.qidx[v];                   // non-decreasing in v (App. A Q4)
+        if (qi != last) { kp_list[nk++] = qi; kp_bits[qi >> 6] |= 1ull << (qi & 63u); last = qi; }
+        ++nm;
+        bits &= bits - 1ull;
+      }
+    }
+    out->n_match_inliers = nm;
+    out->n_kp_inliers = nk;
+    out->passes = passes;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ K11
+// InvalidateQueryIndices (adjacency_ransac.cpp:93-123): drop every valid match whose keypoint is an inlier
+// keypoint, then InvalidateIndices (:63-89): repeatedly drop valid matches whose sample degree is < 3.
+__global__ __launch_bounds__(1024) void invalidate_kernel(ObjJob job, const u64* kp_bits, u64* scratch) {
+  __shared__ uint32_t sAny;
+  const uint32_t tid = threadIdx.x, W = job.W, n = job.n;
+  if (tid == 0) sAny = 0u;
+  __syncthreads();
+  for (uint32_t w = tid; w < W; w += 1024u) {
+    u64 gone = 0ull, val = job.valid[w];
+    u64 bits = val;
+    while (bits) {
+      const uint32_t b = (uint32_t)__ffsll((long long)bits) - 1u;
+      const uint32_t qi = job.qidx[w * 64u + b];
+      if ((kp_bits[qi >> 6] >> (qi & 63u)) & 1ull) gone |= 1ull << b;
+      bits &= bits - 1ull;
+    }
+    if (gone) { job.valid[w] = val & ~gone; atomicOr(&sAny, 1u); }
+  }
+  __syncthreads();
+  if (sAny == 0u) return;                                  // InvalidateIndices(empty) does nothing (:68)
+  while (true) {
+    __syncthreads();
+    if (tid == 0) sAny = 0u;
+    __syncthreads();
+    for (uint32_t w = tid; w < W; w += 1024u) scratch[w] = 0ull;
+    __syncthreads();
+    for (uint32_t v = tid; v < n; v += 1024u) {
+      if ((job.valid[v >> 6] >> (v & 63u)) & 1ull) {
+        uint32_t d = 0;
+        for (uint32_t w = 0; w < W; ++w) d += (uint32_t)__popcll(job.samp[(size_t)v * W + w] & job.valid[w]);
+        if (d < 3u) { atomicOr(&scratch[v >> 6], 1ull << (v & 63u)); atomicOr(&sAny, 1u); }   // min_sample_size_
+      }
+    }
+    __syncthreads();
+    if (sAny == 0u) break;
+    for (uint32_t w = tid; w < W; w += 1024u) job.valid[w] &= ~scratch[w];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct VerifyWs {
+  DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, rnd, table, iter_samples, iter_pos, counts, gate_m,
+      small, deferred, stacks, kp_list, kp_bits, clique_adj;
+  HostBuf h_small, h_counts, h_pos, h_kp;
+  std::vector<uint32_t> rnd_host;
+};
+
+constexpr uint32_t kEvalLdsSmall = 48u * 1024u;
+constexpr uint32_t kEvalLdsBig = 160u * 1024u - 512u;
+constexpr uint32_t kStackCap = 256u * 1024u;       // u16 entries per wave (512 KB)
+constexpr uint32_t kMaxEvalWaves = 2048u;
+
+VerifyWs* ws_of(todhip_ctx* ctx) {
+  if (!ctx->verify_ws) ctx->verify_ws = new VerifyWs();
+  return reinterpret_cast<VerifyWs*>(ctx->verify_ws);
+}
+
+// glibc random_r TYPE_3 (see include/todhip.h, decision D4)
+inline uint32_t rng_next(todhip_rng& r) {
+  r.s[r.f] += r.s[r.b];
+  const uint32_t out = r.s[r.f] >> 1;
+  r.f = (r.f + 1) % 31; r.b = (r.b + 1) % 31;
+  ++r.draws;
+  return out;
+}
+
+struct RoundResult {
+  bool have_pose;
+  std::vector<uint32_t> inlier_kp;
+  float R[9], T[3];
+  uint32_t iterations, best_iteration; int32_t best_count;
+};
+
+int set_big_lds_once(todhip_ctx* ctx) {
+  static bool done = false;
+  if (!done) {
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kEvalLdsBig));
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clique_test_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
+    done = true;
+  }
+  return TODHIP_OK;
+}
+
+// AdjacencyRansac::Ransac (adjacency_ransac.cpp:234-309) for one object whose job is resident.
+int ransac_round(todhip_ctx* ctx, VerifyWs* ws, const ObjJob& job, uint32_t nq, float err, uint32_t max_iterations,
+                 todhip_rng* rng, RoundResult* res) {
+  res->have_pose = false;
+  res->inlier_kp.clear();
+  res->iterations = 0; res->best_iteration = 0; res->best_count = -INT_MAX;
+  hipStream_t st = ctx->stream;
+  uint32_t* d_small = ws->small.as<uint32_t>();           // [0] nvalid [1..4] ChainOut [8] work [12..14] status
+  TOD_HIP(hipMemsetAsync(d_small, 0, 64 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(round_prep_kernel, dim3((job.n + 255u) / 256u), dim3(256), 0, st, job, d_small);
+  uint32_t* h_small = ws->h_small.as<uint32_t>();
+  TOD_HIP(hipMemcpyAsync(h_small, d_small, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
+  const uint32_t nvalid = h_small[0];
+  TOD_DBG("round: n=%u W=%u nvalid=%u", job.n, job.W, nvalid);
+  if (nvalid < 3) return TODHIP_OK;                       // :238-241
+
+  const uint32_t total_iters = max_iterations + 1u;       // iterations_ runs 0 .. max_iterations (ransac.h:132-134)
+  TOD_HIP(ws->iter_samples.reserve((size_t)(total_iters + 1) * 3 * sizeof(uint32_t)));
+  TOD_HIP(ws->iter_pos.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
+  TOD_HIP(ws->counts.reserve((size_t)(total_iters + 1) * sizeof(int32_t)));
+  TOD_HIP(ws->gate_m.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
+  TOD_HIP(ws->deferred.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
+  TOD_HIP(ws->h_counts.reserve((size_t)(total_iters + 1) * sizeof(int32_t)));
+  TOD_HIP(ws->h_pos.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
+  TOD_HIP(ws->stacks.reserve((size_t)kMaxEvalWaves * kStackCap * sizeof(uint16_t)));
+
+  // ---- computeModel (ransac.h:80-143): speculative draws in batches, evaluation, host replay
+  todhip_rng gen = *rng;                                  // generator that fills stream windows
+  std::vector<uint32_t>& stream = ws->rnd_host;           // stream[i] = i-th draw after *rng
+  stream.clear();
+  uint64_t consumed = 0;                                  // draws used by completed getSamples calls
+  uint32_t it_drawn = 0, attempts_carry = 0;
+  bool selection_empty = false;
+  int iterations = 0, n_best = -INT_MAX;
+  double k = 1.0;
+  uint32_t best_it = 0;
+  bool loop_done = false;
+  uint64_t pos_after_stop = 0;
+  uint32_t batch = 64, lookahead = 4096;
+  while (!loop_done) {
+    const uint32_t it_begin = it_drawn;
+    const uint32_t want = std::min(batch, total_iters - it_begin);
+    // ---- draw `want` iterations, extending the window as often as needed
+    uint32_t got = 0;
+    while (got < want && !selection_empty) {
+      const uint32_t S = std::min<uint32_t>(4u * (want - got) + 256u, 1u << 20);
+      const uint32_t window_len = S + lookahead;
+      while (stream.size() < consumed + window_len) stream.push_back(rng_next(gen));
+      TOD_HIP(ws->rnd.reserve((size_t)window_len * sizeof(uint32_t)));
+      TOD_HIP(ws->table.reserve((size_t)S * sizeof(DrawEntry)));
+      TOD_HIP(hipMemcpyAsync(ws->rnd.p, stream.data() + consumed, (size_t)window_len * sizeof(uint32_t),
+                             hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(draw_table_kernel, dim3((S + 3u) / 4u), dim3(256), 0, st, job, ws->rnd.as<uint32_t>(),
+                         window_len, S, ws->table.as<DrawEntry>());
+      hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, st, ws->table.as<DrawEntry>(), S, want - got,
+                         attempts_carry, it_begin + got, ws->iter_samples.as<uint32_t>(), ws->iter_pos.as<uint32_t>(),
+                         reinterpret_cast<ChainOut*>(d_small + 1));
+      TOD_HIP(hipMemcpyAsync(h_small + 1, d_small + 1, sizeof(ChainOut), hipMemcpyDeviceToHost, st));
+      TOD_HIP(hipStreamSynchronize(st));
+      const ChainOut co = *reinterpret_cast<ChainOut*>(h_small + 1);
+      TOD_DBG("  draw window: S=%u len=%u -> done=%u pos_end=%u attempts=%u flag=%u", S, window_len, co.n_done, co.pos_end,
+              co.attempts, co.flag);
+      // iter_pos entries of this walk are relative to the window: make them absolute on the host later
+      if (co.n_done) {
+        TOD_HIP(hipMemcpyAsync(ws->h_pos.as<uint32_t>() + it_begin + got, ws->iter_pos.as<uint32_t>() + it_begin + got,
+                               (size_t)co.n_done * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        TOD_HIP(hipStreamSynchronize(st));
+        uint32_t* hp = ws->h_pos.as<uint32_t>();
+        for (uint32_t i = 0; i < co.n_done; ++i) hp[it_begin + got + i] += (uint32_t)consumed;
+      }
+      got += co.n_done;
+      consumed += co.pos_end;
+      attempts_carry = co.attempts;
+      if (co.flag == 2) selection_empty = true;
+      if (co.flag == 1 && co.n_done == 0 && co.pos_end == 0) {
+        // a single attempt longer than the window: enlarge the look-ahead, give up beyond 64M draws
+        if (lookahead >= (1u << 26)) return TODHIP_ESCRATCH;
+        lookahead *= 4u;
+      }
+    }
+    it_drawn = it_begin + got;
+    // ---- evaluate the drawn iterations
+    if (got > 0) {
+      EvalArgs A;
+      A.job = job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = it_begin; A.it_end = it_drawn;
+      A.counts = ws->counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
+      A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>(); A.stacks = ws->stacks.as<uint16_t>();
+      A.stack_cap = kStackCap; A.lds_bytes = kEvalLdsSmall; A.from_deferred = 0; A.n_deferred = 0;
+      A.dbg = nullptr; A.dbg_stride = 0; A.stop_level = 0;
+      TOD_HIP(hipMemsetAsync(d_small + 8, 0, 12 * sizeof(uint32_t), st));
+      const uint32_t waves = got;                         // one block per hypothesis; batches are <= 1024
+      TOD_DBG("  eval: iterations [%u,%u) on %u waves", it_begin, it_drawn, waves);
+      hipLaunchKernelGGL(eval_kernel, dim3(waves), dim3(64), kEvalLdsSmall, st, A);
+      TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      TOD_HIP(hipStreamSynchronize(st));
+      if (h_small[12] != 0) {
+        if (getenv("TODHIP_DEBUG"))
+          fprintf(stderr, "[todhip] eval status %u: g=%u value=%u m=%u it=%u (n=%u W=%u)\n", h_small[12], h_small[16],
+                  h_small[17], h_small[18], h_small[19], job.n, job.W);
+        return TODHIP_ESCRATCH;
+      }
+      const uint32_t n_def = h_small[14];
+      TOD_DBG("  eval done: gate calls=%u deferred=%u", h_small[13], n_def);
+      ctx->counters.last_gate_calls += h_small[13];
+      if (n_def > 0) {                                    // graphs that need the whole LDS of a CU
+        A.lds_bytes = kEvalLdsBig; A.from_deferred = 1; A.n_deferred = n_def;
+        TOD_HIP(hipMemsetAsync(d_small + 8, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(eval_kernel, dim3(n_def), dim3(64), kEvalLdsBig, st, A);
+        TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        TOD_HIP(hipStreamSynchronize(st));
+        if (h_small[12] != 0) return TODHIP_ESCRATCH;
+      }
+      TOD_HIP(hipMemcpyAsync(ws->h_counts.as<int32_t>() + it_begin, ws->counts.as<int32_t>() + it_begin,
+                             (size_t)got * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      TOD_HIP(hipStreamSynchronize(st));
+      ctx->counters.last_hypotheses += got;
+    }
+    // ---- replay ransac.h:95-135 over the iterations known so far
+    const int32_t* hc = ws->h_counts.as<int32_t>();
+    const uint32_t* hp = ws->h_pos.as<uint32_t>();
+    while (!loop_done) {
+      if (!(iterations < k)) { loop_done = true; pos_after_stop = iterations > 0 ? hp[iterations - 1] : 0; break; }
+      if ((uint32_t)iterations >= it_drawn) {
+        if (selection_empty) { loop_done = true; pos_after_stop = consumed; }   // selection.empty() -> break (:100-101)
+        break;                                            // need more iterations
+      }
+      const int n_count = hc[iterations];
+      if (n_count > n_best) {
+        n_best = n_count;
+        best_it = (uint32_t)iterations;
+        const double w = (double)n_best / (double)nvalid;
+        double p_no_outliers = 1.0 - std::pow(w, 3.0);
+        p_no_outliers = std::max(std::numeric_limits<double>::epsilon(), p_no_outliers);
+        p_no_outliers = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no_outliers);
+        k = std::log(1.0 - 0.99) / std::log(p_no_outliers);
+      }
+      ++iterations;
+      if (iterations > (int)max_iterations) { loop_done = true; pos_after_stop = hp[iterations - 1]; }
+    }
+    batch = std::min<uint32_t>(batch * 4u, 1024u);
+  }
+  // advance the caller's generator by exactly the draws the reference would have consumed
+  for (uint64_t i = 0; i < pos_after_stop; ++i) (void)rng_next(*rng);
+  res->iterations = (uint32_t)iterations; res->best_iteration = best_it; res->best_count = n_best;
+  TOD_DBG("  replay: iterations=%d best_it=%u n_best=%d draws=%llu", iterations, best_it, n_best,
+          (unsigned long long)pos_after_stop);
+  if (n_best <= 0) return TODHIP_OK;                      // inliers_.empty(): computeModel() == false (:137-138)
+
+  // ---- growth (adjacency_ransac.cpp:255-308)
+  const uint32_t kp_words = (nq + 63u) / 64u;
+  TOD_HIP(ws->kp_list.reserve((size_t)std::max(nq, 1u) * sizeof(uint32_t)));
+  TOD_HIP(ws->kp_bits.reserve((size_t)(kp_words + 1) * sizeof(u64)));
+  TOD_HIP(ws->h_kp.reserve((size_t)std::max(nq, 1u) * sizeof(uint32_t) + sizeof(GrowthOut)));
+  u64* d_bits = ws->bits.as<u64>();                       // finite | valid | deg7 | inl | rest | extra | scratch
+  const uint32_t W = job.W;
+  uint32_t trip[3];
+  TOD_HIP(hipMemcpyAsync(trip, ws->iter_samples.as<uint32_t>() + 3 * best_it, sizeof(trip), hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
+  GrowthOut* d_go = reinterpret_cast<GrowthOut*>(d_small + 32);
+  hipLaunchKernelGGL(growth_kernel, dim3(1), dim3(256), 0, st, job, trip[0], trip[1], trip[2], err, d_bits + 3 * W,
+                     d_bits + 4 * W, d_bits + 5 * W, ws->kp_list.as<uint32_t>(), ws->kp_bits.as<u64>(), kp_words, d_go);
+  GrowthOut* h_go = reinterpret_cast<GrowthOut*>(ws->h_kp.as<unsigned char>());
+  TOD_HIP(hipMemcpyAsync(h_go, d_go, sizeof(GrowthOut), hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
+  uint32_t* h_list = reinterpret_cast<uint32_t*>(ws->h_kp.as<unsigned char>() + sizeof(GrowthOut));
+  if (h_go->n_kp_inliers) {
+    TOD_HIP(hipMemcpyAsync(h_list, ws->kp_list.p, (size_t)h_go->n_kp_inliers * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    TOD_HIP(hipStreamSynchronize(st));
+  }
+  TOD_DBG("  growth: model=%u matches=%u kps=%u passes=%u", h_go->n_model_inliers, h_go->n_match_inliers,
+          h_go->n_kp_inliers, h_go->passes);
+  res->have_pose = true;
+  res->inlier_kp.assign(h_list, h_list + h_go->n_kp_inliers);
+  std::memcpy(res->R, h_go->R, sizeof(res->R));
+  std::memcpy(res->T, h_go->T, sizeof(res->T));
+  return TODHIP_OK;
+}
+
+}  // namespace
+
+void tod_verify_ws_free(todhip_ctx* ctx) {
+  if (!ctx->verify_ws) return;
+  VerifyWs* ws = reinterpret_cast<VerifyWs*>(ctx->verify_ws);
+  DevBuf* bufs[] = {&ws->train, &ws->query, &ws->qidx, &ws->kpxy, &ws->phys, &ws->samp, &ws->bits, &ws->sampdeg,
+                    &ws->rnd, &ws->table, &ws->iter_samples, &ws->iter_pos, &ws->counts, &ws->gate_m, &ws->small,
+                    &ws->deferred, &ws->stacks, &ws->kp_list, &ws->kp_bits, &ws->clique_adj};
+  for (DevBuf* b : bufs) b->release();
+  ws->h_small.release(); ws->h_counts.release(); ws->h_pos.release(); ws->h_kp.release();
+  delete ws;
+  ctx->verify_ws = nullptr;
+}
+
+extern "C" {
+
+void todhip_rng_seed(todhip_rng* r, uint32_t seed) {
+  if (!r) return;
+  if (seed == 0) seed = 1;
+  int32_t word = (int32_t)seed;
+  r->s[0] = seed;
+  for (int i = 1; i < 31; ++i) {                          // srandom_r: Lehmer LCG, Schrage's method
+    const long hi = word / 127773, lo = word % 127773;
+    word = (int32_t)(16807 * lo - 2836 * hi);
+    if (word < 0) word += 2147483647;
+    r->s[i] = (uint32_t)word;
+  }
+  r->f = 3; r->b = 0;
+  for (int i = 0; i < 310; ++i) {
+    r->s[r->f] += r->s[r->b];
+    r->f = (r->f + 1) % 31; r->b = (r->b + 1) % 31;
+  }
+  r->draws = 0;
+}
+
+int todhip_verify(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float* cloud, uint32_t H, uint32_t Wimg,
+                  const uint32_t* row_ptr, const todhip_dmatch* matches, const float* mxyz, const float* spans,
+                  uint32_t n_objs, const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses,
+                  uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  if (!ctx || !prm || !rng || !n_poses || !n_inlier_kp || (*n_poses && !poses) || (*n_inlier_kp && !inlier_kp))
+    return TODHIP_EINVAL;
+  const uint32_t pose_cap = *n_poses, kp_cap = *n_inlier_kp;
+  *n_poses = 0; *n_inlier_kp = 0;
+  ctx->counters.last_objects_verified = ctx->counters.last_rounds = ctx->counters.last_hypotheses = 0;
+  ctx->counters.last_gate_calls = ctx->counters.last_poses = 0;
+  ctx->traces.clear();
+  if (!cloud || H == 0 || Wimg == 0) return TODHIP_OK;   // 2D-only input is an empty TODO (GuessGenerator.cpp:147-152)
+  if (nq && (!kp_xy || !row_ptr || !spans)) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  int rc = set_big_lds_once(ctx);
+  if (rc != TODHIP_OK) return rc;
+  VerifyWs* ws = ws_of(ctx);
+
+  // ---- ClusterPerObject (adjacency_ransac.cpp:176-205): per object, matches in (query asc, rank asc) order
+  struct HostCluster { std::vector<float> train, query, kpxy; std::vector<uint32_t> qidx; };
+  std::map<uint32_t, HostCluster> objects;
+  for (uint32_t qi = 0; qi < nq; ++qi) {
+    const int row = (int)kp_xy[2 * qi + 1], col = (int)kp_xy[2 * qi];   // float -> int truncation (:185)
+    if (row < 0 || col < 0 || (uint32_t)row >= H || (uint32_t)col >= Wimg) return TODHIP_ERANGE;
+    const float* qp = cloud + 3 * ((size_t)row * Wimg + col);
+    if (std::isnan(qp[0])) continue;                                     // only .x is tested (:189)
+    for (uint32_t m = row_ptr[qi]; m < row_ptr[qi + 1]; ++m) {
+      if (matches[m].imgIdx < 0 || (uint32_t)matches[m].imgIdx >= n_objs) return TODHIP_ERANGE;
+      HostCluster& c = objects[(uint32_t)matches[m].imgIdx];
+      for (int k = 0; k < 3; ++k) { c.train.push_back(mxyz[3 * (size_t)m + k]); c.query.push_back(qp[k]); }
+      c.kpxy.push_back(kp_xy[2 * qi]); c.kpxy.push_back(kp_xy[2 * qi + 1]);
+      c.qidx.push_back(qi);
+    }
+  }
+  TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
+  TOD_HIP(ws->h_small.reserve(256 * sizeof(uint32_t)));
+  hipStream_t st = ctx->stream;
+  // ---- objects in ascending imgIdx (GuessGenerator.cpp:170-235)
+  for (auto& kv : objects) {
+    const uint32_t obj = kv.first;
+    HostCluster& c = kv.second;
+    const uint32_t n = (uint32_t)c.qidx.size();
+    if (n < 3) continue;               // Ransac returns no inliers for < 3 valid matches and draws nothing (:238-241)
+    if (n > (uint32_t)kMaxWords * 64u) return TODHIP_ESCRATCH;
+    const uint32_t W = (n + 63u) / 64u;
+    TOD_HIP(ws->train.reserve((size_t)n * 12)); TOD_HIP(ws->query.reserve((size_t)n * 12));
+    TOD_HIP(ws->qidx.reserve((size_t)n * 4)); TOD_HIP(ws->kpxy.reserve((size_t)n * 8));
+    TOD_HIP(ws->phys.reserve((size_t)n * W * 8)); TOD_HIP(ws->samp.reserve((size_t)n * W * 8));
+    TOD_HIP(ws->bits.reserve((size_t)8 * W * 8)); TOD_HIP(ws->sampdeg.reserve((size_t)n * 4));
+    TOD_HIP(hipMemcpyAsync(ws->train.p, c.train.data(), (size_t)n * 12, hipMemcpyHostToDevice, st));
+    TOD_HIP(hipMemcpyAsync(ws->query.p, c.query.data(), (size_t)n * 12, hipMemcpyHostToDevice, st));
+    TOD_HIP(hipMemcpyAsync(ws->qidx.p, c.qidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    TOD_HIP(hipMemcpyAsync(ws->kpxy.p, c.kpxy.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    ObjJob job;
+    job.n = n; job.W = W;
+    job.train = ws->train.as<float>(); job.query = ws->query.as<float>(); job.qidx = ws->qidx.as<uint32_t>();
+    job.kpxy = ws->kpxy.as<float>(); job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
+    u64* bits = ws->bits.as<u64>();
+    job.finite = bits; job.valid = bits + W; job.deg7 = bits + 2 * W;
+    job.sampdeg = ws->sampdeg.as<uint32_t>();
+    hipLaunchKernelGGL(finite_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, job);
+    hipLaunchKernelGGL(adjacency_kernel, dim3(n, (W + 3u) / 4u), dim3(256), 0, st, job, spans[obj], prm->sensor_error);
+    TOD_HIP(hipGetLastError());
+    ctx->counters.last_objects_verified += 1;
+    while (true) {                     // GuessGenerator.cpp:192-231
+      RoundResult rr;
+      todhip_round_trace tr;
+      tr.object = obj; tr.draws_before = rng->draws;
+      rc = ransac_round(ctx, ws, job, nq, prm->sensor_error, prm->n_ransac_iterations, rng, &rr);
+      if (rc != TODHIP_OK) return rc;
+      ctx->counters.last_rounds += 1;
+      tr.draws_after = rng->draws; tr.iterations = rr.iterations; tr.best_iteration = rr.best_iteration;
+      tr.best_count = rr.best_count; tr.n_inlier_kp = (uint32_t)rr.inlier_kp.size();
+      tr.accepted = rr.inlier_kp.size() >= prm->min_inliers;
+      ctx->traces.push_back(tr);
+      if (rr.inlier_kp.size() < prm->min_inliers) break;                 // :205-206
+      hipLaunchKernelGGL(invalidate_kernel, dim3(1), dim3(1024), 0, st, job, ws->kp_bits.as<u64>(), bits + 6 * W);
+      TOD_HIP(hipGetLastError());
+      if (*n_poses >= pose_cap || *n_inlier_kp + rr.inlier_kp.size() > kp_cap) return TODHIP_ECAPACITY;
+      todhip_pose& p = poses[(*n_poses)++];
+      p.object = obj;
+      std::memcpy(p.R, rr.R, sizeof(p.R));
+      std::memcpy(p.t, rr.T, sizeof(p.t));
+      p.inlier_begin = *n_inlier_kp;
+      for (uint32_t v : rr.inlier_kp) inlier_kp[(*n_inlier_kp)++] = v;
+      p.inlier_end = *n_inlier_kp;
+      ctx->counters.last_poses += 1;
+    }
+  }
+  TOD_HIP(hipStreamSynchronize(st));
+  return TODHIP_OK;
+}
+
+int todhip_verify_trace(const todhip_ctx* ctx, todhip_round_trace* out, uint32_t* n) {
+  if (!ctx || !n || (*n && !out)) return TODHIP_EINVAL;
+  const uint32_t cap = *n;
+  *n = (uint32_t)ctx->traces.size();
+  for (uint32_t i = 0; i < cap && i < ctx->traces.size(); ++i) out[i] = ctx->traces[i];
+  return ctx->traces.size() > cap ? TODHIP_ECAPACITY : TODHIP_OK;
+}
+
+int todhip_test_adjacency(todhip_ctx* ctx, const float* train, const float* query, const float* kpxy, uint32_t n,
+                          float span, float err, uint64_t* phys, uint64_t* samp) {
+  if (!ctx || !train || !query || !kpxy || !phys || !samp || n == 0 || n > (uint32_t)kMaxWords * 64u) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  VerifyWs* ws = ws_of(ctx);
+  const uint32_t W = (n + 63u) / 64u;
+  hipStream_t st = ctx->stream;
+  TOD_HIP(ws->train.reserve((size_t)n * 12)); TOD_HIP(ws->query.reserve((size_t)n * 12));
+  TOD_HIP(ws->kpxy.reserve((size_t)n * 8));
+  TOD_HIP(ws->phys.reserve((size_t)n * W * 8)); TOD_HIP(ws->samp.reserve((size_t)n * W * 8));
+  TOD_HIP(ws->bits.reserve((size_t)8 * W * 8));
+  TOD_HIP(hipMemcpyAsync(ws->train.p, train, (size_t)n * 12, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->query.p, query, (size_t)n * 12, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->kpxy.p, kpxy, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  ObjJob job;
+  std::memset(&job, 0, sizeof(job));
+  job.n = n; job.W = W;
+  job.train = ws->train.as<float>(); job.query = ws->query.as<float>(); job.kpxy = ws->kpxy.as<float>();
+  job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
+  hipLaunchKernelGGL(adjacency_kernel, dim3(n, (W + 3u) / 4u), dim3(256), 0, st, job, span, err);
+  TOD_HIP(hipGetLastError());
+  TOD_HIP(hipMemcpyAsync(phys, ws->phys.p, (size_t)n * W * 8, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipMemcpyAsync(samp, ws->samp.p, (size_t)n * W * 8, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
+  return TODHIP_OK;
+}
+
+// Test hook: FillAdjacency + selectWithinDistance (sac_model_registration_graph.h:171-269) for given sample
+// triples (samples_ order). counts[t] = consensus size (0 = rejected by the gate). With stop_level 1 the clique
+// search is skipped and counts[t] = -|F| for hypotheses that reach it. dbg (optional): dbg_stride words per triple.
+int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* query, const float* kpxy, uint32_t n,
+                          float span, float err, const uint32_t* triples, uint32_t n_triples, uint32_t stop_level,
+                          int32_t* counts, uint32_t* dbg, uint32_t dbg_stride) {
+  if (!ctx || !train || !query || !kpxy || !triples || !counts || n < 3 || n > (uint32_t)kMaxWords * 64u || n_triples == 0)
+    return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  int rc = set_big_lds_once(ctx);
+  if (rc != TODHIP_OK) return rc;
+  VerifyWs* ws = ws_of(ctx);
+  const uint32_t W = (n + 63u) / 64u;
+  hipStream_t st = ctx->stream;
+  TOD_HIP(ws->train.reserve((size_t)n * 12)); TOD_HIP(ws->query.reserve((size_t)n * 12));
+  TOD_HIP(ws->qidx.reserve((size_t)n * 4)); TOD_HIP(ws->kpxy.reserve((size_t)n * 8));
+  TOD_HIP(ws->phys.reserve((size_t)n * W * 8)); TOD_HIP(ws->samp.reserve((size_t)n * W * 8));
+  TOD_HIP(ws->bits.reserve((size_t)8 * W * 8)); TOD_HIP(ws->sampdeg.reserve((size_t)n * 4));
+  TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t))); TOD_HIP(ws->h_small.reserve(256 * sizeof(uint32_t)));
+  TOD_HIP(ws->iter_samples.reserve((size_t)n_triples * 12)); TOD_HIP(ws->counts.reserve((size_t)n_triples * 4));
+  TOD_HIP(ws->gate_m.reserve((size_t)n_triples * 4)); TOD_HIP(ws->deferred.reserve((size_t)n_triples * 4));
+  TOD_HIP(ws->stacks.reserve((size_t)kMaxEvalWaves * kStackCap * sizeof(uint16_t)));
+  if (dbg) TOD_HIP(ws->table.reserve((size_t)n_triples * dbg_stride * 4));
+  TOD_HIP(hipMemcpyAsync(ws->train.p, train, (size_t)n * 12, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->query.p, query, (size_t)n * 12, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->kpxy.p, kpxy, (size_t)n * 8, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->iter_samples.p, triples, (size_t)n_triples * 12, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemsetAsync(ws->qidx.p, 0, (size_t)n * 4, st));
+  if (dbg) TOD_HIP(hipMemsetAsync(ws->table.p, 0, (size_t)n_triples * dbg_stride * 4, st));
+  ObjJob job;
+  job.n = n; job.W = W;
+  job.train = ws->train.as<float>(); job.query = ws->query.as<float>(); job.qidx = ws->qidx.as<uint32_t>();
+  job.kpxy = ws->kpxy.as<float>(); job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
+  u64* bits = ws->bits.as<u64>();
+  job.finite = bits; job.valid = bits + W; job.deg7 = bits + 2 * W; job.sampdeg = ws->sampdeg.as<uint32_t>();
+  uint32_t* d_small = ws->small.as<uint32_t>();
+  uint32_t* h_small = ws->h_small.as<uint32_t>();
+  TOD_HIP(hipMemsetAsync(d_small, 0, 64 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(finite_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, job);
+  hipLaunchKernelGGL(adjacency_kernel, dim3(n, (W + 3u) / 4u), dim3(256), 0, st, job, span, err);
+  hipLaunchKernelGGL(round_prep_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, job, d_small);
+  EvalArgs A;
+  A.job = job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = 0; A.it_end = n_triples;
+  A.counts = ws->counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
+  A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>(); A.stacks = ws->stacks.as<uint16_t>();
+  A.stack_cap = kStackCap; A.lds_bytes = kEvalLdsSmall; A.from_deferred = 0; A.n_deferred = 0;
+  A.dbg = dbg ? ws->table.as<uint32_t>() : nullptr; A.dbg_stride = dbg_stride; A.stop_level = stop_level;
+  if (n_triples > kMaxEvalWaves) return TODHIP_EINVAL;
+  hipLaunchKernelGGL(eval_kernel, dim3(n_triples), dim3(64), kEvalLdsSmall, st, A);
+  TOD_HIP(hipGetLastError());
+  TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
+  const uint32_t status = h_small[12], n_def = h_small[14];
+  if (status == 0 && n_def > 0) {
+    A.lds_bytes = kEvalLdsBig; A.from_deferred = 1; A.n_deferred = n_def;
+    TOD_HIP(hipMemsetAsync(d_small + 8, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(eval_kernel, dim3(n_def), dim3(64), kEvalLdsBig, st, A);
+    TOD_HIP(hipGetLastError());
+    TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    TOD_HIP(hipStreamSynchronize(st));
+  }
+  TOD_HIP(hipMemcpyAsync(counts, ws->counts.p, (size_t)n_triples * 4, hipMemcpyDeviceToHost, st));
+  if (dbg) TOD_HIP(hipMemcpyAsync(dbg, ws->table.p, (size_t)n_triples * dbg_stride * 4, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
+  if (h_small[12] != 0) {
+    TOD_DBG("consensus status %u: g=%u value=%u m=%u it=%u", h_small[12], h_small[16], h_small[17], h_small[18], h_small[19]);
+    return TODHIP_ESCRATCH;
+  }
+  return TODHIP_OK;
+}
+
+// Test hook: the clique search on an explicit graph (edges as pairs), FindClique(minimal_size).
+// out3 = {clique size, error flag, steps}. Mirrors the reference's gtest shape (test/test_maximum_clique.cpp).
+int todhip_test_clique(todhip_ctx* ctx, uint32_t m, const uint32_t* edges, uint32_t n_edges, uint32_t minimal_size,
+                       uint32_t* out3) {
+  if (!ctx || !out3 || m == 0 || m > 1024 || (n_edges && !edges)) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  int rc = set_big_lds_once(ctx);
+  if (rc != TODHIP_OK) return rc;
+  VerifyWs* ws = ws_of(ctx);
+  const uint32_t MW = (m + 63u) / 64u;
+  std::vector<u64> adj((size_t)m * MW, 0ull);
+  for (uint32_t e = 0; e < n_edges; ++e) {
+    const uint32_t a = edges[2 * e], b = edges[2 * e + 1];
+    if (a >= m || b >= m || a == b) return TODHIP_EINVAL;
+    adj[(size_t)a * MW + (b >> 6)] |= 1ull << (b & 63u);
+    adj[(size_t)b * MW + (a >> 6)] |= 1ull << (a & 63u);
+  }
+  TOD_HIP(ws->clique_adj.reserve(adj.size() * 8 + 64));
+  TOD_HIP(ws->stacks.reserve((size_t)kStackCap * sizeof(uint16_t)));
+  TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
+  TOD_HIP(hipMemcpyAsync(ws->clique_adj.p, adj.data(), adj.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  const uint32_t lds = gate_lds_bytes(m);
+  if (lds > kEvalLdsBig) return TODHIP_ESCRATCH;
+  hipLaunchKernelGGL(clique_test_kernel, dim3(1), dim3(64), lds, ctx->stream, ws->clique_adj.as<u64>(), m, minimal_size,
+                     ws->stacks.as<uint16_t>(), kStackCap, ws->small.as<uint32_t>());
+  TOD_HIP(hipGetLastError());
+  TOD_HIP(hipMemcpyAsync(out3, ws->small.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  TOD_HIP(hipStreamSynchronize(ctx->stream));
+  return TODHIP_OK;
+}
+
+}  // extern "C"

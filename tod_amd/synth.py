@@ -89,3 +89,56 @@ def random_graph_edges(n, p, seed):
     iu = np.triu_indices(n, 1)
     keep = rng.random(len(iu[0])) < p
     return np.stack([iu[0][keep], iu[1][keep]], axis=1).astype(np.uint32)
+
+
+def make_verify_scene(n_kp, n_objects=6, per_object=400, visible=((1, 0.30),), matches_per_kp=5, seed=0, H=480, W=640,
+                      f=525.0, noise=0.002, nan_frac=0.10, true_match_rank=0):
+    """A hard scene for stage C, with the matches given directly (SURVEY probe P4 style): every keypoint carries
+    `matches_per_kp` matches; a keypoint on a visible object has its true match plus random distractors, a clutter
+    keypoint has only distractors. `visible` = ((object, fraction of keypoints), ...), each object at its own pose.
+    Returns dict(kp_xy, cloud, row_ptr, matches(DMATCH), matches_xyz, spans, poses{obj: (R, t)})."""
+    from .capi import DMATCH_DTYPE
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    model = (rng.random((n_objects, per_object, 3)) - 0.5) * np.array([0.20, 0.15, 0.10])
+    model = model.astype(np.float32)
+    spans = np.sqrt((((model.max(1) - model.min(1)).astype(np.float32)) ** 2).sum(1, dtype=np.float32)).astype(np.float32)
+    xyz = (rng.random((n_kp, 3)) * np.array([1.0, 0.8, 0.8]) + np.array([-0.5, -0.4, 0.6])).astype(np.float32)
+    owner = np.full(n_kp, -1, np.int64)
+    src = np.zeros(n_kp, np.int64)
+    poses = {}
+    start = 0
+    for vi, (obj, frac) in enumerate(visible):
+        cnt = int(round(n_kp * frac))
+        ang = 0.7 + 0.9 * vi
+        c, s_ = np.cos(ang), np.sin(ang)
+        R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
+        t = np.array([0.05 - 0.35 * vi, -0.02 + 0.2 * vi, 0.8 + 0.15 * vi], np.float32)
+        rows = rng.choice(per_object, size=min(cnt, per_object), replace=False)
+        cnt = len(rows)
+        xyz[start:start + cnt] = (model[obj][rows] @ R.T + t + rng.normal(0, noise, (cnt, 3))).astype(np.float32)
+        owner[start:start + cnt] = obj
+        src[start:start + cnt] = rows
+        poses[obj] = (R, t)
+        start += cnt
+    u = np.clip(f * xyz[:, 0] / xyz[:, 2] + W / 2.0, 0, W - 1.001).astype(np.float32)
+    v = np.clip(f * xyz[:, 1] / xyz[:, 2] + H / 2.0, 0, H - 1.001).astype(np.float32)
+    perm = rng.permutation(n_kp)
+    u, v, xyz, owner, src = u[perm], v[perm], xyz[perm], owner[perm], src[perm]
+    cloud = np.full((H, W, 3), np.nan, np.float32)
+    ok = rng.random(n_kp) >= nan_frac
+    cloud[v[ok].astype(np.int64), u[ok].astype(np.int64)] = xyz[ok]
+    kp_xy = np.stack([u, v], axis=1).astype(np.float32)
+    matches = np.zeros(n_kp * matches_per_kp, DMATCH_DTYPE)
+    mxyz = np.zeros((n_kp * matches_per_kp, 3), np.float32)
+    row_ptr = (np.arange(n_kp + 1) * matches_per_kp).astype(np.uint32)
+    for i in range(n_kp):
+        objs = rng.integers(0, n_objects, matches_per_kp)
+        rows = rng.integers(0, per_object, matches_per_kp)
+        if owner[i] >= 0:
+            objs[true_match_rank] = owner[i]
+            rows[true_match_rank] = src[i]
+        for j in range(matches_per_kp):
+            m = i * matches_per_kp + j
+            matches[m] = (i, rows[j], objs[j], float(rng.integers(0, 60)))
+            mxyz[m] = model[objs[j]][rows[j]]
+    return dict(kp_xy=kp_xy, cloud=cloud, row_ptr=row_ptr, matches=matches, matches_xyz=mxyz, spans=spans, poses=poses)
