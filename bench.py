@@ -40,13 +40,15 @@ def parse():
     ap.add_argument("--k", type=int, default=2)
     ap.add_argument("--radius", type=int, default=35)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
-    ap.add_argument("--stages", default="match", help="comma list of: match,verify,orb")
+    ap.add_argument("--stages", default="match,verify", help="comma list of: match,verify")
+    ap.add_argument("--iterations", type=int, default=2500, help="n_ransac_iterations (conf/detection.ork:38)")
+    ap.add_argument("--min-inliers", type=int, default=8, help="min_inliers (conf/detection.ork:39)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(desc, pts, off, frames, k, radius, budget_s, stages):
+def cpu_baseline(desc, pts, off, frames, k, radius, budget_s, stages, iterations=2500, min_inliers=8):
     """The CPU oracle (1 thread, the reference has no threads) on as many whole frames as fit the budget."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -57,7 +59,7 @@ def cpu_baseline(desc, pts, off, frames, k, radius, budget_s, stages):
         rc, row_ptr, m, xyz = O.match(desc, off, pts, fr["q_desc"], k, radius)
         if "verify" in stages:
             rng = O.rng_new(1)
-            O.verify(fr["kp_xy"], fr["cloud"], row_ptr, m, xyz, spans, 8, 2500, 0.01, rng)
+            O.verify(fr["kp_xy"], fr["cloud"], row_ptr, m, xyz, spans, min_inliers, iterations, 0.01, rng)
         t_total += time.perf_counter() - t0
         n += 1
         if t_total > budget_s:
@@ -92,7 +94,7 @@ def main():
 
     stream = torch.cuda.current_stream()
     ctx = capi.Context(local_rank, stream.cuda_stream)
-    ctx.db_load(desc, pts, off, shard_rank=rank, shard_count=world)
+    db_spans = ctx.db_load(desc, pts, off, shard_rank=rank, shard_count=world)
     info = ctx.db_info()
 
     nq, k = args.nq, args.k
@@ -102,6 +104,11 @@ def main():
     d_xyz = torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")
     d_keys = torch.empty((nq, k), dtype=torch.int64, device="cuda")
     d_keys_all = torch.empty((world, nq, k), dtype=torch.int64, device="cuda")
+    do_verify = "verify" in stages
+    d_kp = [torch.from_numpy(fr["kp_xy"]).cuda() for fr in frames] if do_verify else []
+    d_cloud = [torch.from_numpy(fr["cloud"]).cuda() for fr in frames] if do_verify else []
+    H, W = frames[0]["cloud"].shape[:2]
+    n_pose_total = [0]
 
     def step(i):
         q = d_q[i % len(d_q)]
@@ -113,6 +120,15 @@ def main():
             dist.all_gather_into_tensor(d_keys_all.view(-1), d_keys.view(-1))
             ctx.merge_shards_device(d_keys_all.data_ptr(), world, nq, k, args.radius, d_counts.data_ptr(),
                                     d_matches.data_ptr(), d_xyz.data_ptr())
+        if do_verify:
+            # every rank verifies the frame it just matched (the merged candidates are identical on all ranks);
+            # rand() restarts per frame (decision D4)
+            f = i % len(d_q)
+            rng = capi.rng_new(1)
+            poses = ctx.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), H, W, d_counts.data_ptr(),
+                                      d_matches.data_ptr(), d_xyz.data_ptr(), k, db_spans, args.min_inliers,
+                                      args.iterations, 0.01, rng)
+            n_pose_total[0] += len(poses)
 
     def fence():
         torch.cuda.synchronize()
@@ -155,6 +171,8 @@ def main():
             "config": {"workload": "C3: one 640x480 frame = %d ORB descriptors vs %d-descriptor DB (%d objects x 5000), "
                                    "Hamming BF k=%d, radius %d" % (nq, desc.shape[0], args.objects, k, args.radius),
                        "stages": stages, "db_rows_per_gpu": info["shard_rows"],
+                       "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
+                       "poses_per_frame": n_pose_total[0] / max(args.steps + args.warmup, 1),
                        "parallelism": "db-shard x%d + RCCL all-gather of candidates" % world if world > 1 else "1 GPU"},
             "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -166,7 +184,8 @@ def main():
                               "frac": valu_frac, "distances_per_launch": distances},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages)
+            out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
+                                               args.iterations, args.min_inliers)
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -115,6 +115,14 @@ int todhip_verify(todhip_ctx*, const float* kp_xy, uint32_t nq, const float* clo
                   const float* spans, uint32_t n_objs, const todhip_verify_params*, todhip_rng* rng,
                   todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp);
 
+/* Device-resident form: d_kp_xy[nq*2] f32, d_cloud_xyz[H*W*3] f32 and the matcher's fixed-stride outputs
+ * (d_counts[nq] u32, d_matches[nq*k], d_matches_xyz[nq*k*3], exactly what todhip_match_device produced) are in
+ * HBM already; ClusterPerObject (adjacency_ransac.cpp:176-205) runs as kernels. Poses come back to the host. */
+int todhip_verify_device(todhip_ctx*, const void* d_kp_xy, uint32_t nq, const void* d_cloud_xyz, uint32_t H, uint32_t W,
+                         const void* d_counts, const void* d_matches, const void* d_matches_xyz, uint32_t k,
+                         const float* spans, uint32_t n_objs, const todhip_verify_params*, todhip_rng* rng,
+                         todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp);
+
 /* ---- stage A: ORB features (ecto_opencv FeatureDescriptor -> cv::ORB; detector.py:10,27) --------- */
 /* gray: H x W u8, row stride `stride`. Outputs up to n_features keypoints: kp_xy (x,y level-0 pixels),
  * kp_aux (size, angle_deg, response, octave) and 32-byte rBRIEF descriptors. *n_out: capacity in, count out.

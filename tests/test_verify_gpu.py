@@ -176,3 +176,73 @@ def test_empty_and_degenerate_inputs(ctx):
     with pytest.raises(capi.TodError) as e:
         ctx.verify(kp, sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 100, 0.01, rng)
     assert e.value.status == capi.ERANGE
+
+
+# ------------------------------------------------------------------------------------------ device-resident form
+def _verify_device_from_scene(ctx, sc, k, min_inliers, n_iter, seed=1):
+    import torch
+    nq = len(sc["kp_xy"])
+    counts = np.diff(sc["row_ptr"].astype(np.int64)).astype(np.int32)
+    m = np.zeros((nq, k), capi.DMATCH_DTYPE)
+    xyz = np.zeros((nq, k, 3), np.float32)
+    for q in range(nq):
+        lo, hi = int(sc["row_ptr"][q]), int(sc["row_ptr"][q + 1])
+        m[q, :hi - lo] = sc["matches"][lo:hi]
+        xyz[q, :hi - lo] = sc["matches_xyz"][lo:hi]
+    d_kp = torch.from_numpy(np.ascontiguousarray(sc["kp_xy"], np.float32)).cuda()
+    d_cloud = torch.from_numpy(np.ascontiguousarray(sc["cloud"], np.float32)).cuda()
+    d_counts = torch.from_numpy(counts).cuda()
+    d_m = torch.from_numpy(m.view(np.int32).reshape(nq * k, 4).copy()).cuda()
+    d_xyz = torch.from_numpy(xyz.reshape(nq * k, 3)).cuda()
+    torch.cuda.synchronize()
+    rng = capi.rng_new(seed)
+    H, W = sc["cloud"].shape[:2]
+    poses = ctx.verify_device(d_kp.data_ptr(), nq, d_cloud.data_ptr(), H, W, d_counts.data_ptr(), d_m.data_ptr(),
+                              d_xyz.data_ptr(), k, sc["spans"], min_inliers, n_iter, 0.01, rng)
+    return poses, rng, ctx.verify_trace()
+
+
+@pytest.mark.parametrize("cfg", [dict(n_kp=300, visible=((1, 0.30),), seed=300, k=5),
+                                 dict(n_kp=500, visible=((1, 0.30), (4, 0.20)), seed=500, k=5),
+                                 dict(n_kp=250, visible=((2, 0.2), (5, 0.2), (3, 0.2)), seed=41, k=3, matches_per_kp=3)])
+def test_device_form_equals_host_form(ctx, cfg):
+    cfg = dict(cfg)
+    k = cfg.pop("k")
+    sc = synth.make_verify_scene(**cfg)
+    rng_h = capi.rng_new(1)
+    host = ctx.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 400,
+                      0.01, rng_h)
+    host_tr = [(r.object, r.iterations, r.best_iteration, r.best_count, r.draws_after) for r in ctx.verify_trace()]
+    dev, rng_d, dev_tr = _verify_device_from_scene(ctx, sc, k, 8, 400)
+    assert [(r.object, r.iterations, r.best_iteration, r.best_count, r.draws_after) for r in dev_tr] == host_tr
+    assert rng_d.draws == rng_h.draws and list(rng_d.s) == list(rng_h.s)
+    assert len(dev) == len(host) and len(host) >= 1
+    for a, b in zip(dev, host):
+        assert a["object"] == b["object"] and np.array_equal(a["inliers"], b["inliers"])
+        assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])      # same kernels, same inputs
+
+
+def test_device_pipeline_match_then_verify(ctx):
+    """match_device -> verify_device without leaving HBM == oracle on the same frame (C1 shape)"""
+    import torch
+    desc, pts, off = synth.make_db(2, per_object=3000)
+    fr = synth.make_frame(desc, pts, off, 500, frame=4, visible_object=1)
+    spans = ctx.db_load(desc, pts, off)
+    nq, k = 500, 5
+    d_q = torch.from_numpy(fr["q_desc"]).cuda()
+    d_counts = torch.empty(nq, dtype=torch.int32, device="cuda")
+    d_m = torch.empty((nq * k, 4), dtype=torch.int32, device="cuda")
+    d_xyz = torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")
+    d_kp = torch.from_numpy(fr["kp_xy"]).cuda()
+    d_cloud = torch.from_numpy(fr["cloud"]).cuda()
+    torch.cuda.synchronize()
+    ctx.match_device(d_q.data_ptr(), nq, k, 35, d_counts.data_ptr(), d_m.data_ptr(), d_xyz.data_ptr())
+    rng = capi.rng_new(1)
+    poses = ctx.verify_device(d_kp.data_ptr(), nq, d_cloud.data_ptr(), 480, 640, d_counts.data_ptr(), d_m.data_ptr(),
+                              d_xyz.data_ptr(), k, spans, 8, 2500, 0.01, rng)
+    rc, row_ptr, m, xyz = O.match(desc, off, pts, fr["q_desc"], k, 35)
+    rng_o = O.rng_new(1)
+    rc, o_poses, _ = O.verify(fr["kp_xy"], fr["cloud"], row_ptr, m, xyz, O.spans(pts, off), 8, 2500, 0.01, rng_o)
+    assert rng.draws == rng_o.draws and len(poses) == len(o_poses) == 1
+    assert poses[0]["object"] == o_poses[0]["object"] == 1 and np.array_equal(poses[0]["inliers"], o_poses[0]["inliers"])
+    assert np.abs(poses[0]["R"] - o_poses[0]["R"]).max() < POSE_TOL and np.abs(poses[0]["t"] - o_poses[0]["t"]).max() < POSE_TOL

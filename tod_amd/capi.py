@@ -55,7 +55,7 @@ EXPORTS = [
     "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_db_load", "todhip_db_info",
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device",
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
-    "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus",
+    "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
 ]
 
 _lib = None
@@ -213,6 +213,32 @@ class Context:
                                  C.c_uint32(len(sp)), C.byref(prm), C.byref(rng), poses, C.byref(n_poses),
                                  _np_ptr(inl), C.byref(n_inl))
         _check(rc, "todhip_verify")
+        out = []
+        for i in range(n_poses.value):
+            p = poses[i]
+            out.append(dict(object=int(p.object), R=np.array(p.R[:], np.float32).reshape(3, 3),
+                            t=np.array(p.t[:], np.float32), inliers=inl[p.inlier_begin:p.inlier_end].copy()))
+        return out
+
+    def verify_device(self, d_kp_xy, nq, d_cloud, H, W, d_counts, d_matches, d_xyz, k, spans, min_inliers, n_iter,
+                      err, rng, max_poses=64):
+        """Device-pointer form (ints from tensor.data_ptr()); poses are returned on the host."""
+        sp = np.ascontiguousarray(spans, np.float32)
+        prm = VerifyParams(min_inliers, n_iter, err)
+        poses = (Pose * max_poses)()
+        n_poses = C.c_uint32(max_poses)
+        cap = max(nq, 1) * max_poses
+        if getattr(self, "_inl_cap", 0) < cap:
+            self._inl = np.zeros(cap, np.uint32)
+            self._inl_cap = cap
+        inl = self._inl
+        n_inl = C.c_uint32(cap)
+        rc = lib().todhip_verify_device(self._h, C.c_void_p(d_kp_xy), C.c_uint32(nq), C.c_void_p(d_cloud),
+                                        C.c_uint32(H), C.c_uint32(W), C.c_void_p(d_counts), C.c_void_p(d_matches),
+                                        C.c_void_p(d_xyz), C.c_uint32(k), _np_ptr(sp), C.c_uint32(len(sp)),
+                                        C.byref(prm), C.byref(rng), poses, C.byref(n_poses), _np_ptr(inl),
+                                        C.byref(n_inl))
+        _check(rc, "todhip_verify_device")
         out = []
         for i in range(n_poses.value):
             p = poses[i]

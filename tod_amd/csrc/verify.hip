@@ -644,7 +644,7 @@ struct GrowthOut {
 
 // One block. inl/rest/extra are W-word bitsets in global scratch. Sums that the reference accumulates
 // sequentially (centroids in float, the correlation matrix in double) are accumulated sequentially here too,
-// each by one lane, so that the admitted sets are reproducible against the CPU oracle bit for bit.
+// each by one lane, so that the admitted sets are reproducible bit for bit against a sequential CPU evaluation.
 __global__ __launch_bounds__(256) void growth_kernel(ObjJob job, uint32_t s0, uint32_t s1, uint32_t s2, float err,
                                                      u64* inl, u64* rest, u64* extra, uint32_t* kp_list,
                                                      u64* kp_bits, uint32_t kp_words, GrowthOut* out) {
@@ -863,10 +863,94 @@ __global__ __launch_bounds__(1024) void invalidate_kernel(ObjJob job, const u64*
   }
 }
 
+// ------------------------------------------------------------------------------------------------ K_c
+// ClusterPerObject (adjacency_ransac.cpp:176-205) for device-resident inputs. Matches arrive in the matcher's
+// fixed-stride layout (k slots per query, counts[q] used); the flat order (query asc, rank asc) is what the
+// reference's push_back order produces, and grouping by object is stable, so query_indices_ stays
+// non-decreasing per object (App. A Q4).
+__global__ __launch_bounds__(256) void cluster_lookup_kernel(const float* __restrict__ kp_xy, uint32_t nq,
+                                                             const float* __restrict__ cloud, uint32_t H, uint32_t Wimg,
+                                                             const uint32_t* __restrict__ counts, uint32_t* kept,
+                                                             float* qpt, uint32_t* err) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= nq) return;
+  const int row = (int)kp_xy[2 * q + 1], col = (int)kp_xy[2 * q];        // float -> int truncation (:185)
+  if (row < 0 || col < 0 || (uint32_t)row >= H || (uint32_t)col >= Wimg) {
+    atomicExch(err, 1u);
+    kept[q] = 0;
+    return;
+  }
+  const float* p = cloud + 3 * ((size_t)row * Wimg + col);
+  qpt[3 * q] = p[0]; qpt[3 * q + 1] = p[1]; qpt[3 * q + 2] = p[2];
+  kept[q] = isnan(p[0]) ? 0u : counts[q];                                // only .x is tested (:189)
+}
+
+// exclusive scan of kept[0..nq) into offs[0..nq], one block
+__global__ __launch_bounds__(1024) void cluster_scan_kernel(const uint32_t* __restrict__ kept, uint32_t nq, uint32_t* offs) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = (nq + 1023u) / 1024u;
+  const uint32_t lo = min(nq, tid * chunk), hi = min(nq, lo + chunk);
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; ++i) s += kept[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < 1024u; ++i) { const uint32_t c = part[i]; part[i] = acc; acc += c; }
+    offs[nq] = acc;
+  }
+  __syncthreads();
+  uint32_t acc = part[tid];
+  for (uint32_t i = lo; i < hi; ++i) { offs[i] = acc; acc += kept[i]; }
+}
+
+__global__ __launch_bounds__(256) void cluster_scatter_kernel(const float* __restrict__ kp_xy, uint32_t nq, uint32_t k,
+                                                              const todhip_dmatch* __restrict__ matches,
+                                                              const float* __restrict__ mxyz,
+                                                              const uint32_t* __restrict__ kept,
+                                                              const uint32_t* __restrict__ offs,
+                                                              const float* __restrict__ qpt, uint32_t n_objs,
+                                                              uint32_t* obj_of, uint32_t* hist, float* ftrain,
+                                                              float* fquery, uint32_t* fqidx, float* fkp, uint32_t* err) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t q = t / k, j = t % k;
+  if (q >= nq || j >= kept[q]) return;
+  const uint32_t f = offs[q] + j;
+  const todhip_dmatch m = matches[(size_t)q * k + j];
+  uint32_t o = (uint32_t)m.imgIdx;
+  if (m.imgIdx < 0 || o >= n_objs) { atomicExch(err, 2u); o = 0; }
+  obj_of[f] = o;
+  atomicAdd(&hist[o], 1u);
+  for (int c = 0; c < 3; ++c) { ftrain[3 * f + c] = mxyz[((size_t)q * k + j) * 3 + c]; fquery[3 * f + c] = qpt[3 * q + c]; }
+  fqidx[f] = q;
+  fkp[2 * f] = kp_xy[2 * q]; fkp[2 * f + 1] = kp_xy[2 * q + 1];
+}
+
+// stable grouping by object: destination = group offset + number of earlier matches of the same object
+__global__ __launch_bounds__(256) void cluster_group_kernel(uint32_t n_all, const uint32_t* __restrict__ obj_of,
+                                                            const uint32_t* __restrict__ goff,
+                                                            const float* __restrict__ ftrain,
+                                                            const float* __restrict__ fquery,
+                                                            const uint32_t* __restrict__ fqidx,
+                                                            const float* __restrict__ fkp, float* train, float* query,
+                                                            uint32_t* qidx, float* kpxy) {
+  const uint32_t f = blockIdx.x * 256u + threadIdx.x;
+  if (f >= n_all) return;
+  const uint32_t o = obj_of[f];
+  uint32_t rank = 0;
+  for (uint32_t g = 0; g < f; ++g) rank += obj_of[g] == o;
+  const uint32_t d = goff[o] + rank;
+  for (int c = 0; c < 3; ++c) { train[3 * d + c] = ftrain[3 * f + c]; query[3 * d + c] = fquery[3 * f + c]; }
+  qidx[d] = fqidx[f];
+  kpxy[2 * d] = fkp[2 * f]; kpxy[2 * d + 1] = fkp[2 * f + 1];
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct VerifyWs {
   DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, rnd, table, iter_samples, iter_pos, counts, gate_m,
-      small, deferred, stacks, kp_list, kp_bits, clique_adj;
+      small, deferred, stacks, kp_list, kp_bits, clique_adj, c_kept, c_offs, c_qpt, c_obj, c_hist, c_goff, f_train,
+      f_query, f_qidx, f_kp;
   HostBuf h_small, h_counts, h_pos, h_kp;
   std::vector<uint32_t> rnd_host;
 };
@@ -1095,7 +1179,8 @@ void tod_verify_ws_free(todhip_ctx* ctx) {
   VerifyWs* ws = reinterpret_cast<VerifyWs*>(ctx->verify_ws);
   DevBuf* bufs[] = {&ws->train, &ws->query, &ws->qidx, &ws->kpxy, &ws->phys, &ws->samp, &ws->bits, &ws->sampdeg,
                     &ws->rnd, &ws->table, &ws->iter_samples, &ws->iter_pos, &ws->counts, &ws->gate_m, &ws->small,
-                    &ws->deferred, &ws->stacks, &ws->kp_list, &ws->kp_bits, &ws->clique_adj};
+                    &ws->deferred, &ws->stacks, &ws->kp_list, &ws->kp_bits, &ws->clique_adj, &ws->c_kept, &ws->c_offs,
+                    &ws->c_qpt, &ws->c_obj, &ws->c_hist, &ws->c_goff, &ws->f_train, &ws->f_query, &ws->f_qidx, &ws->f_kp};
   for (DevBuf* b : bufs) b->release();
   ws->h_small.release(); ws->h_counts.release(); ws->h_pos.release(); ws->h_kp.release();
   delete ws;
@@ -1123,25 +1208,95 @@ void todhip_rng_seed(todhip_rng* r, uint32_t seed) {
   r->draws = 0;
 }
 
+struct ObjSpan { uint32_t obj, offset, n; };
+
+// GuessGenerator::process after clustering (GuessGenerator.cpp:170-235): the grouped match arrays are resident
+// in ws->train/query/qidx/kpxy; objects are visited in ascending imgIdx.
+static int verify_grouped(todhip_ctx* ctx, VerifyWs* ws, const std::vector<ObjSpan>& objs, uint32_t nq,
+                          const float* spans, const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses,
+                          uint32_t pose_cap, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t kp_cap,
+                          uint32_t* n_inlier_kp) {
+  hipStream_t st = ctx->stream;
+  uint32_t max_n = 0;
+  for (const ObjSpan& o : objs) max_n = std::max(max_n, o.n);
+  if (max_n > (uint32_t)kMaxWords * 64u) return TODHIP_ESCRATCH;
+  if (max_n >= 3) {
+    const uint32_t Wm = (max_n + 63u) / 64u;
+    TOD_HIP(ws->phys.reserve((size_t)max_n * Wm * 8)); TOD_HIP(ws->samp.reserve((size_t)max_n * Wm * 8));
+    TOD_HIP(ws->bits.reserve((size_t)8 * Wm * 8)); TOD_HIP(ws->sampdeg.reserve((size_t)max_n * 4));
+  }
+  for (const ObjSpan& o : objs) {
+    const uint32_t n = o.n;
+    if (n < 3) continue;               // Ransac returns no inliers for < 3 valid matches and draws nothing (:238-241)
+    const uint32_t W = (n + 63u) / 64u;
+    ObjJob job;
+    job.n = n; job.W = W;
+    job.train = ws->train.as<float>() + 3 * (size_t)o.offset; job.query = ws->query.as<float>() + 3 * (size_t)o.offset;
+    job.qidx = ws->qidx.as<uint32_t>() + o.offset; job.kpxy = ws->kpxy.as<float>() + 2 * (size_t)o.offset;
+    job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
+    u64* bits = ws->bits.as<u64>();
+    job.finite = bits; job.valid = bits + W; job.deg7 = bits + 2 * W;
+    job.sampdeg = ws->sampdeg.as<uint32_t>();
+    hipLaunchKernelGGL(finite_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, job);
+    hipLaunchKernelGGL(adjacency_kernel, dim3(n, (W + 3u) / 4u), dim3(256), 0, st, job, spans[o.obj], prm->sensor_error);
+    TOD_HIP(hipGetLastError());
+    ctx->counters.last_objects_verified += 1;
+    while (true) {                     // GuessGenerator.cpp:192-231
+      RoundResult rr;
+      todhip_round_trace tr;
+      tr.object = o.obj; tr.draws_before = rng->draws;
+      int rc = ransac_round(ctx, ws, job, nq, prm->sensor_error, prm->n_ransac_iterations, rng, &rr);
+      if (rc != TODHIP_OK) return rc;
+      ctx->counters.last_rounds += 1;
+      tr.draws_after = rng->draws; tr.iterations = rr.iterations; tr.best_iteration = rr.best_iteration;
+      tr.best_count = rr.best_count; tr.n_inlier_kp = (uint32_t)rr.inlier_kp.size();
+      tr.accepted = rr.inlier_kp.size() >= prm->min_inliers;
+      ctx->traces.push_back(tr);
+      if (rr.inlier_kp.size() < prm->min_inliers) break;                 // :205-206
+      hipLaunchKernelGGL(invalidate_kernel, dim3(1), dim3(1024), 0, st, job, ws->kp_bits.as<u64>(), bits + 6 * W);
+      TOD_HIP(hipGetLastError());
+      if (*n_poses >= pose_cap || *n_inlier_kp + rr.inlier_kp.size() > kp_cap) return TODHIP_ECAPACITY;
+      todhip_pose& p = poses[(*n_poses)++];
+      p.object = o.obj;
+      std::memcpy(p.R, rr.R, sizeof(p.R));
+      std::memcpy(p.t, rr.T, sizeof(p.t));
+      p.inlier_begin = *n_inlier_kp;
+      for (uint32_t v : rr.inlier_kp) inlier_kp[(*n_inlier_kp)++] = v;
+      p.inlier_end = *n_inlier_kp;
+      ctx->counters.last_poses += 1;
+    }
+  }
+  TOD_HIP(hipStreamSynchronize(st));
+  return TODHIP_OK;
+}
+
+static int verify_prologue(todhip_ctx* ctx, const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses,
+                           uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  if (!ctx || !prm || !rng || !n_poses || !n_inlier_kp || (*n_poses && !poses) || (*n_inlier_kp && !inlier_kp))
+    return TODHIP_EINVAL;
+  ctx->counters.last_objects_verified = ctx->counters.last_rounds = ctx->counters.last_hypotheses = 0;
+  ctx->counters.last_gate_calls = ctx->counters.last_poses = 0;
+  ctx->traces.clear();
+  return TODHIP_OK;
+}
+
 int todhip_verify(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float* cloud, uint32_t H, uint32_t Wimg,
                   const uint32_t* row_ptr, const todhip_dmatch* matches, const float* mxyz, const float* spans,
                   uint32_t n_objs, const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses,
                   uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
-  if (!ctx || !prm || !rng || !n_poses || !n_inlier_kp || (*n_poses && !poses) || (*n_inlier_kp && !inlier_kp))
-    return TODHIP_EINVAL;
+  int rc = verify_prologue(ctx, prm, rng, poses, n_poses, inlier_kp, n_inlier_kp);
+  if (rc != TODHIP_OK) return rc;
   const uint32_t pose_cap = *n_poses, kp_cap = *n_inlier_kp;
   *n_poses = 0; *n_inlier_kp = 0;
-  ctx->counters.last_objects_verified = ctx->counters.last_rounds = ctx->counters.last_hypotheses = 0;
-  ctx->counters.last_gate_calls = ctx->counters.last_poses = 0;
-  ctx->traces.clear();
   if (!cloud || H == 0 || Wimg == 0) return TODHIP_OK;   // 2D-only input is an empty TODO (GuessGenerator.cpp:147-152)
   if (nq && (!kp_xy || !row_ptr || !spans)) return TODHIP_EINVAL;
   TOD_HIP(hipSetDevice(ctx->device));
-  int rc = set_big_lds_once(ctx);
+  rc = set_big_lds_once(ctx);
   if (rc != TODHIP_OK) return rc;
   VerifyWs* ws = ws_of(ctx);
 
-  // ---- ClusterPerObject (adjacency_ransac.cpp:176-205): per object, matches in (query asc, rank asc) order
+  // ---- ClusterPerObject (adjacency_ransac.cpp:176-205) on the host buffers the caller handed over: a gather of
+  // one cloud point per keypoint and a bucket by imgIdx; per object, matches stay in (query asc, rank asc) order
   struct HostCluster { std::vector<float> train, query, kpxy; std::vector<uint32_t> qidx; };
   std::map<uint32_t, HostCluster> objects;
   for (uint32_t qi = 0; qi < nq; ++qi) {
@@ -1160,60 +1315,91 @@ int todhip_verify(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float*
   TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
   TOD_HIP(ws->h_small.reserve(256 * sizeof(uint32_t)));
   hipStream_t st = ctx->stream;
-  // ---- objects in ascending imgIdx (GuessGenerator.cpp:170-235)
+  std::vector<ObjSpan> spans_list;
+  uint32_t total = 0;
+  for (auto& kv : objects) { spans_list.push_back({kv.first, total, (uint32_t)kv.second.qidx.size()}); total += (uint32_t)kv.second.qidx.size(); }
+  if (total == 0) return TODHIP_OK;
+  TOD_HIP(ws->train.reserve((size_t)total * 12)); TOD_HIP(ws->query.reserve((size_t)total * 12));
+  TOD_HIP(ws->qidx.reserve((size_t)total * 4)); TOD_HIP(ws->kpxy.reserve((size_t)total * 8));
+  size_t i = 0;
   for (auto& kv : objects) {
-    const uint32_t obj = kv.first;
     HostCluster& c = kv.second;
-    const uint32_t n = (uint32_t)c.qidx.size();
-    if (n < 3) continue;               // Ransac returns no inliers for < 3 valid matches and draws nothing (:238-241)
-    if (n > (uint32_t)kMaxWords * 64u) return TODHIP_ESCRATCH;
-    const uint32_t W = (n + 63u) / 64u;
-    TOD_HIP(ws->train.reserve((size_t)n * 12)); TOD_HIP(ws->query.reserve((size_t)n * 12));
-    TOD_HIP(ws->qidx.reserve((size_t)n * 4)); TOD_HIP(ws->kpxy.reserve((size_t)n * 8));
-    TOD_HIP(ws->phys.reserve((size_t)n * W * 8)); TOD_HIP(ws->samp.reserve((size_t)n * W * 8));
-    TOD_HIP(ws->bits.reserve((size_t)8 * W * 8)); TOD_HIP(ws->sampdeg.reserve((size_t)n * 4));
-    TOD_HIP(hipMemcpyAsync(ws->train.p, c.train.data(), (size_t)n * 12, hipMemcpyHostToDevice, st));
-    TOD_HIP(hipMemcpyAsync(ws->query.p, c.query.data(), (size_t)n * 12, hipMemcpyHostToDevice, st));
-    TOD_HIP(hipMemcpyAsync(ws->qidx.p, c.qidx.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    TOD_HIP(hipMemcpyAsync(ws->kpxy.p, c.kpxy.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-    ObjJob job;
-    job.n = n; job.W = W;
-    job.train = ws->train.as<float>(); job.query = ws->query.as<float>(); job.qidx = ws->qidx.as<uint32_t>();
-    job.kpxy = ws->kpxy.as<float>(); job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
-    u64* bits = ws->bits.as<u64>();
-    job.finite = bits; job.valid = bits + W; job.deg7 = bits + 2 * W;
-    job.sampdeg = ws->sampdeg.as<uint32_t>();
-    hipLaunchKernelGGL(finite_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, job);
-    hipLaunchKernelGGL(adjacency_kernel, dim3(n, (W + 3u) / 4u), dim3(256), 0, st, job, spans[obj], prm->sensor_error);
-    TOD_HIP(hipGetLastError());
-    ctx->counters.last_objects_verified += 1;
-    while (true) {                     // GuessGenerator.cpp:192-231
-      RoundResult rr;
-      todhip_round_trace tr;
-      tr.object = obj; tr.draws_before = rng->draws;
-      rc = ransac_round(ctx, ws, job, nq, prm->sensor_error, prm->n_ransac_iterations, rng, &rr);
-      if (rc != TODHIP_OK) return rc;
-      ctx->counters.last_rounds += 1;
-      tr.draws_after = rng->draws; tr.iterations = rr.iterations; tr.best_iteration = rr.best_iteration;
-      tr.best_count = rr.best_count; tr.n_inlier_kp = (uint32_t)rr.inlier_kp.size();
-      tr.accepted = rr.inlier_kp.size() >= prm->min_inliers;
-      ctx->traces.push_back(tr);
-      if (rr.inlier_kp.size() < prm->min_inliers) break;                 // :205-206
-      hipLaunchKernelGGL(invalidate_kernel, dim3(1), dim3(1024), 0, st, job, ws->kp_bits.as<u64>(), bits + 6 * W);
-      TOD_HIP(hipGetLastError());
-      if (*n_poses >= pose_cap || *n_inlier_kp + rr.inlier_kp.size() > kp_cap) return TODHIP_ECAPACITY;
-      todhip_pose& p = poses[(*n_poses)++];
-      p.object = obj;
-      std::memcpy(p.R, rr.R, sizeof(p.R));
-      std::memcpy(p.t, rr.T, sizeof(p.t));
-      p.inlier_begin = *n_inlier_kp;
-      for (uint32_t v : rr.inlier_kp) inlier_kp[(*n_inlier_kp)++] = v;
-      p.inlier_end = *n_inlier_kp;
-      ctx->counters.last_poses += 1;
-    }
+    const ObjSpan& o = spans_list[i++];
+    if (o.n == 0) continue;
+    TOD_HIP(hipMemcpyAsync(ws->train.as<float>() + 3 * (size_t)o.offset, c.train.data(), (size_t)o.n * 12, hipMemcpyHostToDevice, st));
+    TOD_HIP(hipMemcpyAsync(ws->query.as<float>() + 3 * (size_t)o.offset, c.query.data(), (size_t)o.n * 12, hipMemcpyHostToDevice, st));
+    TOD_HIP(hipMemcpyAsync(ws->qidx.as<uint32_t>() + o.offset, c.qidx.data(), (size_t)o.n * 4, hipMemcpyHostToDevice, st));
+    TOD_HIP(hipMemcpyAsync(ws->kpxy.as<float>() + 2 * (size_t)o.offset, c.kpxy.data(), (size_t)o.n * 8, hipMemcpyHostToDevice, st));
   }
+  TOD_HIP(hipStreamSynchronize(st));   // the host vectors die with this scope
+  return verify_grouped(ctx, ws, spans_list, nq, spans, prm, rng, poses, pose_cap, n_poses, inlier_kp, kp_cap, n_inlier_kp);
+}
+
+// Device-resident form: keypoints, cloud and the matcher's fixed-stride outputs (counts[nq], matches[nq*k],
+// matches_xyz[nq*k*3], see todhip_match_device) are already in HBM; only poses come back to the host.
+int todhip_verify_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const void* d_cloud, uint32_t H,
+                         uint32_t Wimg, const void* d_counts, const void* d_matches, const void* d_mxyz, uint32_t k,
+                         const float* spans, uint32_t n_objs, const todhip_verify_params* prm, todhip_rng* rng,
+                         todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  int rc = verify_prologue(ctx, prm, rng, poses, n_poses, inlier_kp, n_inlier_kp);
+  if (rc != TODHIP_OK) return rc;
+  const uint32_t pose_cap = *n_poses, kp_cap = *n_inlier_kp;
+  *n_poses = 0; *n_inlier_kp = 0;
+  if (!d_cloud || H == 0 || Wimg == 0) return TODHIP_OK;
+  if (nq == 0 || n_objs == 0) return TODHIP_OK;
+  if (!d_kp_xy || !d_counts || !d_matches || !d_mxyz || !spans || k == 0) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  rc = set_big_lds_once(ctx);
+  if (rc != TODHIP_OK) return rc;
+  VerifyWs* ws = ws_of(ctx);
+  hipStream_t st = ctx->stream;
+  const size_t cap = (size_t)nq * k;
+  TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
+  TOD_HIP(ws->h_small.reserve((256 + (size_t)n_objs + 8) * sizeof(uint32_t)));
+  TOD_HIP(ws->c_kept.reserve((size_t)nq * 4)); TOD_HIP(ws->c_offs.reserve(((size_t)nq + 1) * 4));
+  TOD_HIP(ws->c_qpt.reserve((size_t)nq * 12)); TOD_HIP(ws->c_obj.reserve(cap * 4));
+  TOD_HIP(ws->c_hist.reserve((size_t)n_objs * 4)); TOD_HIP(ws->c_goff.reserve((size_t)n_objs * 4));
+  TOD_HIP(ws->f_train.reserve(cap * 12)); TOD_HIP(ws->f_query.reserve(cap * 12));
+  TOD_HIP(ws->f_qidx.reserve(cap * 4)); TOD_HIP(ws->f_kp.reserve(cap * 8));
+  TOD_HIP(ws->train.reserve(cap * 12)); TOD_HIP(ws->query.reserve(cap * 12));
+  TOD_HIP(ws->qidx.reserve(cap * 4)); TOD_HIP(ws->kpxy.reserve(cap * 8));
+  uint32_t* d_small = ws->small.as<uint32_t>();
+  TOD_HIP(hipMemsetAsync(d_small + 60, 0, sizeof(uint32_t), st));
+  TOD_HIP(hipMemsetAsync(ws->c_hist.p, 0, (size_t)n_objs * 4, st));
+  hipLaunchKernelGGL(cluster_lookup_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, st, (const float*)d_kp_xy, nq,
+                     (const float*)d_cloud, H, Wimg, (const uint32_t*)d_counts, ws->c_kept.as<uint32_t>(),
+                     ws->c_qpt.as<float>(), d_small + 60);
+  hipLaunchKernelGGL(cluster_scan_kernel, dim3(1), dim3(1024), 0, st, ws->c_kept.as<uint32_t>(), nq, ws->c_offs.as<uint32_t>());
+  hipLaunchKernelGGL(cluster_scatter_kernel, dim3((uint32_t)((cap + 255u) / 256u)), dim3(256), 0, st, (const float*)d_kp_xy, nq, k,
+                     (const todhip_dmatch*)d_matches, (const float*)d_mxyz, ws->c_kept.as<uint32_t>(),
+                     ws->c_offs.as<uint32_t>(), ws->c_qpt.as<float>(), n_objs, ws->c_obj.as<uint32_t>(),
+                     ws->c_hist.as<uint32_t>(), ws->f_train.as<float>(), ws->f_query.as<float>(),
+                     ws->f_qidx.as<uint32_t>(), ws->f_kp.as<float>(), d_small + 60);
+  TOD_HIP(hipGetLastError());
+  uint32_t* h = ws->h_small.as<uint32_t>();
+  TOD_HIP(hipMemcpyAsync(h + 200, d_small + 60, 4, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipMemcpyAsync(h + 201, ws->c_offs.as<uint32_t>() + nq, 4, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipMemcpyAsync(h + 256, ws->c_hist.p, (size_t)n_objs * 4, hipMemcpyDeviceToHost, st));
   TOD_HIP(hipStreamSynchronize(st));
-  return TODHIP_OK;
+  if (h[200] != 0) return TODHIP_ERANGE;
+  const uint32_t n_all = h[201];
+  if (n_all == 0) return TODHIP_OK;
+  std::vector<ObjSpan> spans_list;
+  std::vector<uint32_t> goff(n_objs, 0u);
+  uint32_t total = 0;
+  for (uint32_t o = 0; o < n_objs; ++o) {
+    goff[o] = total;
+    if (h[256 + o]) spans_list.push_back({o, total, h[256 + o]});
+    total += h[256 + o];
+  }
+  TOD_HIP(hipMemcpyAsync(ws->c_goff.p, goff.data(), (size_t)n_objs * 4, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(cluster_group_kernel, dim3((n_all + 255u) / 256u), dim3(256), 0, st, n_all, ws->c_obj.as<uint32_t>(),
+                     ws->c_goff.as<uint32_t>(), ws->f_train.as<float>(), ws->f_query.as<float>(),
+                     ws->f_qidx.as<uint32_t>(), ws->f_kp.as<float>(), ws->train.as<float>(), ws->query.as<float>(),
+                     ws->qidx.as<uint32_t>(), ws->kpxy.as<float>());
+  TOD_HIP(hipGetLastError());
+  TOD_HIP(hipStreamSynchronize(st));   // goff lives on this stack frame
+  return verify_grouped(ctx, ws, spans_list, nq, spans, prm, rng, poses, pose_cap, n_poses, inlier_kp, kp_cap, n_inlier_kp);
 }
 
 int todhip_verify_trace(const todhip_ctx* ctx, todhip_round_trace* out, uint32_t* n) {
