@@ -4,9 +4,10 @@
 Workload (config C3 of BASELINE.json, also run at N=1 because the 1M-descriptor DB fits one GPU):
 one 640x480 synthetic frame = 1000 ORB descriptors matched against the 1M-descriptor object DB
 (200 objects x 5000), Hamming brute force k=2, radius 35, then geometric verification.
-With N GPUs the descriptor rows are split into N object-aligned shards (strong scaling: the DB is
-fixed), every rank matches the frame against its shard, the per-shard candidates are exchanged with
-one RCCL all-gather and merged with the order (distance asc, global row asc).
+With N GPUs (tod_amd/sharded.py) the descriptor rows are split into N object-aligned shards and a step
+processes N frames, one per rank: descriptors are all-gathered, every rank matches all N frames against
+its shard, the per-shard candidates are exchanged with one RCCL all-gather, and every rank merges (order:
+distance asc, global row asc) and verifies its own frame. Per-GPU work is constant as N grows.
 
 One JSON line on rank 0; see the task contract for the fields. `roofline` is for the dominant kernel
 (hamming_topk_tiles); `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
@@ -84,51 +85,89 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # rehearsal on a 1-GPU box: TOD_BENCH_BACKEND=gloo TOD_BENCH_ONE_DEVICE=1 puts every rank on device 0
+    one_device = os.environ.get("TOD_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("TOD_BENCH_BACKEND", "nccl")
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     desc, pts, off = synth.make_db(args.objects)
     frames = [synth.make_frame(desc, pts, off, args.nq, frame=f, visible_object=(17 * f + 3) % args.objects)
               for f in range(args.frames)]
 
-    stream = torch.cuda.current_stream()
+    # one explicit stream for everything: libtodhip kernels, torch copies and the RCCL collectives (which order
+    # themselves against torch's current stream). The default stream's handle is 0 == "create your own" for
+    # todhip_create, which would put the kernels on a different stream than the collectives.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     ctx = capi.Context(local_rank, stream.cuda_stream)
     db_spans = ctx.db_load(desc, pts, off, shard_rank=rank, shard_count=world)
     info = ctx.db_info()
 
     nq, k = args.nq, args.k
-    d_q = [torch.from_numpy(fr["q_desc"]).cuda() for fr in frames]
+    do_verify = "verify" in stages
+    from tod_amd import sharded
+    # frame f of step i belongs to rank (f % world); every rank keeps its own frames resident in HBM
+    my_frames = [fr for f, fr in enumerate(frames) if f % world == rank] or [frames[rank % len(frames)]]
+    d_q = [torch.from_numpy(fr["q_desc"]).cuda() for fr in my_frames]
+    d_kp = [torch.from_numpy(fr["kp_xy"]).cuda() for fr in my_frames]
+    d_cloud = [torch.from_numpy(fr["cloud"]).cuda() for fr in my_frames] if do_verify else []
+    H, W = frames[0]["cloud"].shape[:2]
     d_counts = torch.empty(nq, dtype=torch.int32, device="cuda")
     d_matches = torch.empty((nq * k, 4), dtype=torch.int32, device="cuda")
     d_xyz = torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")
-    d_keys = torch.empty((nq, k), dtype=torch.int64, device="cuda")
-    d_keys_all = torch.empty((world, nq, k), dtype=torch.int64, device="cuda")
-    do_verify = "verify" in stages
-    d_kp = [torch.from_numpy(fr["kp_xy"]).cuda() for fr in frames] if do_verify else []
-    d_cloud = [torch.from_numpy(fr["cloud"]).cuda() for fr in frames] if do_verify else []
-    H, W = frames[0]["cloud"].shape[:2]
+    d_keys = torch.empty((world * nq, k), dtype=torch.int64, device="cuda")
     n_pose_total = [0]
+    cur = [0]
+
+    def alloc(shape, dtype_name):
+        return torch.empty(shape, dtype=getattr(torch, dtype_name), device="cuda")
+
+    def all_gather(out, inp):
+        if backend == "nccl":
+            dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1))
+        else:                                           # gloo rehearsal: stage through the host
+            parts = [torch.empty(inp.numel(), dtype=inp.dtype) for _ in range(world)]
+            dist.all_gather(parts, inp.contiguous().view(-1).cpu())
+            out.view(-1).copy_(torch.cat(parts).to(out.device))
+
+    def match_shard(q_all):
+        ctx.match_shard_device(q_all.data_ptr(), q_all.shape[0], k, d_keys.data_ptr())
+        return d_keys[:q_all.shape[0]]
+
+    def merge(keys_mine):
+        ctx.merge_shards_device(keys_mine.data_ptr(), keys_mine.shape[0], nq, k, args.radius, d_counts.data_ptr(),
+                                d_matches.data_ptr(), d_xyz.data_ptr())
+        return None
+
+    def verify(_):
+        if not do_verify:
+            return []
+        f = cur[0]
+        rng = capi.rng_new(1)                     # rand() restarts per frame (decision D4)
+        poses = ctx.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), H, W, d_counts.data_ptr(),
+                                  d_matches.data_ptr(), d_xyz.data_ptr(), k, db_spans, args.min_inliers,
+                                  args.iterations, 0.01, rng)
+        n_pose_total[0] += len(poses)
+        return poses
 
     def step(i):
-        q = d_q[i % len(d_q)]
+        f = i % len(d_q)
+        cur[0] = f
         if world == 1:
-            ctx.match_device(q.data_ptr(), nq, k, args.radius, d_counts.data_ptr(), d_matches.data_ptr(),
+            # single device: the tile lists go straight into the finalize kernel (no key exchange)
+            ctx.match_device(d_q[f].data_ptr(), nq, k, args.radius, d_counts.data_ptr(), d_matches.data_ptr(),
                              d_xyz.data_ptr())
+            verify(None)
         else:
-            ctx.match_shard_device(q.data_ptr(), nq, k, d_keys.data_ptr())
-            dist.all_gather_into_tensor(d_keys_all.view(-1), d_keys.view(-1))
-            ctx.merge_shards_device(d_keys_all.data_ptr(), world, nq, k, args.radius, d_counts.data_ptr(),
-                                    d_matches.data_ptr(), d_xyz.data_ptr())
-        if do_verify:
-            # every rank verifies the frame it just matched (the merged candidates are identical on all ranks);
-            # rand() restarts per frame (decision D4)
-            f = i % len(d_q)
-            rng = capi.rng_new(1)
-            poses = ctx.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), H, W, d_counts.data_ptr(),
-                                      d_matches.data_ptr(), d_xyz.data_ptr(), k, db_spans, args.min_inliers,
-                                      args.iterations, 0.01, rng)
-            n_pose_total[0] += len(poses)
+            sharded.sharded_step(dist, world, rank, d_q[f], match_shard, merge, verify, alloc, all_gather)
 
     def fence():
         torch.cuda.synchronize()
@@ -149,31 +188,33 @@ def main():
     c1 = ctx.counters()
     ctx.set_kernel_timing(False)
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
     n_launch = c1.n_match_kernel_launches - c0.n_match_kernel_launches
     k4_ms = (c1.sum_match_kernel_ms - c0.sum_match_kernel_ms) / max(n_launch, 1)
-    alg_bytes = info["shard_rows"] * 32 + nq * 32 + nq * k * 8          # N*32 + Q*32 + Q*k*8
+    alg_bytes = info["shard_rows"] * 32 + world * nq * (32 + k * 8)      # N*32 + F*Q*32 + F*Q*k*8
     achieved = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
-    distances = float(nq) * info["shard_rows"]
+    distances = float(nq) * world * info["shard_rows"]          # every rank matches all `world` frames of a step
     valu_frac = LANEOPS_PER_DISTANCE * distances / (k4_ms * 1e-3) / VALU_PEAK_LANEOPS if k4_ms > 0 else 0.0
 
     if rank == 0:
         out = {
             "metric": "frames/sec @ 640x480, 1M-descriptor DB; achieved HBM GB/s on BF-matcher",
-            "value": args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u32 (xor + popcount), f32 in the verifier",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (xor + popcount), f32 in the verifier",
             "data": "synthetic",
             "config": {"workload": "C3: one 640x480 frame = %d ORB descriptors vs %d-descriptor DB (%d objects x 5000), "
                                    "Hamming BF k=%d, radius %d" % (nq, desc.shape[0], args.objects, k, args.radius),
                        "stages": stages, "db_rows_per_gpu": info["shard_rows"],
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
-                       "poses_per_frame": n_pose_total[0] / max(args.steps + args.warmup, 1),
-                       "parallelism": "db-shard x%d + RCCL all-gather of candidates" % world if world > 1 else "1 GPU"},
+                       "poses_per_frame_rank0": n_pose_total[0] / max(args.steps + args.warmup, 1),
+                       "frames_per_step": world,
+                       "parallelism": ("DB rows sharded x%d (object aligned), one frame per rank per step, RCCL all-gather of "
+                                       "descriptors and of per-shard candidates" % world) if world > 1 else "1 GPU"},
             "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,

@@ -184,3 +184,16 @@ def test_c3_full_size_properties(ctx):
     keys = O.knn_keys(desc, fr["q_desc"][sub], 2)
     assert np.array_equal(keys >> np.uint64(32), d2[sub].astype(np.uint64))
     assert np.array_equal(keys & np.uint64(0xFFFFFFFF), r2[sub].astype(np.uint64))
+
+
+def test_shard_layout_matches_python_mirror(ctx):
+    from tod_amd import sharded
+    desc, pts, off = synth.make_db_ragged([900, 50, 0, 1200, 700, 5, 333, 2000, 41, 800], seed=77)
+    for world in (1, 2, 3, 8):
+        for r in range(world):
+            c = capi.Context(0)
+            c.db_load(desc, pts, off, shard_rank=r, shard_count=world)
+            info = c.db_info()
+            lo, hi, row_lo, row_hi = sharded.shard_bounds(off, r, world)
+            assert (info["shard_first"], info["shard_rows"]) == (row_lo, row_hi - row_lo)
+            c.close()

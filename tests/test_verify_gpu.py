@@ -246,3 +246,47 @@ def test_device_pipeline_match_then_verify(ctx):
     assert rng.draws == rng_o.draws and len(poses) == len(o_poses) == 1
     assert poses[0]["object"] == o_poses[0]["object"] == 1 and np.array_equal(poses[0]["inliers"], o_poses[0]["inliers"])
     assert np.abs(poses[0]["R"] - o_poses[0]["R"]).max() < POSE_TOL and np.abs(poses[0]["t"] - o_poses[0]["t"]).max() < POSE_TOL
+
+
+def test_two_rank_step_in_process(ctx):
+    """tod_amd/sharded.py driven with two contexts on one GPU and in-process 'collectives': every rank's frame
+    must come out exactly as on a single device."""
+    import torch
+    from tod_amd import sharded
+    world, nq, k, radius = 2, 400, 2, 35
+    desc, pts, off = synth.make_db(6, per_object=2000)
+    frames = [synth.make_frame(desc, pts, off, nq, frame=20 + r, visible_object=(1, 4)[r]) for r in range(world)]
+    ctxs = [capi.Context(0) for _ in range(world)]
+    spans = [c.db_load(desc, pts, off, shard_rank=r, shard_count=world) for r, c in enumerate(ctxs)][0]
+    d_q = [torch.from_numpy(f["q_desc"]).cuda() for f in frames]
+    q_all = torch.stack(d_q)                                            # what all_gather of descriptors yields
+    keys = []
+    for r in range(world):
+        kk = torch.empty((world * nq, k), dtype=torch.int64, device="cuda")
+        ctxs[r].match_shard_device(q_all.data_ptr(), world * nq, k, kk.data_ptr())
+        ctxs[r].synchronize()
+        keys.append(kk.reshape(world, nq, k))
+    keys_all = torch.stack(keys)                                        # [shard][frame][Q][k]
+    single = capi.Context(0)
+    single.db_load(desc, pts, off)
+    for r in range(world):
+        mine = keys_all[:, r].contiguous()
+        d_counts = torch.empty(nq, dtype=torch.int32, device="cuda")
+        d_m = torch.empty((nq * k, 4), dtype=torch.int32, device="cuda")
+        d_xyz = torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")
+        ctxs[r].merge_shards_device(mine.data_ptr(), world, nq, k, radius, d_counts.data_ptr(), d_m.data_ptr(),
+                                    d_xyz.data_ptr())
+        d_kp = torch.from_numpy(frames[r]["kp_xy"]).cuda()
+        d_cloud = torch.from_numpy(frames[r]["cloud"]).cuda()
+        torch.cuda.synchronize()
+        rng = capi.rng_new(1)
+        poses = ctxs[r].verify_device(d_kp.data_ptr(), nq, d_cloud.data_ptr(), 480, 640, d_counts.data_ptr(),
+                                      d_m.data_ptr(), d_xyz.data_ptr(), k, spans, 8, 2500, 0.01, rng)
+        row_ptr, m, xyz = single.match(frames[r]["q_desc"], k, radius)
+        assert np.array_equal(d_counts.cpu().numpy(), np.diff(row_ptr.astype(np.int64)))
+        rng1 = capi.rng_new(1)
+        want = single.verify(frames[r]["kp_xy"], frames[r]["cloud"], row_ptr, m, xyz, spans, 8, 2500, 0.01, rng1)
+        assert len(poses) == len(want) == 1 and poses[0]["object"] == (1, 4)[r]
+        assert np.array_equal(poses[0]["inliers"], want[0]["inliers"]) and np.array_equal(poses[0]["R"], want[0]["R"])
+    for c in ctxs + [single]:
+        c.close()
