@@ -1,0 +1,300 @@
+// adapter/ecto_cells.hpp -- the two detection cells of wg-perception/tod, re-hosted on libtodhip.
+//
+// Same cell names, parameter names, tendril names and tendril types as the reference cells
+//   tod::DescriptorMatcher   src/detection/DescriptorMatcher.cpp:58-269
+//   tod::GuessGenerator      src/detection/GuessGenerator.cpp:69-276
+// so that python/object_recognition_tod/detector.py and conf/*.ork run unchanged.
+// The cells hold no algorithm: they convert tendril types to the flat buffers of include/todhip.h.
+//
+// The including translation unit provides the framework types first:
+//   * a ROS/ORK build includes <ecto/ecto.hpp>, <opencv2/core/core.hpp>, <opencv2/features2d/features2d.hpp>,
+//     ORK-core's ModelReader.h / pose_result.h and defines TOD_AMD_WITH_ORK;
+//   * this repo's test includes tests/mini_ecto/mini_ecto.hpp (a test double, not part of the product).
+#pragma once
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../include/todhip.h"
+
+namespace tod_amd {
+
+// ---- the two JSON lookups the cells need ("radius": 35, "type": "LSH"); no dependency on json_spirit
+inline bool json_find(const std::string& js, const std::string& key, size_t* value_pos) {
+  const std::string pat = "\"" + key + "\"";
+  size_t p = js.find(pat);
+  if (p == std::string::npos) return false;
+  p = js.find(':', p + pat.size());
+  if (p == std::string::npos) return false;
+  ++p;
+  while (p < js.size() && (js[p] == ' ' || js[p] == '\t' || js[p] == '\n')) ++p;
+  *value_pos = p;
+  return true;
+}
+inline double json_number(const std::string& js, const std::string& key, double dflt) {
+  size_t p;
+  if (!json_find(js, key, &p)) return dflt;
+  return std::strtod(js.c_str() + p, nullptr);
+}
+inline std::string json_string(const std::string& js, const std::string& key, const std::string& dflt) {
+  size_t p;
+  if (!json_find(js, key, &p) || p >= js.size() || js[p] != '"') return dflt;
+  const size_t e = js.find('"', p + 1);
+  return e == std::string::npos ? dflt : js.substr(p + 1, e - p - 1);
+}
+
+typedef std::string ObjectId;   // object_recognition_core::db::ObjectId
+
+// One shared context per process (one HIP device + stream); cells of one plasm run sequentially.
+inline todhip_ctx* shared_context() {
+  static todhip_ctx* ctx = nullptr;
+  if (!ctx) {
+    const char* dev = std::getenv("TODHIP_DEVICE");
+    if (todhip_create(dev ? std::atoi(dev) : 0, nullptr, &ctx) != TODHIP_OK)
+      throw std::runtime_error("todhip_create failed: no usable MI355X / HIP device");
+  }
+  return ctx;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+struct DescriptorMatcher
+#ifdef TOD_AMD_WITH_ORK
+    : public object_recognition_core::db::bases::ModelReaderBase
+#endif
+{
+  // DescriptorMatcher.cpp:131-140
+  static void declare_params(ecto::tendrils& p) {
+#ifdef TOD_AMD_WITH_ORK
+    object_recognition_core::db::bases::declare_params_impl(p, "TOD");
+#endif
+    p.declare<std::string>("search_json_params",
+                           "JSON string that can contain the following fields: \"radius\" (for epsilon nearest "
+                           "neighbor search), \"ratio\" when applying the ratio criterion like in SIFT").required(true);
+  }
+  // DescriptorMatcher.cpp:142-152
+  static void declare_io(const ecto::tendrils&, ecto::tendrils& inputs, ecto::tendrils& outputs) {
+    inputs.declare<cv::Mat>("descriptors", "The descriptors to match to the database");
+    outputs.declare<std::vector<std::vector<cv::DMatch> > >("matches", "The matches for the input descriptors");
+    outputs.declare<std::vector<cv::Mat> >("matches_3d", "For each point, the 3d position of the matches, 1 by n "
+                                                         "matrix with 3 channels for, x, y, and z.");
+    outputs.declare<std::vector<ObjectId> >("object_ids", "The ids of the objects");
+    outputs.declare<std::map<ObjectId, float> >("spans", "The ids of the objects");
+  }
+  // DescriptorMatcher.cpp:154-188: radius_/ratio_ are `unsigned int` there (:257-259), so 0.8 -> 0
+  void configure(const ecto::tendrils& params, const ecto::tendrils&, const ecto::tendrils&) {
+#ifdef TOD_AMD_WITH_ORK
+    configure_impl();
+#endif
+    const std::string js = params.get<std::string>("search_json_params");
+    radius_ = (unsigned int)json_number(js, "radius", 0);
+    ratio_ = (unsigned int)json_number(js, "ratio", 0);
+    // The reference accepts only "LSH" and `throw;`s otherwise (:182-186). The LSH table parameters
+    // (n_tables, key_size, multi_probe_level) select an *approximate* index there; here the search is exact.
+    if (json_string(js, "type", "") != "LSH") throw std::runtime_error("Search not implemented for that type");
+    ctx_ = shared_context();
+  }
+  // DescriptorMatcher.cpp:60-129. `docs`: per object the "descriptors" (n x 32 CV_8U) and "points" attachments.
+  struct ObjectModel { ObjectId id; cv::Mat descriptors, points; };
+  void load_models(const std::vector<ObjectModel>& docs) {
+    object_ids_.clear();
+    std::vector<todhip_object> objs;
+    keep_.clear();
+    for (size_t i = 0; i < docs.size(); ++i) {
+      cv::Mat pts = docs[i].points;
+      if (pts.rows != 1) pts = pts.t();                                  // :84-85
+      keep_.push_back(docs[i].descriptors.isContinuous() ? docs[i].descriptors : docs[i].descriptors.clone());
+      keep_.push_back(pts.isContinuous() ? pts : pts.clone());
+      todhip_object o;
+      o.desc = keep_[2 * i].template ptr<uint8_t>(0);
+      o.pts_xyz = keep_[2 * i + 1].template ptr<float>(0);
+      o.n = (uint32_t)keep_[2 * i].rows;
+      objs.push_back(o);
+      object_ids_.push_back(docs[i].id);
+    }
+    std::vector<float> spans(docs.size());
+    const int rc = todhip_db_load(ctx_, objs.data(), (uint32_t)objs.size(), 32, 0, 1, spans.data());
+    if (rc != TODHIP_OK) throw std::runtime_error("todhip_db_load failed");
+    spans_.clear();
+    for (size_t i = 0; i < docs.size(); ++i) spans_[docs[i].id] = spans[i];
+    keep_.clear();
+  }
+#ifdef TOD_AMD_WITH_ORK
+  void parameter_callback(const object_recognition_core::db::Documents& db_documents) {
+    std::vector<ObjectModel> docs;
+    BOOST_FOREACH(const object_recognition_core::db::Document& document, db_documents) {
+      ObjectModel m;
+      m.id = document.get_field<std::string>("object_id");
+      document.get_attachment<cv::Mat>("descriptors", m.descriptors);
+      document.get_attachment<cv::Mat>("points", m.points);
+      docs.push_back(m);
+    }
+    load_models(docs);
+  }
+#endif
+  // DescriptorMatcher.cpp:195-252
+  int process(const ecto::tendrils& inputs, const ecto::tendrils& outputs) {
+    const cv::Mat& descriptors = inputs.get<cv::Mat>("descriptors");
+    std::vector<std::vector<cv::DMatch> > matches;
+    const uint32_t nq = (uint32_t)descriptors.rows, k = 5;               // knnMatch(descriptors, matches, 5), :211
+    std::vector<uint32_t> row_ptr(nq + 1, 0u);
+    std::vector<todhip_dmatch> flat((size_t)nq * k);
+    std::vector<float> xyz((size_t)nq * k * 3);
+    if (radius_) {                                                       // :202
+      cv::Mat q = descriptors.isContinuous() ? descriptors : descriptors.clone();
+      const int rc = todhip_match(ctx_, q.template ptr<uint8_t>(0), nq, k, radius_, row_ptr.data(), flat.data(), xyz.data());
+      if (rc == TODHIP_ENODB) return ecto::OK;                           // "No descriptors loaded", :204-208
+      if (rc != TODHIP_OK) throw std::runtime_error("todhip_match failed");
+      matches.resize(nq);
+    }
+    std::vector<cv::Mat> matches_3d(nq);
+    for (uint32_t qi = 0; qi < nq && !matches.empty(); ++qi) {
+      const uint32_t lo = row_ptr[qi], hi = row_ptr[qi + 1];
+      matches[qi].resize(hi - lo);
+      static_assert(sizeof(cv::DMatch) == sizeof(todhip_dmatch), "cv::DMatch layout");
+      if (hi > lo) std::memcpy(&matches[qi][0], &flat[lo], (hi - lo) * sizeof(todhip_dmatch));
+      matches_3d[qi] = cv::Mat(1, (int)(hi - lo), CV_32FC3);
+      if (hi > lo) std::memcpy(matches_3d[qi].template ptr<float>(0), &xyz[3 * (size_t)lo], (hi - lo) * 12);
+    }
+    outputs["matches"] << matches;
+    outputs["matches_3d"] << matches_3d;
+    outputs["object_ids"] << object_ids_;
+    outputs["spans"] << spans_;
+    return ecto::OK;
+  }
+
+  todhip_ctx* ctx_ = nullptr;
+  unsigned int radius_ = 0, ratio_ = 0;
+  std::vector<ObjectId> object_ids_;
+  std::map<ObjectId, float> spans_;
+  std::vector<cv::Mat> keep_;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// What GuessGenerator publishes per pose when ORK-core's PoseResult is not available (the test double).
+struct PoseOut { ObjectId object_id; float R[9]; float T[3]; std::vector<unsigned int> inlier_keypoints; };
+
+struct GuessGenerator {
+  // GuessGenerator.cpp:71-81
+  static void declare_params(ecto::tendrils& params) {
+    params.declare<unsigned int>("min_inliers", "Minimum number of inliers", 15u);
+    params.declare<unsigned int>("n_ransac_iterations", "Number of RANSAC iterations.", 1000u);
+    params.declare<float>("sensor_error", "The error (in meters) from the Kinect", 0.01f);
+    params.declare<bool>("visualize", "If true, display temporary info through highgui", false);
+    params.declare<std::string>("db", "The DB to get data from, as a JSON string").required(true);
+  }
+  // GuessGenerator.cpp:83-99
+  static void declare_io(const ecto::tendrils&, ecto::tendrils& inputs, ecto::tendrils& outputs) {
+    inputs.declare<cv::Mat>("image", "The height by width 3 channel point cloud");
+    inputs.declare<cv::Mat>("points3d", "The height by width 3 channel point cloud");
+    inputs.declare<std::vector<cv::KeyPoint> >("keypoints", "The interesting keypoints");
+    inputs.declare<std::vector<std::vector<cv::DMatch> > >("matches", "The list of OpenCV DMatch");
+    inputs.declare<std::vector<cv::Mat> >("matches_3d", "The corresponding 3d position of those matches. For each "
+                                                        "point, a 1 by n 3 channel matrix (for x,y and z)");
+    inputs.declare<std::map<ObjectId, float> >("spans", "For each found object, its span based on known features.");
+    inputs.declare<std::vector<ObjectId> >("object_ids", "The ids used in the matches");
+#ifdef TOD_AMD_WITH_ORK
+    outputs.declare<std::vector<object_recognition_core::common::PoseResult> >("pose_results", "The results of object recognition");
+#else
+    outputs.declare<std::vector<PoseOut> >("pose_results", "The results of object recognition");
+#endif
+    outputs.declare<std::vector<cv::Mat> >("Rs", "The rotations of the poses (useful for visualization)");
+    outputs.declare<std::vector<cv::Mat> >("Ts", "The translations of the poses (useful for visualization)");
+  }
+  // GuessGenerator.cpp:101-120 (the visualisation colours are dropped, decision D5)
+  void configure(const ecto::tendrils& params, const ecto::tendrils&, const ecto::tendrils&) {
+    min_inliers_ = params.get<unsigned int>("min_inliers");
+    n_ransac_iterations_ = params.get<unsigned int>("n_ransac_iterations");
+    sensor_error_ = params.get<float>("sensor_error");
+#ifdef TOD_AMD_WITH_ORK
+    db_ = object_recognition_core::db::ObjectDbParameters(params.get<std::string>("db")).generateDb();
+#endif
+    ctx_ = shared_context();
+    todhip_rng_seed(&rng_, 1);          // the reference never calls srand (sac.h:71): one stream per process
+  }
+  // GuessGenerator.cpp:127-250
+  int process(const ecto::tendrils& inputs, const ecto::tendrils& outputs) {
+    const std::vector<std::vector<cv::DMatch> >& matches = inputs.get<std::vector<std::vector<cv::DMatch> > >("matches");
+    const std::vector<cv::Mat>& matches_3d = inputs.get<std::vector<cv::Mat> >("matches_3d");
+    const std::vector<cv::KeyPoint>& keypoints = inputs.get<std::vector<cv::KeyPoint> >("keypoints");
+    const cv::Mat point_cloud = inputs.get<cv::Mat>("points3d");
+    const std::vector<ObjectId>& object_ids_in = inputs.get<std::vector<ObjectId> >("object_ids");
+    const std::map<ObjectId, float>& spans = inputs.get<std::map<ObjectId, float> >("spans");
+    std::vector<cv::Mat> Rs, Ts;
+#ifdef TOD_AMD_WITH_ORK
+    std::vector<object_recognition_core::common::PoseResult> pose_results;
+#else
+    std::vector<PoseOut> pose_results;
+#endif
+    if (!point_cloud.empty()) {                                          // :147-152: the 2D-only branch is a TODO
+      const uint32_t nq = (uint32_t)matches.size();
+      std::vector<float> kp(2 * (size_t)keypoints.size());
+      for (size_t i = 0; i < keypoints.size(); ++i) { kp[2 * i] = keypoints[i].pt.x; kp[2 * i + 1] = keypoints[i].pt.y; }
+      std::vector<uint32_t> row_ptr(nq + 1, 0u);
+      for (uint32_t q = 0; q < nq; ++q) row_ptr[q + 1] = row_ptr[q] + (uint32_t)matches[q].size();
+      std::vector<todhip_dmatch> flat(row_ptr[nq]);
+      std::vector<float> xyz(3 * (size_t)row_ptr[nq]);
+      for (uint32_t q = 0; q < nq; ++q) {
+        const uint32_t n = (uint32_t)matches[q].size();
+        if (!n) continue;
+        std::memcpy(&flat[row_ptr[q]], &matches[q][0], n * sizeof(todhip_dmatch));
+        std::memcpy(&xyz[3 * (size_t)row_ptr[q]], matches_3d[q].template ptr<float>(0), n * 12);
+      }
+      std::vector<float> span_by_index(object_ids_in.size(), 0.f);
+      for (size_t o = 0; o < object_ids_in.size(); ++o) {
+        std::map<ObjectId, float>::const_iterator it = spans.find(object_ids_in[o]);   // :186
+        if (it != spans.end()) span_by_index[o] = it->second;
+      }
+      cv::Mat cloud = point_cloud.isContinuous() ? point_cloud : point_cloud.clone();
+      todhip_verify_params prm = {min_inliers_, n_ransac_iterations_, sensor_error_};
+      std::vector<todhip_pose> poses(256);
+      std::vector<uint32_t> inl((size_t)256 * (keypoints.size() + 1));
+      uint32_t n_poses = (uint32_t)poses.size(), n_inl = (uint32_t)inl.size();
+      const int rc = todhip_verify(ctx_, kp.data(), nq, cloud.template ptr<float>(0), (uint32_t)cloud.rows,
+                                   (uint32_t)cloud.cols, row_ptr.data(), flat.data(), xyz.data(), span_by_index.data(),
+                                   (uint32_t)span_by_index.size(), &prm, &rng_, poses.data(), &n_poses, inl.data(), &n_inl);
+      if (rc != TODHIP_OK) throw std::runtime_error("todhip_verify failed");
+      for (uint32_t i = 0; i < n_poses; ++i) {                            // :223-230
+        cv::Mat R(3, 3, CV_32F), T(3, 1, CV_32F);
+        std::memcpy(R.template ptr<float>(0), poses[i].R, 36);
+        std::memcpy(T.template ptr<float>(0), poses[i].t, 12);
+#ifdef TOD_AMD_WITH_ORK
+        object_recognition_core::common::PoseResult pr;
+        pr.set_R(R); pr.set_T(T); pr.set_object_id(db_, object_ids_in[poses[i].object]);
+        pose_results.push_back(pr);
+#else
+        PoseOut pr;
+        pr.object_id = object_ids_in[poses[i].object];
+        std::memcpy(pr.R, poses[i].R, 36); std::memcpy(pr.T, poses[i].t, 12);
+        pr.inlier_keypoints.assign(inl.begin() + poses[i].inlier_begin, inl.begin() + poses[i].inlier_end);
+        pose_results.push_back(pr);
+#endif
+        Rs.push_back(R); Ts.push_back(T);
+      }
+    }
+    outputs["pose_results"] << pose_results;
+    outputs["Rs"] << Rs;
+    outputs["Ts"] << Ts;
+    return ecto::OK;
+  }
+
+  todhip_ctx* ctx_ = nullptr;
+  todhip_rng rng_;
+  unsigned int min_inliers_ = 15, n_ransac_iterations_ = 1000;
+  float sensor_error_ = 0.01f;
+#ifdef TOD_AMD_WITH_ORK
+  object_recognition_core::db::ObjectDbPtr db_;
+#endif
+};
+
+}  // namespace tod_amd
+
+#ifdef TOD_AMD_WITH_ORK
+// src/detection/module.cpp:38 and the ECTO_CELL lines of the two reference files (:269, :275)
+ECTO_CELL(ecto_detection, tod_amd::DescriptorMatcher, "DescriptorMatcher", "Given descriptors, find matches, relating to objects.");
+ECTO_CELL(ecto_detection, tod_amd::GuessGenerator, "GuessGenerator", "Given descriptors and 3D positions, compute object guesses.");
+#endif

@@ -1,0 +1,135 @@
+// Drives adapter/ecto_cells.hpp the way the ecto scheduler and python/object_recognition_tod/detector.py:56-110
+// do: declare_params / declare_io / configure / (model load) / process, DescriptorMatcher -> GuessGenerator.
+// Inputs are read from binary files written by tests/test_adapter_gpu.py; outputs are written back for comparison.
+#include "mini_ecto/mini_ecto.hpp"
+#include "../adapter/ecto_cells.hpp"
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+template <typename T> static std::vector<T> slurp(const std::string& path) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  const size_t n = (size_t)f.tellg();
+  std::vector<T> v(n / sizeof(T));
+  f.seekg(0);
+  f.read(reinterpret_cast<char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+  return v;
+}
+template <typename T> static void dump(const std::string& path, const std::vector<T>& v) {
+  std::ofstream f(path, std::ios::binary);
+  f.write(reinterpret_cast<const char*>(v.data()), (std::streamsize)(v.size() * sizeof(T)));
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::cerr << "usage: adapter_test <dir> [declare-only]\n"; return 2; }
+  const std::string dir = argv[1];
+  try {
+    // ---- what the cells declare must carry the reference's names
+    ecto::tendrils mp, mi, mo, gp, gi, go;
+    tod_amd::DescriptorMatcher::declare_params(mp);
+    tod_amd::DescriptorMatcher::declare_io(mp, mi, mo);
+    tod_amd::GuessGenerator::declare_params(gp);
+    tod_amd::GuessGenerator::declare_io(gp, gi, go);
+    const char* want_m_out[] = {"matches", "matches_3d", "object_ids", "spans"};
+    const char* want_g_in[] = {"image", "points3d", "keypoints", "matches", "matches_3d", "spans", "object_ids"};
+    const char* want_g_out[] = {"pose_results", "Rs", "Ts"};
+    const char* want_g_par[] = {"min_inliers", "n_ransac_iterations", "sensor_error", "visualize", "db"};
+    if (!mp.has("search_json_params") || !mi.has("descriptors")) return 3;
+    for (const char* n : want_m_out) if (!mo.has(n)) return 3;
+    for (const char* n : want_g_in) if (!gi.has(n)) return 3;
+    for (const char* n : want_g_out) if (!go.has(n)) return 3;
+    for (const char* n : want_g_par) if (!gp.has(n)) return 3;
+    if (gp.get<unsigned int>("min_inliers") != 15u || gp.get<unsigned int>("n_ransac_iterations") != 1000u) return 3;
+    if (argc > 2) { std::cout << "declare ok\n"; return 0; }
+
+    // ---- configure as conf/detection.ork:32-42 would
+    mp["search_json_params"] << std::string("{\"type\": \"LSH\", \"module\": \"ecto_opencv.features2d\", \"key_size\": 16, "
+                                            "\"multi_probe_level\": 1, \"n_tables\": 10, \"radius\": 35, \"ratio\": 0.8}");
+    gp["min_inliers"] << 8u;
+    gp["n_ransac_iterations"] << 2500u;
+    gp["sensor_error"] << 0.01f;
+    gp["db"] << std::string("{}");
+    tod_amd::DescriptorMatcher matcher;
+    tod_amd::GuessGenerator guess;
+    matcher.configure(mp, mi, mo);
+    guess.configure(gp, gi, go);
+
+    // ---- models (what parameter_callback receives from the DB)
+    std::vector<uint32_t> off = slurp<uint32_t>(dir + "/obj_off.bin");
+    std::vector<uint8_t> desc = slurp<uint8_t>(dir + "/desc.bin");
+    std::vector<float> pts = slurp<float>(dir + "/pts.bin");
+    std::vector<tod_amd::DescriptorMatcher::ObjectModel> docs;
+    for (size_t o = 0; o + 1 < off.size(); ++o) {
+      const int n = (int)(off[o + 1] - off[o]);
+      tod_amd::DescriptorMatcher::ObjectModel m;
+      m.id = "object_" + std::to_string(o);
+      m.descriptors = cv::Mat(n, 32, CV_8U);
+      m.points = cv::Mat(n, 1, CV_32FC3);                      // stored n x 1: the cell transposes to 1 x n (:84-85)
+      if (n) {
+        std::memcpy(m.descriptors.ptr<uint8_t>(0), &desc[(size_t)off[o] * 32], (size_t)n * 32);
+        std::memcpy(m.points.ptr<float>(0), &pts[(size_t)off[o] * 3], (size_t)n * 12);
+      }
+      docs.push_back(m);
+    }
+    matcher.load_models(docs);
+
+    // ---- one frame through both cells
+    std::vector<uint8_t> q = slurp<uint8_t>(dir + "/q_desc.bin");
+    std::vector<float> kp = slurp<float>(dir + "/kp_xy.bin");
+    std::vector<float> cloud = slurp<float>(dir + "/cloud.bin");
+    const int nq = (int)(q.size() / 32), H = 480, W = 640;
+    cv::Mat qm(nq, 32, CV_8U);
+    std::memcpy(qm.ptr<uint8_t>(0), q.data(), q.size());
+    mi["descriptors"] << qm;
+    if (matcher.process(mi, mo) != ecto::OK) return 4;
+
+    std::vector<cv::KeyPoint> kps(nq);
+    for (int i = 0; i < nq; ++i) { kps[i].pt.x = kp[2 * i]; kps[i].pt.y = kp[2 * i + 1]; }
+    cv::Mat cm(H, W, CV_32FC3);
+    std::memcpy(cm.ptr<float>(0), cloud.data(), cloud.size() * 4);
+    gi["image"] << cv::Mat();
+    gi["points3d"] << cm;
+    gi["keypoints"] << kps;
+    gi["matches"] << mo.get<std::vector<std::vector<cv::DMatch> > >("matches");
+    gi["matches_3d"] << mo.get<std::vector<cv::Mat> >("matches_3d");
+    gi["spans"] << mo.get<std::map<tod_amd::ObjectId, float> >("spans");
+    gi["object_ids"] << mo.get<std::vector<tod_amd::ObjectId> >("object_ids");
+    if (guess.process(gi, go) != ecto::OK) return 5;
+
+    // ---- outputs for the Python side
+    const std::vector<std::vector<cv::DMatch> >& matches = mo.get<std::vector<std::vector<cv::DMatch> > >("matches");
+    std::vector<int32_t> flat;
+    std::vector<float> dist;
+    for (size_t qi = 0; qi < matches.size(); ++qi)
+      for (const cv::DMatch& m : matches[qi]) { flat.push_back(m.queryIdx); flat.push_back(m.trainIdx); flat.push_back(m.imgIdx); dist.push_back(m.distance); }
+    dump(dir + "/out_matches.bin", flat);
+    dump(dir + "/out_dist.bin", dist);
+    const std::vector<tod_amd::PoseOut>& poses = go.get<std::vector<tod_amd::PoseOut> >("pose_results");
+    std::vector<float> rt;
+    std::vector<uint32_t> inl;
+    for (const tod_amd::PoseOut& p : poses) {
+      for (float v : p.R) rt.push_back(v);
+      for (float v : p.T) rt.push_back(v);
+      inl.push_back((uint32_t)std::stoul(p.object_id.substr(7)));
+      inl.push_back((uint32_t)p.inlier_keypoints.size());
+      for (unsigned v : p.inlier_keypoints) inl.push_back(v);
+    }
+    dump(dir + "/out_poses.bin", rt);
+    dump(dir + "/out_inliers.bin", inl);
+    const std::vector<cv::Mat>& Rs = go.get<std::vector<cv::Mat> >("Rs");
+    std::cout << "adapter ok: " << dist.size() << " matches, " << poses.size() << " poses, " << Rs.size() << " Rs\n";
+    // a non-LSH search type must throw, as DescriptorMatcher.cpp:182-186 does
+    ecto::tendrils bad;
+    tod_amd::DescriptorMatcher::declare_params(bad);
+    bad["search_json_params"] << std::string("{\"type\": \"KDTREE\", \"radius\": 35}");
+    bool threw = false;
+    try { tod_amd::DescriptorMatcher m2; m2.configure(bad, mi, mo); } catch (const std::exception&) { threw = true; }
+    if (!threw) return 6;
+    return 0;
+  } catch (const std::exception& e) {
+    std::cerr << "adapter_test: " << e.what() << "\n";
+    return 1;
+  }
+}

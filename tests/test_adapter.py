@@ -1,0 +1,56 @@
+"""The ecto adapter (adapter/ecto_cells.hpp) compiled against the mini_ecto test double: cell/tendril names on CPU,
+and on the GPU a full DescriptorMatcher -> GuessGenerator frame whose outputs must equal the C-ABI results."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "adapter_test")
+
+
+def _build():
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-o", EXE, os.path.join(ROOT, "tests", "adapter_test.cpp"),
+           "-L" + os.path.join(ROOT, "tod_amd"), "-ltodhip", "-Wl,-rpath," + os.path.join(ROOT, "tod_amd"),
+           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+
+
+def test_adapter_compiles_and_declares_reference_names():
+    """tendril and parameter names/defaults of DescriptorMatcher.cpp:131-152 and GuessGenerator.cpp:71-99"""
+    _build()
+    out = subprocess.run([EXE, tempfile.gettempdir(), "declare-only"], capture_output=True, text=True)
+    assert out.returncode == 0 and "declare ok" in out.stdout, out.stderr
+
+
+@pytest.mark.gpu
+def test_adapter_frame_equals_c_abi():
+    from tod_amd import capi, synth
+    if not os.path.exists(EXE):
+        _build()
+    desc, pts, off = synth.make_db_ragged([3000, 10, 2500], seed=5)
+    fr = synth.make_frame(desc, pts, off, 500, frame=3, visible_object=2)
+    with tempfile.TemporaryDirectory() as d:
+        for name, arr in (("desc", desc), ("pts", pts), ("obj_off", off.astype(np.uint32)), ("q_desc", fr["q_desc"]),
+                          ("kp_xy", fr["kp_xy"]), ("cloud", fr["cloud"])):
+            np.ascontiguousarray(arr).tofile(os.path.join(d, name + ".bin"))
+        out = subprocess.run([EXE, d], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        m = np.fromfile(os.path.join(d, "out_matches.bin"), np.int32).reshape(-1, 3)
+        dist = np.fromfile(os.path.join(d, "out_dist.bin"), np.float32)
+        rt = np.fromfile(os.path.join(d, "out_poses.bin"), np.float32).reshape(-1, 12)
+        inl = np.fromfile(os.path.join(d, "out_inliers.bin"), np.uint32)
+    ctx = capi.Context(0)
+    spans = ctx.db_load(desc, pts, off)
+    row_ptr, gm, xyz = ctx.match(fr["q_desc"], 5, 35)          # the cell's k is 5 (DescriptorMatcher.cpp:211)
+    assert np.array_equal(m[:, 0], gm["queryIdx"]) and np.array_equal(m[:, 1], gm["trainIdx"])
+    assert np.array_equal(m[:, 2], gm["imgIdx"]) and np.array_equal(dist, gm["distance"])
+    rng = capi.rng_new(1)
+    poses = ctx.verify(fr["kp_xy"], fr["cloud"], row_ptr, gm, xyz, spans, 8, 2500, 0.01, rng)
+    assert len(poses) == len(rt) == 1
+    assert np.array_equal(rt[0, :9].reshape(3, 3), poses[0]["R"]) and np.array_equal(rt[0, 9:], poses[0]["t"])
+    assert inl[0] == poses[0]["object"] == 2 and inl[1] == len(poses[0]["inliers"])
+    assert np.array_equal(inl[2:], poses[0]["inliers"])
+    ctx.close()
