@@ -34,14 +34,16 @@ LANEOPS_PER_DISTANCE = 16                           # 8 v_xor_b32 + 8 accumulati
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--objects", type=int, default=200, help="objects of 5000 descriptors (200 -> 1M rows)")
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--k", type=int, default=2)
     ap.add_argument("--radius", type=int, default=35)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
     ap.add_argument("--stages", default="match,verify", help="comma list of: match,verify")
+    ap.add_argument("--batch", type=int, default=8, help="frames per rank per step")
+    ap.add_argument("--verify-workers", type=int, default=8, help="verifier contexts (frames verified concurrently)")
     ap.add_argument("--iterations", type=int, default=2500, help="n_ransac_iterations (conf/detection.ork:38)")
     ap.add_argument("--min-inliers", type=int, default=8, help="min_inliers (conf/detection.ork:39)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
@@ -113,19 +115,33 @@ def main():
 
     nq, k = args.nq, args.k
     do_verify = "verify" in stages
+    B = args.batch                                   # frames per rank per step
+    from concurrent.futures import ThreadPoolExecutor
     from tod_amd import sharded
-    # frame f of step i belongs to rank (f % world); every rank keeps its own frames resident in HBM
+    # frame f belongs to rank (f % world); every rank keeps its own frames resident in HBM
     my_frames = [fr for f, fr in enumerate(frames) if f % world == rank] or [frames[rank % len(frames)]]
     d_q = [torch.from_numpy(fr["q_desc"]).cuda() for fr in my_frames]
     d_kp = [torch.from_numpy(fr["kp_xy"]).cuda() for fr in my_frames]
     d_cloud = [torch.from_numpy(fr["cloud"]).cuda() for fr in my_frames] if do_verify else []
     H, W = frames[0]["cloud"].shape[:2]
-    d_counts = torch.empty(nq, dtype=torch.int32, device="cuda")
-    d_matches = torch.empty((nq * k, 4), dtype=torch.int32, device="cuda")
-    d_xyz = torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")
-    d_keys = torch.empty((world * nq, k), dtype=torch.int64, device="cuda")
+    # matcher outputs, double buffered: the verifiers of step s read set (s % 2) while step s+1 fills the other
+    outs = [[dict(counts=torch.empty(nq, dtype=torch.int32, device="cuda"),
+                  matches=torch.empty((nq * k, 4), dtype=torch.int32, device="cuda"),
+                  xyz=torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(B)] for _ in range(2)]
+    d_keys = torch.empty((world * B * nq, k), dtype=torch.int64, device="cuda")
+    # verification is latency bound (host round trips + a single-wave clique search), so several frames are
+    # verified concurrently, each on its own context/stream; matching of the next step overlaps with it
+    n_workers = max(1, min(args.verify_workers, B)) if do_verify else 0
+    # high-priority streams: the verifier's short kernels must not queue behind the matcher's full-chip launches
+    vstreams = [torch.cuda.Stream(priority=-1) for _ in range(n_workers)]
+    vctx = [capi.Context(local_rank, vs.cuda_stream) for vs in vstreams]
+    pool = ThreadPoolExecutor(n_workers) if n_workers else None
+    import queue
+    free_ctx = queue.Queue()                          # one call in flight per context
+    for c in vctx:
+        free_ctx.put(c)
     n_pose_total = [0]
-    cur = [0]
+    pending = []
 
     def alloc(shape, dtype_name):
         return torch.empty(shape, dtype=getattr(torch, dtype_name), device="cuda")
@@ -138,38 +154,51 @@ def main():
             dist.all_gather(parts, inp.contiguous().view(-1).cpu())
             out.view(-1).copy_(torch.cat(parts).to(out.device))
 
-    def match_shard(q_all):
-        ctx.match_shard_device(q_all.data_ptr(), q_all.shape[0], k, d_keys.data_ptr())
-        return d_keys[:q_all.shape[0]]
+    def verify_task(f, o):
+        c = free_ctx.get()
+        try:
+            rng = capi.rng_new(1)                     # rand() restarts per frame (decision D4)
+            poses = c.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), H, W, o["counts"].data_ptr(),
+                                    o["matches"].data_ptr(), o["xyz"].data_ptr(), k, db_spans, args.min_inliers,
+                                    args.iterations, 0.01, rng)
+        finally:
+            free_ctx.put(c)
+        return len(poses)
 
-    def merge(keys_mine):
-        ctx.merge_shards_device(keys_mine.data_ptr(), keys_mine.shape[0], nq, k, args.radius, d_counts.data_ptr(),
-                                d_matches.data_ptr(), d_xyz.data_ptr())
-        return None
-
-    def verify(_):
-        if not do_verify:
-            return []
-        f = cur[0]
-        rng = capi.rng_new(1)                     # rand() restarts per frame (decision D4)
-        poses = ctx.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), H, W, d_counts.data_ptr(),
-                                  d_matches.data_ptr(), d_xyz.data_ptr(), k, db_spans, args.min_inliers,
-                                  args.iterations, 0.01, rng)
-        n_pose_total[0] += len(poses)
-        return poses
+    def drain():
+        for fut in pending:
+            n_pose_total[0] += fut.result()
+        del pending[:]
 
     def step(i):
-        f = i % len(d_q)
-        cur[0] = f
+        buf = outs[i % 2]
+        fidx = [(i * B + b) % len(d_q) for b in range(B)]
         if world == 1:
-            # single device: the tile lists go straight into the finalize kernel (no key exchange)
-            ctx.match_device(d_q[f].data_ptr(), nq, k, args.radius, d_counts.data_ptr(), d_matches.data_ptr(),
-                             d_xyz.data_ptr())
-            verify(None)
+            for b in range(B):                         # single device: no key exchange
+                ctx.match_device(d_q[fidx[b]].data_ptr(), nq, k, args.radius, buf[b]["counts"].data_ptr(),
+                                 buf[b]["matches"].data_ptr(), buf[b]["xyz"].data_ptr())
         else:
-            sharded.sharded_step(dist, world, rank, d_q[f], match_shard, merge, verify, alloc, all_gather)
+            # tod_amd/sharded.py with B frames per rank: gather descriptors, match all world*B frames against this
+            # rank's shard, all-gather the candidates, merge this rank's B frames
+            mine = torch.stack([d_q[f] for f in fidx])                              # [B, Q, 32]
+            q_all = alloc((world, B, nq, 32), "uint8")
+            all_gather(q_all, mine)
+            ctx.match_shard_device(q_all.data_ptr(), world * B * nq, k, d_keys.data_ptr())
+            keys_all = alloc((world, world, B, nq, k), "int64")                     # [shard][rank][b][Q][k]
+            all_gather(keys_all, d_keys)
+            for b in range(B):
+                km = keys_all[:, rank, b].contiguous()                              # [shard][Q][k]
+                ctx.merge_shards_device(km.data_ptr(), world, nq, k, args.radius, buf[b]["counts"].data_ptr(),
+                                        buf[b]["matches"].data_ptr(), buf[b]["xyz"].data_ptr())
+        if do_verify:
+            stream.synchronize()                       # the matcher outputs of this step are complete
+            drain()                                    # verifiers of the previous step (ran beside this step's matching)
+            for b in range(B):
+                pending.append(pool.submit(verify_task, fidx[b], buf[b]))
 
     def fence():
+        if do_verify:
+            drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -195,15 +224,17 @@ def main():
 
     n_launch = c1.n_match_kernel_launches - c0.n_match_kernel_launches
     k4_ms = (c1.sum_match_kernel_ms - c0.sum_match_kernel_ms) / max(n_launch, 1)
-    alg_bytes = info["shard_rows"] * 32 + world * nq * (32 + k * 8)      # N*32 + F*Q*32 + F*Q*k*8
+    frames_per_launch = B if world > 1 else 1
+    alg_bytes = info["shard_rows"] * 32 + world * frames_per_launch * nq * (32 + k * 8)   # N*32 + F*Q*(32 + k*8)
     achieved = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
-    distances = float(nq) * world * info["shard_rows"]          # every rank matches all `world` frames of a step
+    frames_per_launch = B if world > 1 else 1                      # sharded: one launch matches world*B frames
+    distances = float(nq) * world * frames_per_launch * info["shard_rows"]
     valu_frac = LANEOPS_PER_DISTANCE * distances / (k4_ms * 1e-3) / VALU_PEAK_LANEOPS if k4_ms > 0 else 0.0
 
     if rank == 0:
         out = {
             "metric": "frames/sec @ 640x480, 1M-descriptor DB; achieved HBM GB/s on BF-matcher",
-            "value": args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": args.steps * world * B / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 (xor + popcount), f32 in the verifier",
             "data": "synthetic",
@@ -211,8 +242,9 @@ def main():
                                    "Hamming BF k=%d, radius %d" % (nq, desc.shape[0], args.objects, k, args.radius),
                        "stages": stages, "db_rows_per_gpu": info["shard_rows"],
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
-                       "poses_per_frame_rank0": n_pose_total[0] / max(args.steps + args.warmup, 1),
-                       "frames_per_step": world,
+                       "poses_per_frame_rank0": n_pose_total[0] / max((args.steps + args.warmup) * B, 1),
+                       "frames_per_rank_per_step": B, "verify_workers": n_workers,
+                       "frames_per_step": world * B,
                        "parallelism": ("DB rows sharded x%d (object aligned), one frame per rank per step, RCCL all-gather of "
                                        "descriptors and of per-shard candidates" % world) if world > 1 else "1 GPU"},
             "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -228,6 +260,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
                                                args.iterations, args.min_inliers)
         print(json.dumps(out))
+    for c in vctx:
+        c.close()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -263,6 +263,12 @@ __device__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32
   const uint32_t nchunks = (r + 63u) / 64u;
   u64 uncol = 0ull;                                        // lane c holds positions [64c, 64c + 64)
   if (l < nchunks) uncol = (l * 64u + 64u <= r) ? ~0ull : ((1ull << (r - l * 64u)) - 1ull);
+  // the list does not change during the pass: keep this lane's member of every 64-position chunk in registers
+  constexpr uint32_t kRegChunks = 8;                       // lists of up to 512 vertices
+  const bool in_regs = nchunks <= kRegChunks;
+  uint32_t hreg[kRegChunks];
+#pragma unroll
+  for (uint32_t c = 0; c < kRegChunks; ++c) hreg[c] = (c * 64u + l) < r ? list[c * 64u + l] : 0xFFFFFFFFu;
   uint32_t k = 1, outpos = 0;
   while (__ballot(uncol != 0ull) != 0ull) {
     u64 Q = uncol;
@@ -276,14 +282,29 @@ __device__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32
       if (l == 0) { L.tmp[outpos] = (uint16_t)g; L.C[outpos] = k; }
       ++outpos;
       if (l == ll) { uncol &= ~(1ull << bit); Q &= ~(1ull << bit); }
-      const u64 roww = l < MW ? L.adjc[(size_t)g * MW + l] : 0ull;
-      for (uint32_t c = 0; c < nchunks; ++c) {
-        if (!((balQ >> c) & 1ull)) continue;               // wave-uniform
-        const uint32_t pos = c * 64u + l;
-        const uint32_t h = pos < r ? list[pos] : 0u;
-        const bool adj = row_test(roww, h) && pos < r;
-        const u64 bal = __ballot(adj);
-        if (l == c) Q &= ~bal;                             // neighbours cannot join this class
+      const u64* grow = L.adjc + (size_t)g * MW;
+      if (in_regs) {
+        // one LDS read per chunk straight at the word that holds the bit; all reads are issued before any is used
+        u64 wv[kRegChunks];
+#pragma unroll
+        for (uint32_t c = 0; c < kRegChunks; ++c)
+          wv[c] = (c < nchunks && hreg[c] != 0xFFFFFFFFu) ? grow[hreg[c] >> 6] : 0ull;
+#pragma unroll
+        for (uint32_t c = 0; c < kRegChunks; ++c) {
+          if (c < nchunks && ((balQ >> c) & 1ull)) {       // wave-uniform
+            const u64 bal = __ballot(((wv[c] >> (hreg[c] & 63u)) & 1ull) != 0ull);
+            if (l == c) Q &= ~bal;                         // neighbours cannot join this class
+          }
+        }
+      } else {
+        for (uint32_t c = 0; c < nchunks; ++c) {
+          if (!((balQ >> c) & 1ull)) continue;             // wave-uniform
+          const uint32_t pos = c * 64u + l;
+          bool adj = false;
+          if (pos < r) { const uint32_t h = list[pos]; adj = (grow[h >> 6] >> (h & 63u)) & 1ull; }
+          const u64 bal = __ballot(adj);
+          if (l == c) Q &= ~bal;
+        }
       }
     }
     ++k;
@@ -334,12 +355,13 @@ __device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, 
       if (qsz + c > qmax) {                                // :307
         ++qsz;                                             // Q.push_back(p)
         // Intersection(p, R, Rp), :209-217 -- order preserving compaction
-        const u64 roww = l < MW ? L.adjc[(size_t)p * MW + l] : 0ull;
+        const u64* prow = L.adjc + (size_t)p * MW;
         uint32_t rp = 0;
         for (uint32_t i0 = 0; i0 < sz; i0 += 64u) {
           const uint32_t i = i0 + l;
-          const uint32_t h = i < sz ? cur[i] : 0u;
-          const bool adj = row_test(roww, h) && i < sz;
+          uint32_t h = 0;
+          bool adj = false;
+          if (i < sz) { h = cur[i]; adj = (prow[h >> 6] >> (h & 63u)) & 1ull; }
           const u64 bal = __ballot(adj);
           if (adj) nxt[rp + (uint32_t)__popcll(bal & ((1ull << l) - 1ull))] = (uint16_t)h;
           rp += (uint32_t)__popcll(bal);
@@ -475,6 +497,7 @@ __global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
       } else {
         GateLds L = gate_carve(lds_raw, m);
         const uint32_t MW = (m + 63u) / 64u;
+        const long long t_start = A.dbg ? clock64() : 0;   // phase stamps (diagnostics builds of the call only)
         // F in ascending order (:219) -> graph index = rank (:241-243)
         uint32_t base = 0;
 #pragma unroll
@@ -492,30 +515,57 @@ __global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
         }
         __syncthreads();
         // induced sample sub-graph (:245-256) as an m x MW bit matrix in LDS, plus vertex degrees
+        const long long t_flist = A.dbg ? clock64() : 0;
         bool bad_index = false;
-        for (uint32_t g = 0; g < m && A.stop_level != 3u; ++g) {
-          const uint32_t vg = uni(L.flist[g]);
-          if (vg >= job.n) {                               // never dereference an unchecked index
-            if (l == 0) { atomicExch(&A.status[0], 4u); A.status[4] = g; A.status[5] = vg; A.status[6] = m; A.status[7] = it; }
-            bad_index = true;
-            break;
-          }
-          const u64* row = job.samp + (size_t)vg * W;
-          uint32_t d = 0;
-          for (uint32_t c = 0; c < MW; ++c) {
-            const uint32_t pos = c * 64u + l;
-            bool adj = false;
-            if (pos < m) {
-              const uint32_t h = L.flist[pos];
-              adj = (row[h >> 6] >> (h & 63u)) & 1ull;
+        for (uint32_t g = l; g < m; g += 64u) bad_index = bad_index || L.flist[g] >= job.n;
+        bad_index = __ballot(bad_index) != 0ull;           // never dereference an unchecked index
+        if (bad_index && l == 0) { atomicExch(&A.status[0], 4u); A.status[6] = m; A.status[7] = it; }
+        if (!bad_index && A.stop_level != 3u) {
+          if (W <= 64u) {
+            // lane l holds word l of a row; kRows rows are in flight so the global latency is paid once per group
+            constexpr uint32_t kRows = 8;
+            for (uint32_t g0 = 0; g0 < m; g0 += kRows) {
+              u64 rw[kRows];
+#pragma unroll
+              for (uint32_t j = 0; j < kRows; ++j) {
+                const uint32_t g = g0 + j;
+                rw[j] = (g < m && l < W) ? job.samp[(size_t)uni(L.flist[g < m ? g : 0u]) * W + l] : 0ull;
+              }
+#pragma unroll
+              for (uint32_t j = 0; j < kRows; ++j) {
+                const uint32_t g = g0 + j;
+                if (g < m) {                               // wave-uniform
+                  uint32_t d = 0;
+                  for (uint32_t c = 0; c < MW; ++c) {
+                    const uint32_t pos = c * 64u + l;
+                    const uint32_t h = pos < m ? L.flist[pos] : 0u;
+                    const bool adj = row_test(rw[j], h) && pos < m;
+                    const u64 bal = __ballot(adj);
+                    if (l == 0) L.adjc[(size_t)g * MW + c] = bal;
+                    d += (uint32_t)__popcll(bal);
+                  }
+                  if (l == 0) L.deg[g] = d;
+                }
+              }
             }
-            const u64 bal = __ballot(adj);
-            if (l == 0) L.adjc[(size_t)g * MW + c] = bal;
-            d += (uint32_t)__popcll(bal);
+          } else {
+            for (uint32_t g = 0; g < m; ++g) {
+              const u64* row = job.samp + (size_t)uni(L.flist[g]) * W;
+              uint32_t d = 0;
+              for (uint32_t c = 0; c < MW; ++c) {
+                const uint32_t pos = c * 64u + l;
+                bool adj = false;
+                if (pos < m) { const uint32_t h = L.flist[pos]; adj = (row[h >> 6] >> (h & 63u)) & 1ull; }
+                const u64 bal = __ballot(adj);
+                if (l == 0) L.adjc[(size_t)g * MW + c] = bal;
+                d += (uint32_t)__popcll(bal);
+              }
+              if (l == 0) L.deg[g] = d;
+            }
           }
-          if (l == 0) L.deg[g] = d;
         }
         __syncthreads();
+        const long long t_adjc = A.dbg ? clock64() : 0;
         if (A.dbg) {
           uint32_t* d = A.dbg + (size_t)it * A.dbg_stride;
           if (l == 0) { d[0] = cnt; d[1] = m; }
@@ -532,7 +582,13 @@ __global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
           result = 0;
         } else {
           int err = 0;
-          const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, nullptr);
+          uint32_t steps = 0;
+          const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, &steps);
+          if (A.dbg && l == 0 && A.dbg_stride >= 8u) {
+            uint32_t* d = A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 6u);
+            d[0] = (uint32_t)(t_flist - t_start); d[1] = (uint32_t)(t_adjc - t_flist);
+            d[2] = (uint32_t)(clock64() - t_adjc); d[3] = steps; d[4] = q;
+          }
           if (err) {
             if (l == 0) atomicExch(&A.status[0], 1u);
             result = INT_MIN;

@@ -26,3 +26,7 @@ for i, tr in enumerate(triples):
         print(i, tr, "gpu cnt", dbg[i, 0], "m", m, "counts", counts[i], "| oracle |P|", len(P), "|F|", len(F), "oracle consensus", len(inl), gc, gs, "OK" if ok else "MISMATCH")
         if not ok: print("   gpu F", gF[:20], "\n   orc F", F[:20]); bad += 1
 print("mismatches", bad)
+
+if lvl == 0:
+    for i in range(6):
+        print("it", i, "cnt", dbg[i,0], "m", dbg[i,1], "cycles flist/adjc/search", dbg[i,-6:-3], "steps", dbg[i,-3], "q", dbg[i,-2])
