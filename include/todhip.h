@@ -131,6 +131,12 @@ int todhip_orb(todhip_ctx*, const uint8_t* gray, uint32_t H, uint32_t W, uint32_
                uint32_t n_levels, float scale_factor, const int8_t* pattern, float* kp_xy, float* kp_aux,
                uint8_t* desc, uint32_t* n_out);
 
+/* Device-resident form: d_gray (H x W u8, row stride `stride`) is in HBM, keypoints and descriptors stay in HBM
+ * (d_kp_xy[cap*2] f32, d_kp_aux[cap*4] f32, d_desc[cap*32] u8); only the count comes back. *n_out: capacity in. */
+int todhip_orb_device(todhip_ctx*, const void* d_gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
+                      uint32_t n_levels, float scale_factor, const int8_t* pattern, void* d_kp_xy, void* d_kp_aux,
+                      void* d_desc, uint32_t* n_out);
+
 /* ---- diagnostics --------------------------------------------------------------------------------- */
 /* Per-RANSAC-round trace of the last todhip_verify call (what GuessGenerator.cpp:202 prints, plus the
  * rand() stream position): `iterations` = iterations_ at loop exit (ransac.h:95-135). */

@@ -54,8 +54,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(
-            os.path.join(_ORACLE_DIR, "tod_oracle.cpp")):
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("tod_oracle.cpp", "orb_oracle.c", "tod_oracle.h")]
+    if not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         build()
     L = C.CDLL(_LIB_PATH)
     L.orc_rng_next.restype = C.c_int32
@@ -69,6 +69,7 @@ def lib():
     L.orc_match.restype = C.c_int
     L.orc_verify.restype = C.c_int
     L.orc_cluster_kabsch.restype = C.c_int
+    L.orb_detect.restype = C.c_uint32
     _lib = L
     return L
 
@@ -236,3 +237,27 @@ def verify(kp_xy, cloud, row_ptr, matches, matches_xyz, spans_per_obj, min_inlie
         out.append(dict(object=int(p.object), R=np.array(p.R[:], np.float32).reshape(3, 3),
                         t=np.array(p.t[:], np.float32), inliers=inl[p.inlier_begin:p.inlier_end].copy()))
     return rc, out, [rounds[i] for i in range(n_rounds.value)]
+
+
+# ------------------------------------------------------------------------------------------ stage A
+def orb(gray, n_features=1000, n_levels=3, scale_factor=1.2, pattern=None):
+    """oracle/orb_oracle.c. Returns kp_xy f32[n,2], aux f32[n,4] (size, angle, response, octave), desc u8[n,32],
+    lvl_xy i32[n,2] (integer position inside the level)."""
+    g = np.ascontiguousarray(gray, np.uint8)
+    H, W = g.shape
+    cap = n_features
+    kp = np.zeros((cap, 2), np.float32)
+    aux = np.zeros((cap, 4), np.float32)
+    desc = np.zeros((cap, 32), np.uint8)
+    lvl = np.zeros((cap, 2), np.int32)
+    pat = None if pattern is None else np.ascontiguousarray(pattern, np.int8)
+    n = lib().orb_detect(_p(g, C.c_uint8), C.c_uint32(H), C.c_uint32(W), C.c_uint32(W), C.c_uint32(n_features),
+                         C.c_uint32(n_levels), C.c_float(scale_factor), None if pat is None else _p(pat, C.c_int8),
+                         C.c_uint32(cap), _p(kp, C.c_float), _p(aux, C.c_float), _p(desc, C.c_uint8), _p(lvl, C.c_int32))
+    return kp[:n].copy(), aux[:n].copy(), desc[:n].copy(), lvl[:n].copy()
+
+
+def orb_default_pattern():
+    pat = np.zeros((256, 4), np.int8)
+    lib().orb_default_pattern(_p(pat, C.c_int8))
+    return pat

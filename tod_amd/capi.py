@@ -56,6 +56,7 @@ EXPORTS = [
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device",
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
+    "todhip_orb_device",
 ]
 
 _lib = None
@@ -303,6 +304,18 @@ class Context:
         _check(rc, "todhip_orb")
         n = n_out.value
         return kp[:n].copy(), aux[:n].copy(), desc[:n].copy()
+
+
+def _orb_device(self, d_gray, H, W, stride, n_features, n_levels, scale_factor, d_kp_xy, d_kp_aux, d_desc, cap):
+    n_out = C.c_uint32(cap)
+    rc = lib().todhip_orb_device(self._h, C.c_void_p(d_gray), C.c_uint32(H), C.c_uint32(W), C.c_uint32(stride),
+                                 C.c_uint32(n_features), C.c_uint32(n_levels), C.c_float(scale_factor), None,
+                                 C.c_void_p(d_kp_xy), C.c_void_p(d_kp_aux), C.c_void_p(d_desc), C.byref(n_out))
+    _check(rc, "todhip_orb_device")
+    return n_out.value
+
+
+Context.orb_device = _orb_device
 
 
 def rng_new(seed=1):

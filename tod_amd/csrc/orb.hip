@@ -1,5 +1,407 @@
-// placeholder: replaced by the stage A implementation
+// Stage A on gfx950: ORB keypoints (FAST-9/16 + Harris ranking + intensity-centroid orientation) and 256-bit
+// rBRIEF descriptors. In the reference this stage is third-party code outside its tree
+// (ecto_opencv.features2d.FeatureDescriptor -> cv::ORB; python/object_recognition_tod/detector.py:10,27,
+// src/training/Trainer.cpp:144-150), so there is nothing to be bit-exact with except the published algorithm;
+// the free choices (fixed-point resize and blur, score definition, tie-breaks, rotation without angle
+// quantisation, output order) are the ones stated at the top of this repo's CPU restatement and are followed
+// here operation for operation (integer moments and gradients; float expressions without contraction).
+//
+// All images of a 640x480 pyramid are a few hundred KB: every kernel is latency/launch bound, not bandwidth
+// bound; the per-level work is a fixed sequence of small launches with no host round trip until the final count.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
 #include "ctx.h"
-void tod_orb_ws_free(todhip_ctx*) {}
-extern "C" int todhip_orb(todhip_ctx*, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, float,
-                          const int8_t*, float*, float*, uint8_t*, uint32_t*) { return TODHIP_EINVAL; }
+
+namespace {
+
+constexpr int kEdge = 31;
+constexpr int kHalfPatch = 15;
+constexpr int kFastThr = 20;
+constexpr int kMaxLevels = 16;
+
+struct Cand { int x, y, score; float harris; };
+
+// same generator as the CPU restatement: seeded xorshift, points inside radius 13
+void default_pattern(int8_t* pat) {
+  uint32_t s = 0x9E3779B9u;
+  for (int i = 0; i < 256 * 2; ++i) {
+    int x, y;
+    do {
+      s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+      x = (int)(s % 27u) - 13;
+      s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+      y = (int)(s % 27u) - 13;
+    } while (x * x + y * y > 13 * 13);
+    pat[2 * i] = (int8_t)x;
+    pat[2 * i + 1] = (int8_t)y;
+  }
+}
+
+void disc_umax(int* umax) {
+  const int hp = kHalfPatch;
+  const int vmax = (int)std::floor(hp * std::sqrt(2.0) / 2 + 1), vmin = (int)std::ceil(hp * std::sqrt(2.0) / 2);
+  for (int v = 0; v <= vmax; ++v) umax[v] = (int)std::rint(std::sqrt((double)hp * hp - (double)v * v));
+  for (int v = hp, v0 = 0; v >= vmin; --v) {
+    while (umax[v0] == umax[v0 + 1]) ++v0;
+    umax[v] = v0;
+    ++v0;
+  }
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restrict__ src, uint32_t stride, uint8_t* dst,
+                                                        uint32_t h, uint32_t w) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= h * w) return;
+  dst[i] = src[(size_t)(i / w) * stride + (i % w)];
+}
+
+// 11-bit fixed-point bilinear resize, sample positions (x + 0.5) * sx - 0.5, replicate border
+__global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, uint32_t sh, uint32_t sw, uint8_t* dst,
+                                                     uint32_t dh, uint32_t dw) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= dh * dw) return;
+  const uint32_t x = i % dw, y = i / dw;
+  const float sx = (float)sw / (float)dw, sy = (float)sh / (float)dh;
+  const float fy = ((float)y + 0.5f) * sy - 0.5f;
+  const int y0 = (int)floorf(fy);
+  const int wy = (int)rintf((fy - (float)y0) * 2048.f);
+  const int ya = clampi(y0, 0, (int)sh - 1), yb = clampi(y0 + 1, 0, (int)sh - 1);
+  const float fx = ((float)x + 0.5f) * sx - 0.5f;
+  const int x0 = (int)floorf(fx);
+  const int wx = (int)rintf((fx - (float)x0) * 2048.f);
+  const int xa = clampi(x0, 0, (int)sw - 1), xb = clampi(x0 + 1, 0, (int)sw - 1);
+  const int top = src[ya * sw + xa] * (2048 - wx) + src[ya * sw + xb] * wx;
+  const int bot = src[yb * sw + xa] * (2048 - wx) + src[yb * sw + xb] * wx;
+  dst[i] = (uint8_t)((top * (2048 - wy) + bot * wy + (1 << 21)) >> 22);
+}
+
+// FAST-9/16 score: max over the 16 arcs of 9 contiguous circle pixels, both polarities, of the minimum difference.
+// Sliding minima over the (cyclic) circle: windows of 2, 4, 8, then 9.
+__device__ __forceinline__ int arc9_max(const int (&d)[16]) {
+  int m2[16], m4[16], best = -(1 << 30);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m2[i] = min(d[i], d[(i + 1) & 15]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m4[i] = min(m2[i], m2[(i + 2) & 15]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m8 = min(m4[i], m4[(i + 4) & 15]);
+    best = max(best, min(m8, d[(i + 8) & 15]));
+  }
+  return best;
+}
+
+__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, uint32_t h, uint32_t w, int* score) {
+  const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  int s = 0;
+  if (x >= (uint32_t)(kEdge - 1) && x < w - kEdge + 1 && y >= (uint32_t)(kEdge - 1) && y < h - kEdge + 1) {
+    const uint8_t* c = img + (size_t)y * w + x;
+    const int p = c[0];
+    const int W = (int)w;
+    int d[16], nd[16];
+    d[0] = c[3 * W] - p;       d[1] = c[3 * W + 1] - p;   d[2] = c[2 * W + 2] - p;   d[3] = c[W + 3] - p;
+    d[4] = c[3] - p;           d[5] = c[-W + 3] - p;      d[6] = c[-2 * W + 2] - p;  d[7] = c[-3 * W + 1] - p;
+    d[8] = c[-3 * W] - p;      d[9] = c[-3 * W - 1] - p;  d[10] = c[-2 * W - 2] - p; d[11] = c[-W - 3] - p;
+    d[12] = c[-3] - p;         d[13] = c[W - 3] - p;      d[14] = c[2 * W - 2] - p;  d[15] = c[3 * W - 1] - p;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) nd[i] = -d[i];
+    const int best = max(0, max(arc9_max(d), arc9_max(nd)));
+    s = best > kFastThr ? best : 0;
+  }
+  score[(size_t)y * w + x] = s;
+}
+
+// 3x3 strict non-maximum suppression + compaction (order is fixed later by the ranking)
+__global__ __launch_bounds__(256) void nms_kernel(const int* __restrict__ score, uint32_t h, uint32_t w, Cand* cand,
+                                                  uint32_t cap, uint32_t* counter) {
+  const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+  if (x < (uint32_t)kEdge || x >= w - kEdge || y < (uint32_t)kEdge || y >= h - kEdge) return;
+  const int s = score[(size_t)y * w + x];
+  if (s == 0) return;
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx)
+      if ((dx || dy) && score[(size_t)(y + dy) * w + (x + dx)] >= s) return;
+  const uint32_t i = atomicAdd(counter, 1u);
+  if (i < cap) { Cand c; c.x = (int)x; c.y = (int)y; c.score = s; c.harris = 0.f; cand[i] = c; }
+}
+
+__device__ __forceinline__ unsigned long long key_of(const Cand& c, bool by_harris) {
+  uint32_t hi;
+  if (by_harris) {
+    const uint32_t b = __float_as_uint(c.harris);
+    const uint32_t asc = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // order-preserving map of float to uint
+    hi = ~asc;                                                          // descending
+  } else {
+    hi = 0xFFFFFFFFu - (uint32_t)c.score;
+  }
+  return ((unsigned long long)hi << 32) | ((unsigned long long)(uint32_t)c.y << 16) | (uint32_t)c.x;
+}
+
+// keep the `keep` best of in[0..n): rank by counting (keys are unique: they contain the position)
+__global__ __launch_bounds__(256) void rank_select_kernel(const Cand* __restrict__ in, const uint32_t* __restrict__ n_ptr,
+                                                          uint32_t n_cap, uint32_t keep, int by_harris, Cand* out,
+                                                          uint32_t* n_out) {
+  const uint32_t n = min(*n_ptr, n_cap);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i == 0) *n_out = min(n, keep);
+  if (i >= n) return;
+  const Cand me = in[i];
+  const unsigned long long mine = key_of(me, by_harris != 0);
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < n; ++j) rank += key_of(in[j], by_harris != 0) < mine;
+  if (rank < keep) out[rank] = me;
+}
+
+__global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__ img, uint32_t w, Cand* cand,
+                                                     const uint32_t* __restrict__ n_ptr) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= *n_ptr) return;
+  const int x = cand[i].x, y = cand[i].y, W = (int)w;
+  int a = 0, b = 0, c = 0;
+  for (int dy = -3; dy <= 3; ++dy)
+    for (int dx = -3; dx <= 3; ++dx) {
+      const uint8_t* p = img + (size_t)(y + dy) * w + (x + dx);
+      const int ix = ((int)p[1] - (int)p[-1]) * 2 + ((int)p[-W + 1] - (int)p[-W - 1]) + ((int)p[W + 1] - (int)p[W - 1]);
+      const int iy = ((int)p[W] - (int)p[-W]) * 2 + ((int)p[W - 1] - (int)p[-W - 1]) + ((int)p[W + 1] - (int)p[-W + 1]);
+      a += ix * ix; b += iy * iy; c += ix * iy;
+    }
+  const float scale = 1.f / (4.f * 7 * 255.f);
+  const float s4 = (scale * scale) * (scale * scale);
+  const float fa = (float)a, fb = (float)b, fc = (float)c;
+  cand[i].harris = (fa * fb - fc * fc - 0.04f * ((fa + fb) * (fa + fb))) * s4;
+}
+
+__constant__ int c_gauss7[7] = {18, 33, 49, 56, 49, 33, 18};
+
+__global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= h * w) return;
+  const int x = (int)(i % w), y = (int)(i / w);
+  int s = 0;
+#pragma unroll
+  for (int k = -3; k <= 3; ++k) s += c_gauss7[k + 3] * src[(size_t)y * w + clampi(x + k, 0, (int)w - 1)];
+  dst[i] = (uint8_t)((s + 128) >> 8);
+}
+__global__ __launch_bounds__(256) void blur_v_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= h * w) return;
+  const int x = (int)(i % w), y = (int)(i / w);
+  int s = 0;
+#pragma unroll
+  for (int k = -3; k <= 3; ++k) s += c_gauss7[k + 3] * src[(size_t)clampi(y + k, 0, (int)h - 1) * w + x];
+  dst[i] = (uint8_t)((s + 128) >> 8);
+}
+
+struct DescribeArgs {
+  const uint8_t* img; const uint8_t* blur; uint32_t w;
+  const Cand* sel; const uint32_t* n_sel;       // this level's selection
+  const uint32_t* level_counts; uint32_t level; // output base = sum of the earlier levels' counts
+  float scale; uint32_t cap;
+  const int8_t* pattern; int umax[kHalfPatch + 2];
+  float* kp_xy; float* kp_aux; uint8_t* desc;
+};
+
+// one wave per keypoint: integer moments over the radius-15 disc (lane = row), then 4 tests per lane
+__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs A) {
+  const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+  if (i >= *A.n_sel) return;
+  uint32_t base = 0;
+  for (uint32_t j = 0; j < A.level; ++j) base += A.level_counts[j];
+  const uint32_t o = base + i;
+  if (o >= A.cap) return;
+  const Cand c = A.sel[i];
+  const int x = c.x, y = c.y, W = (int)A.w;
+  int m10 = 0, m01 = 0;
+  if (l < 31u) {
+    const int v = (int)l - kHalfPatch;
+    const int d = v == 0 ? kHalfPatch : A.umax[v < 0 ? -v : v];
+    int rs = 0;
+    for (int u = -d; u <= d; ++u) {
+      const int px = A.img[(size_t)(y + v) * W + x + u];
+      m10 += u * px;
+      rs += px;
+    }
+    m01 = v * rs;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
+  const float fm10 = (float)m10, fm01 = (float)m01;
+  const float nrm = sqrtf(fm10 * fm10 + fm01 * fm01);
+  const float ca = nrm > 0.f ? fm10 / nrm : 1.f, sa = nrm > 0.f ? fm01 / nrm : 0.f;
+  uint32_t nib = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int8_t* pp = A.pattern + 4 * (4 * (int)l + b);
+    const int x0 = (int)rintf((float)pp[0] * ca - (float)pp[1] * sa), y0 = (int)rintf((float)pp[0] * sa + (float)pp[1] * ca);
+    const int x1 = (int)rintf((float)pp[2] * ca - (float)pp[3] * sa), y1 = (int)rintf((float)pp[2] * sa + (float)pp[3] * ca);
+    const int t0 = A.blur[(size_t)(y + y0) * W + (x + x0)], t1 = A.blur[(size_t)(y + y1) * W + (x + x1)];
+    nib |= (uint32_t)(t0 < t1) << b;
+  }
+  const uint32_t hi = __shfl_down(nib, 1);
+  if ((l & 1u) == 0u) A.desc[(size_t)o * 32 + (l >> 1)] = (uint8_t)(nib | (hi << 4));
+  if (l == 0) {
+    float ang = atan2f(fm01, fm10) * 57.29577951308232f;
+    if (ang < 0.f) ang += 360.f;
+    A.kp_xy[2 * o] = (float)x * A.scale; A.kp_xy[2 * o + 1] = (float)y * A.scale;
+    A.kp_aux[4 * o] = 31.f * A.scale; A.kp_aux[4 * o + 1] = ang; A.kp_aux[4 * o + 2] = c.harris; A.kp_aux[4 * o + 3] = (float)A.level;
+  }
+}
+
+struct OrbWs {
+  DevBuf img[2], blur, tmp, score, cand, sel1, sel2, small, pattern, in_img, kp_xy, kp_aux, desc;
+  HostBuf h_out;
+  bool pattern_is_default = false;
+};
+
+OrbWs* ows_of(todhip_ctx* ctx) {
+  if (!ctx->orb_ws) ctx->orb_ws = new OrbWs();
+  return reinterpret_cast<OrbWs*>(ctx->orb_ws);
+}
+
+void features_per_level(uint32_t n_features, uint32_t n_levels, float scale_factor, uint32_t* out) {
+  const float factor = 1.0f / scale_factor;
+  float n_desired = (float)n_features * (1.f - factor) / (1.f - powf(factor, (float)n_levels));
+  int sum = 0;
+  for (uint32_t l = 0; l + 1 < n_levels; ++l) {
+    out[l] = (uint32_t)rintf(n_desired);
+    sum += (int)out[l];
+    n_desired *= factor;
+  }
+  const int rest = (int)n_features - sum;
+  out[n_levels - 1] = rest > 0 ? (uint32_t)rest : 0u;
+}
+
+// d_gray: H x W u8 on the device (row stride `stride`). Results stay on the device; *n_out is read back.
+int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
+               uint32_t n_levels, float scale_factor, const int8_t* pattern, float* d_kp_xy, float* d_kp_aux,
+               uint8_t* d_desc, uint32_t cap, uint32_t* n_out) {
+  if (n_levels == 0 || n_levels > (uint32_t)kMaxLevels || scale_factor <= 1.f || H < 8 || W < 8 || n_features == 0)
+    return TODHIP_EINVAL;
+  OrbWs* ws = ows_of(ctx);
+  hipStream_t st = ctx->stream;
+  const size_t px = (size_t)H * W;
+  const uint32_t cand_cap = (uint32_t)(px / 4 + 64);
+  TOD_HIP(ws->img[0].reserve(px)); TOD_HIP(ws->img[1].reserve(px));
+  TOD_HIP(ws->blur.reserve(px)); TOD_HIP(ws->tmp.reserve(px)); TOD_HIP(ws->score.reserve(px * sizeof(int)));
+  TOD_HIP(ws->cand.reserve((size_t)cand_cap * sizeof(Cand)));
+  TOD_HIP(ws->sel1.reserve((size_t)2 * n_features * sizeof(Cand) + 64));
+  TOD_HIP(ws->sel2.reserve((size_t)n_features * sizeof(Cand) + 64));
+  TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
+  TOD_HIP(ws->pattern.reserve(1024));
+  TOD_HIP(ws->h_out.reserve(64));
+  int8_t hpat[1024];
+  if (pattern) { std::memcpy(hpat, pattern, 1024); ws->pattern_is_default = false; }
+  if (pattern || !ws->pattern_is_default) {
+    if (!pattern) { default_pattern(hpat); ws->pattern_is_default = true; }
+    TOD_HIP(hipMemcpyAsync(ws->pattern.p, hpat, 1024, hipMemcpyHostToDevice, st));
+    TOD_HIP(hipStreamSynchronize(st));                   // hpat lives on this stack frame
+  }
+  uint32_t per_level[kMaxLevels];
+  features_per_level(n_features, n_levels, scale_factor, per_level);
+  uint32_t* d_small = ws->small.as<uint32_t>();           // [0] cand count, [1] sel1 count, [8 + l] level counts
+  TOD_HIP(hipMemsetAsync(d_small, 0, 64 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, st, d_gray, stride,
+                     ws->img[0].as<uint8_t>(), H, W);
+  DescribeArgs D;
+  disc_umax(D.umax);
+  uint32_t ph = H, pw = W;
+  int cur = 0;
+  for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
+    float scale = 1.f;
+    for (uint32_t i = 0; i < lvl; ++i) scale = scale * scale_factor;
+    const uint32_t w = (uint32_t)rintf((float)W / scale), h = (uint32_t)rintf((float)H / scale);
+    if (lvl > 0) {
+      hipLaunchKernelGGL(resize_kernel, dim3((h * w + 255u) / 256u), dim3(256), 0, st, ws->img[cur].as<uint8_t>(), ph, pw,
+                         ws->img[cur ^ 1].as<uint8_t>(), h, w);
+      cur ^= 1; ph = h; pw = w;
+    }
+    if (h <= 2u * kEdge || w <= 2u * kEdge) continue;     // level count stays 0
+    const uint8_t* img = ws->img[cur].as<uint8_t>();
+    const dim3 grid2((w + 63u) / 64u, (h + 3u) / 4u);
+    TOD_HIP(hipMemsetAsync(d_small, 0, 2 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(fast_score_kernel, grid2, dim3(256), 0, st, img, h, w, ws->score.as<int>());
+    hipLaunchKernelGGL(nms_kernel, grid2, dim3(256), 0, st, ws->score.as<int>(), h, w, ws->cand.as<Cand>(), cand_cap, d_small);
+    const uint32_t want = per_level[lvl];
+    if (want == 0) continue;
+    hipLaunchKernelGGL(rank_select_kernel, dim3((cand_cap + 255u) / 256u), dim3(256), 0, st, ws->cand.as<Cand>(), d_small,
+                       cand_cap, 2u * want, 0, ws->sel1.as<Cand>(), d_small + 1);
+    hipLaunchKernelGGL(harris_kernel, dim3((2u * want + 255u) / 256u), dim3(256), 0, st, img, w, ws->sel1.as<Cand>(), d_small + 1);
+    hipLaunchKernelGGL(rank_select_kernel, dim3((2u * want + 255u) / 256u), dim3(256), 0, st, ws->sel1.as<Cand>(), d_small + 1,
+                       2u * want, want, 1, ws->sel2.as<Cand>(), d_small + 8 + lvl);
+    hipLaunchKernelGGL(blur_h_kernel, dim3((h * w + 255u) / 256u), dim3(256), 0, st, img, h, w, ws->tmp.as<uint8_t>());
+    hipLaunchKernelGGL(blur_v_kernel, dim3((h * w + 255u) / 256u), dim3(256), 0, st, ws->tmp.as<uint8_t>(), h, w, ws->blur.as<uint8_t>());
+    D.img = img; D.blur = ws->blur.as<uint8_t>(); D.w = w; D.sel = ws->sel2.as<Cand>(); D.n_sel = d_small + 8 + lvl;
+    D.level_counts = d_small + 8; D.level = lvl; D.scale = scale; D.cap = cap; D.pattern = ws->pattern.as<int8_t>();
+    D.kp_xy = d_kp_xy; D.kp_aux = d_kp_aux; D.desc = d_desc;
+    hipLaunchKernelGGL(describe_kernel, dim3((want + 3u) / 4u), dim3(256), 0, st, D);
+    TOD_HIP(hipGetLastError());
+  }
+  uint32_t* h_counts = ws->h_out.as<uint32_t>();
+  TOD_HIP(hipMemcpyAsync(h_counts, d_small + 8, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
+  uint32_t total = 0;
+  for (uint32_t l = 0; l < n_levels; ++l) total += h_counts[l];
+  *n_out = std::min(total, cap);
+  return TODHIP_OK;
+}
+
+}  // namespace
+
+void tod_orb_ws_free(todhip_ctx* ctx) {
+  if (!ctx->orb_ws) return;
+  OrbWs* ws = reinterpret_cast<OrbWs*>(ctx->orb_ws);
+  DevBuf* bufs[] = {&ws->img[0], &ws->img[1], &ws->blur, &ws->tmp, &ws->score, &ws->cand, &ws->sel1, &ws->sel2,
+                    &ws->small, &ws->pattern, &ws->in_img, &ws->kp_xy, &ws->kp_aux, &ws->desc};
+  for (DevBuf* b : bufs) b->release();
+  ws->h_out.release();
+  delete ws;
+  ctx->orb_ws = nullptr;
+}
+
+extern "C" {
+
+int todhip_orb_device(todhip_ctx* ctx, const void* d_gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
+                      uint32_t n_levels, float scale_factor, const int8_t* pattern, void* d_kp_xy, void* d_kp_aux,
+                      void* d_desc, uint32_t* n_out) {
+  if (!ctx || !d_gray || !d_kp_xy || !d_kp_aux || !d_desc || !n_out || stride < W) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  const uint32_t cap = *n_out;
+  *n_out = 0;
+  return orb_device(ctx, reinterpret_cast<const uint8_t*>(d_gray), H, W, stride, n_features, n_levels, scale_factor, pattern,
+                    reinterpret_cast<float*>(d_kp_xy), reinterpret_cast<float*>(d_kp_aux), reinterpret_cast<uint8_t*>(d_desc),
+                    cap, n_out);
+}
+
+int todhip_orb(todhip_ctx* ctx, const uint8_t* gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
+               uint32_t n_levels, float scale_factor, const int8_t* pattern, float* kp_xy, float* kp_aux, uint8_t* desc,
+               uint32_t* n_out) {
+  if (!ctx || !gray || !kp_xy || !kp_aux || !desc || !n_out || stride < W) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  OrbWs* ws = ows_of(ctx);
+  const uint32_t cap = *n_out;
+  *n_out = 0;
+  if (cap == 0) return TODHIP_ECAPACITY;
+  TOD_HIP(ws->in_img.reserve((size_t)H * stride));
+  TOD_HIP(ws->kp_xy.reserve((size_t)cap * 8)); TOD_HIP(ws->kp_aux.reserve((size_t)cap * 16)); TOD_HIP(ws->desc.reserve((size_t)cap * 32));
+  TOD_HIP(hipMemcpyAsync(ws->in_img.p, gray, (size_t)H * stride, hipMemcpyHostToDevice, ctx->stream));
+  uint32_t n = 0;
+  const int rc = orb_device(ctx, ws->in_img.as<uint8_t>(), H, W, stride, n_features, n_levels, scale_factor, pattern,
+                            ws->kp_xy.as<float>(), ws->kp_aux.as<float>(), ws->desc.as<uint8_t>(), cap, &n);
+  if (rc != TODHIP_OK) return rc;
+  if (n) {
+    TOD_HIP(hipMemcpyAsync(kp_xy, ws->kp_xy.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TOD_HIP(hipMemcpyAsync(kp_aux, ws->kp_aux.p, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    TOD_HIP(hipMemcpyAsync(desc, ws->desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    TOD_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  *n_out = n;
+  return TODHIP_OK;
+}
+
+}  // extern "C"
