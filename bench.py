@@ -34,16 +34,16 @@ LANEOPS_PER_DISTANCE = 16                           # 8 v_xor_b32 + 8 accumulati
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--objects", type=int, default=200, help="objects of 5000 descriptors (200 -> 1M rows)")
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--k", type=int, default=2)
     ap.add_argument("--radius", type=int, default=35)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
-    ap.add_argument("--stages", default="match,verify", help="comma list of: match,verify")
-    ap.add_argument("--batch", type=int, default=8, help="frames per rank per step")
-    ap.add_argument("--verify-workers", type=int, default=8, help="verifier contexts (frames verified concurrently)")
+    ap.add_argument("--stages", default="orb,match,verify", help="comma list of: orb,match,verify")
+    ap.add_argument("--batch", type=int, default=16, help="frames per rank per step")
+    ap.add_argument("--verify-workers", type=int, default=4, help="ORB + verifier contexts (frames in flight beside the matcher)")
     ap.add_argument("--iterations", type=int, default=2500, help="n_ransac_iterations (conf/detection.ork:38)")
     ap.add_argument("--min-inliers", type=int, default=8, help="min_inliers (conf/detection.ork:39)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
@@ -115,6 +115,7 @@ def main():
 
     nq, k = args.nq, args.k
     do_verify = "verify" in stages
+    do_orb = "orb" in stages
     B = args.batch                                   # frames per rank per step
     from concurrent.futures import ThreadPoolExecutor
     from tod_amd import sharded
@@ -123,6 +124,11 @@ def main():
     d_q = [torch.from_numpy(fr["q_desc"]).cuda() for fr in my_frames]
     d_kp = [torch.from_numpy(fr["kp_xy"]).cuda() for fr in my_frames]
     d_cloud = [torch.from_numpy(fr["cloud"]).cuda() for fr in my_frames] if do_verify else []
+    # stage A runs on the SURVEY 8(d) synthetic grey image of the frame. Its descriptors are not the matcher's input
+    # (random-image ORB descriptors cannot match a synthetic DB; the frame's planted descriptors do that), but its
+    # work is part of every frame: it runs on the frame's worker context, overlapped with the next batch's matching.
+    my_ids = [f for f in range(len(frames)) if f % world == rank] or [rank % len(frames)]
+    d_img = [torch.from_numpy(synth.make_image(f)).cuda() for f in my_ids] if do_orb else []
     H, W = frames[0]["cloud"].shape[:2]
     # matcher outputs, double buffered: the verifiers of step s read set (s % 2) while step s+1 fills the other
     outs = [[dict(counts=torch.empty(nq, dtype=torch.int32, device="cuda"),
@@ -131,7 +137,7 @@ def main():
     d_keys = torch.empty((world * B * nq, k), dtype=torch.int64, device="cuda")
     # verification is latency bound (host round trips + a single-wave clique search), so several frames are
     # verified concurrently, each on its own context/stream; matching of the next step overlaps with it
-    n_workers = max(1, min(args.verify_workers, B)) if do_verify else 0
+    n_workers = max(1, min(args.verify_workers, B)) if (do_verify or do_orb) else 0
     # high-priority streams: the verifier's short kernels must not queue behind the matcher's full-chip launches
     vstreams = [torch.cuda.Stream(priority=-1) for _ in range(n_workers)]
     vctx = [capi.Context(local_rank, vs.cuda_stream) for vs in vstreams]
@@ -139,7 +145,10 @@ def main():
     import queue
     free_ctx = queue.Queue()                          # one call in flight per context
     for c in vctx:
+        c.orb_out = (torch.empty((args.nq, 2), device="cuda"), torch.empty((args.nq, 4), device="cuda"),
+                     torch.empty((args.nq, 32), dtype=torch.uint8, device="cuda"))
         free_ctx.put(c)
+    n_kp_total = [0]
     n_pose_total = [0]
     pending = []
 
@@ -157,17 +166,25 @@ def main():
     def verify_task(f, o):
         c = free_ctx.get()
         try:
-            rng = capi.rng_new(1)                     # rand() restarts per frame (decision D4)
-            poses = c.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), H, W, o["counts"].data_ptr(),
-                                    o["matches"].data_ptr(), o["xyz"].data_ptr(), k, db_spans, args.min_inliers,
-                                    args.iterations, 0.01, rng)
+            n_kp = 0
+            if do_orb:
+                n_kp = c.orb_device(d_img[f].data_ptr(), H, W, W, args.nq, 3, 1.2, c.orb_out[0].data_ptr(),
+                                              c.orb_out[1].data_ptr(), c.orb_out[2].data_ptr(), args.nq)
+            poses = []
+            if do_verify:
+                rng = capi.rng_new(1)                 # rand() restarts per frame (decision D4)
+                poses = c.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), H, W, o["counts"].data_ptr(),
+                                        o["matches"].data_ptr(), o["xyz"].data_ptr(), k, db_spans, args.min_inliers,
+                                        args.iterations, 0.01, rng)
         finally:
             free_ctx.put(c)
-        return len(poses)
+        return len(poses), n_kp
 
     def drain():
         for fut in pending:
-            n_pose_total[0] += fut.result()
+            n_p, n_k = fut.result()
+            n_pose_total[0] += n_p
+            n_kp_total[0] += n_k
         del pending[:]
 
     def step(i):
@@ -190,14 +207,14 @@ def main():
                 km = keys_all[:, rank, b].contiguous()                              # [shard][Q][k]
                 ctx.merge_shards_device(km.data_ptr(), world, nq, k, args.radius, buf[b]["counts"].data_ptr(),
                                         buf[b]["matches"].data_ptr(), buf[b]["xyz"].data_ptr())
-        if do_verify:
+        if n_workers:
             stream.synchronize()                       # the matcher outputs of this step are complete
             drain()                                    # verifiers of the previous step (ran beside this step's matching)
             for b in range(B):
                 pending.append(pool.submit(verify_task, fidx[b], buf[b]))
 
     def fence():
-        if do_verify:
+        if n_workers:
             drain()
         torch.cuda.synchronize()
         if world > 1:
@@ -244,6 +261,8 @@ def main():
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
                        "poses_per_frame_rank0": n_pose_total[0] / max((args.steps + args.warmup) * B, 1),
                        "frames_per_rank_per_step": B, "verify_workers": n_workers,
+                       "orb": "ORB-%d, 3 levels, scale 1.2 on the 8(d) synthetic image; %.0f keypoints/frame" %
+                              (args.nq, n_kp_total[0] / max((args.steps + args.warmup) * B, 1)) if do_orb else None,
                        "frames_per_step": world * B,
                        "parallelism": ("DB rows sharded x%d (object aligned), one frame per rank per step, RCCL all-gather of "
                                        "descriptors and of per-shard candidates" % world) if world > 1 else "1 GPU"},

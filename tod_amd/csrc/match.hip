@@ -13,6 +13,8 @@
 //                          min3/min/compare so the top-k test costs 0.75 VALU op per pair.
 // K4m merge_tiles_kernel   per query: merge the per-tile lists into k global keys.
 // K4f finalize_kernel      per query: merge shard lists, radius cut, object lookup, 3D gather.
+#include <cstdlib>
+
 #include "ctx.h"
 
 namespace {
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void merge_tiles_kernel(const uint32_t* __r
                                                              uint32_t nq_pad, uint32_t n_tiles,
                                                              uint32_t rows_per_tile, uint64_t first_global_row,
                                                              uint32_t n_groups, uint64_t* __restrict__ keys) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t grp = blockIdx.y;
   if (qi >= nq) return;
@@ -205,6 +208,7 @@ __global__ __launch_bounds__(kBlock) void merge_tiles_kernel(const uint32_t* __r
 // K4s: per query, the k smallest of n_lists ascending lists (layout [list][nq][k]) -> keys[nq][k].
 __global__ __launch_bounds__(kBlock) void select_keys_kernel(const uint64_t* __restrict__ lists, uint32_t n_lists,
                                                              uint32_t nq, uint32_t k, uint64_t* __restrict__ keys) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
   if (qi >= nq) return;
   uint64_t last = 0;
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __rest
                                                           uint32_t* __restrict__ counts,
                                                           todhip_dmatch* __restrict__ matches,
                                                           float* __restrict__ xyz) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
   if (qi >= nq) return;
   uint32_t kept = 0;
@@ -290,7 +295,8 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint64_t* d_l
   const uint32_t n_qw = (nq + 63u) / 64u;
   const uint32_t nq_pad = n_qw * 64u;
   // a fully resident grid (no second round of blocks): n_cu x kWavesPerCU waves, equal work per wave
-  const uint32_t target_waves = (uint32_t)ctx->n_cu * kWavesPerCU;
+  static const int env_wpc = getenv("TODHIP_K4_WAVES_PER_CU") ? atoi(getenv("TODHIP_K4_WAVES_PER_CU")) : 0;   // tuning knob
+  const uint32_t target_waves = (uint32_t)ctx->n_cu * (uint32_t)(env_wpc > 0 ? env_wpc : kWavesPerCU);
   uint32_t n_tiles = target_waves / n_qw;
   if (n_tiles < 1) n_tiles = 1;
   uint32_t rows_per_tile = (n_rows + n_tiles - 1) / n_tiles;

@@ -55,6 +55,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restrict__ src, uint32_t stride, uint8_t* dst,
                                                         uint32_t h, uint32_t w) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
   dst[i] = src[(size_t)(i / w) * stride + (i % w)];
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restric
 // 11-bit fixed-point bilinear resize, sample positions (x + 0.5) * sx - 0.5, replicate border
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, uint32_t sh, uint32_t sw, uint8_t* dst,
                                                      uint32_t dh, uint32_t dw) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= dh * dw) return;
   const uint32_t x = i % dw, y = i / dw;
@@ -97,6 +99,7 @@ __device__ __forceinline__ int arc9_max(const int (&d)[16]) {
 }
 
 __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, uint32_t h, uint32_t w, int* score) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
   int s = 0;
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restri
 
 // 3x3 strict non-maximum suppression + compaction (order is fixed later by the ranking)
 __global__ __launch_bounds__(256) void nms_kernel(const int* __restrict__ score, uint32_t h, uint32_t w, Cand* cand,
-                                                  uint32_t cap, uint32_t* counter) {
+                                                  uint32_t cap, uint32_t* counter, uint32_t* hist) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
   if (x < (uint32_t)kEdge || x >= w - kEdge || y < (uint32_t)kEdge || y >= h - kEdge) return;
   const int s = score[(size_t)y * w + x];
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const int* __restrict__ score,
     for (int dx = -1; dx <= 1; ++dx)
       if ((dx || dy) && score[(size_t)(y + dy) * w + (x + dx)] >= s) return;
   const uint32_t i = atomicAdd(counter, 1u);
-  if (i < cap) { Cand c; c.x = (int)x; c.y = (int)y; c.score = s; c.harris = 0.f; cand[i] = c; }
+  if (i < cap) { Cand c; c.x = (int)x; c.y = (int)y; c.score = s; c.harris = 0.f; cand[i] = c; atomicAdd(&hist[s & 255], 1u); }
 }
 
 __device__ __forceinline__ unsigned long long key_of(const Cand& c, bool by_harris) {
@@ -143,23 +147,73 @@ __device__ __forceinline__ unsigned long long key_of(const Cand& c, bool by_harr
   return ((unsigned long long)hi << 32) | ((unsigned long long)(uint32_t)c.y << 16) | (uint32_t)c.x;
 }
 
-// keep the `keep` best of in[0..n): rank by counting (keys are unique: they contain the position)
-__global__ __launch_bounds__(256) void rank_select_kernel(const Cand* __restrict__ in, const uint32_t* __restrict__ n_ptr,
-                                                          uint32_t n_cap, uint32_t keep, int by_harris, Cand* out,
-                                                          uint32_t* n_out) {
-  const uint32_t n = min(*n_ptr, n_cap);
+// control words of one level (device): what the selection kernels hand to each other without a host round trip
+enum { W_NCAND = 0, W_NSEL1 = 1, W_THR = 2, W_NEED_EQ = 3, W_NEQ = 4, W_NGT = 5, W_HIST = 32 };
+
+// "keep the 2n best by FAST score" only defines a SET (the Harris ranking re-orders it), so a 256-bin histogram
+// gives the score threshold T: everything above T is kept, and of the candidates at exactly T the first
+// keep - count(> T) in (y, x) order.
+__global__ void fast_threshold_kernel(uint32_t* ctl, uint32_t cand_cap, uint32_t keep) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  if (threadIdx.x != 0) return;
+  const uint32_t n = min(ctl[W_NCAND], cand_cap);
+  uint32_t above = 0, thr = 0, need = 0;
+  if (n > keep) {
+    for (int sc = 255; sc >= 0; --sc) {
+      const uint32_t c = ctl[W_HIST + sc];
+      if (above + c >= keep) { thr = (uint32_t)sc; need = keep - above; break; }
+      above += c;
+    }
+  }
+  ctl[W_NCAND] = n;
+  ctl[W_THR] = thr; ctl[W_NEED_EQ] = (n > keep) ? need : 0u;
+  ctl[W_NSEL1] = min(n, keep);
+  ctl[W_NGT] = 0u; ctl[W_NEQ] = 0u;
+}
+
+__global__ __launch_bounds__(256) void split_kernel(const Cand* __restrict__ cand, uint32_t* ctl, uint32_t keep, Cand* sel1,
+                                                    Cand* eq) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const uint32_t n = ctl[W_NCAND];
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i == 0) *n_out = min(n, keep);
   if (i >= n) return;
-  const Cand me = in[i];
-  const unsigned long long mine = key_of(me, by_harris != 0);
+  const Cand c = cand[i];
+  if (n <= keep || (uint32_t)c.score > ctl[W_THR]) sel1[atomicAdd(&ctl[W_NGT], 1u)] = c;
+  else if ((uint32_t)c.score == ctl[W_THR]) eq[atomicAdd(&ctl[W_NEQ], 1u)] = c;
+}
+
+// keep the `keep` best of in[0..n) at out[out_off + rank]: rank by counting against LDS-staged key tiles
+// (keys are unique: they contain the position).
+constexpr uint32_t kRankTile = 2048;
+__global__ __launch_bounds__(256) void rank_tiled_kernel(const Cand* __restrict__ in, const uint32_t* __restrict__ n_ptr,
+                                                         const uint32_t* __restrict__ keep_ptr, uint32_t keep_val,
+                                                         int by_harris, Cand* out, const uint32_t* __restrict__ off_ptr,
+                                                         uint32_t* n_out) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  __shared__ unsigned long long keys[kRankTile];
+  const uint32_t n = *n_ptr;
+  const uint32_t keep = keep_ptr ? *keep_ptr : keep_val;
+  const uint32_t off = off_ptr ? *off_ptr : 0u;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (n_out && i == 0) *n_out = min(n, keep);
+  if (blockIdx.x * 256u >= n) return;                       // block-uniform
+  Cand me;
+  unsigned long long mine = ~0ull;
+  if (i < n) { me = in[i]; mine = key_of(me, by_harris != 0); }
   uint32_t rank = 0;
-  for (uint32_t j = 0; j < n; ++j) rank += key_of(in[j], by_harris != 0) < mine;
-  if (rank < keep) out[rank] = me;
+  for (uint32_t t0 = 0; t0 < n; t0 += kRankTile) {
+    const uint32_t tn = min(kRankTile, n - t0);
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < tn; j += 256u) keys[j] = key_of(in[t0 + j], by_harris != 0);
+    __syncthreads();
+    for (uint32_t j = 0; j < tn; ++j) rank += keys[j] < mine;
+  }
+  if (i < n && rank < keep) out[off + rank] = me;
 }
 
 __global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__ img, uint32_t w, Cand* cand,
                                                      const uint32_t* __restrict__ n_ptr) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= *n_ptr) return;
   const int x = cand[i].x, y = cand[i].y, W = (int)w;
@@ -180,6 +234,7 @@ __global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__
 __constant__ int c_gauss7[7] = {18, 33, 49, 56, 49, 33, 18};
 
 __global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
   const int x = (int)(i % w), y = (int)(i / w);
@@ -189,6 +244,7 @@ __global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__
   dst[i] = (uint8_t)((s + 128) >> 8);
 }
 __global__ __launch_bounds__(256) void blur_v_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
   const int x = (int)(i % w), y = (int)(i / w);
@@ -209,6 +265,7 @@ struct DescribeArgs {
 
 // one wave per keypoint: integer moments over the radius-15 disc (lane = row), then 4 tests per lane
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs A) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
   if (i >= *A.n_sel) return;
   uint32_t base = 0;
@@ -254,7 +311,7 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs A) {
 }
 
 struct OrbWs {
-  DevBuf img[2], blur, tmp, score, cand, sel1, sel2, small, pattern, in_img, kp_xy, kp_aux, desc;
+  DevBuf img[2], blur, tmp, score, cand, eq, sel1, sel2, small, pattern, in_img, kp_xy, kp_aux, desc;
   HostBuf h_out;
   bool pattern_is_default = false;
 };
@@ -290,9 +347,10 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
   TOD_HIP(ws->img[0].reserve(px)); TOD_HIP(ws->img[1].reserve(px));
   TOD_HIP(ws->blur.reserve(px)); TOD_HIP(ws->tmp.reserve(px)); TOD_HIP(ws->score.reserve(px * sizeof(int)));
   TOD_HIP(ws->cand.reserve((size_t)cand_cap * sizeof(Cand)));
+  TOD_HIP(ws->eq.reserve((size_t)cand_cap * sizeof(Cand)));
   TOD_HIP(ws->sel1.reserve((size_t)2 * n_features * sizeof(Cand) + 64));
   TOD_HIP(ws->sel2.reserve((size_t)n_features * sizeof(Cand) + 64));
-  TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
+  TOD_HIP(ws->small.reserve(1024 * sizeof(uint32_t)));
   TOD_HIP(ws->pattern.reserve(1024));
   TOD_HIP(ws->h_out.reserve(64));
   int8_t hpat[1024];
@@ -304,8 +362,8 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
   }
   uint32_t per_level[kMaxLevels];
   features_per_level(n_features, n_levels, scale_factor, per_level);
-  uint32_t* d_small = ws->small.as<uint32_t>();           // [0] cand count, [1] sel1 count, [8 + l] level counts
-  TOD_HIP(hipMemsetAsync(d_small, 0, 64 * sizeof(uint32_t), st));
+  uint32_t* d_small = ws->small.as<uint32_t>();           // level control words (W_*), [8 + l] level counts
+  TOD_HIP(hipMemsetAsync(d_small, 0, 512 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, st, d_gray, stride,
                      ws->img[0].as<uint8_t>(), H, W);
   DescribeArgs D;
@@ -324,16 +382,22 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
     if (h <= 2u * kEdge || w <= 2u * kEdge) continue;     // level count stays 0
     const uint8_t* img = ws->img[cur].as<uint8_t>();
     const dim3 grid2((w + 63u) / 64u, (h + 3u) / 4u);
-    TOD_HIP(hipMemsetAsync(d_small, 0, 2 * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(fast_score_kernel, grid2, dim3(256), 0, st, img, h, w, ws->score.as<int>());
-    hipLaunchKernelGGL(nms_kernel, grid2, dim3(256), 0, st, ws->score.as<int>(), h, w, ws->cand.as<Cand>(), cand_cap, d_small);
     const uint32_t want = per_level[lvl];
     if (want == 0) continue;
-    hipLaunchKernelGGL(rank_select_kernel, dim3((cand_cap + 255u) / 256u), dim3(256), 0, st, ws->cand.as<Cand>(), d_small,
-                       cand_cap, 2u * want, 0, ws->sel1.as<Cand>(), d_small + 1);
-    hipLaunchKernelGGL(harris_kernel, dim3((2u * want + 255u) / 256u), dim3(256), 0, st, img, w, ws->sel1.as<Cand>(), d_small + 1);
-    hipLaunchKernelGGL(rank_select_kernel, dim3((2u * want + 255u) / 256u), dim3(256), 0, st, ws->sel1.as<Cand>(), d_small + 1,
-                       2u * want, want, 1, ws->sel2.as<Cand>(), d_small + 8 + lvl);
+    TOD_HIP(hipMemsetAsync(d_small, 0, 8 * sizeof(uint32_t), st));
+    TOD_HIP(hipMemsetAsync(d_small + W_HIST, 0, 256 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(fast_score_kernel, grid2, dim3(256), 0, st, img, h, w, ws->score.as<int>());
+    hipLaunchKernelGGL(nms_kernel, grid2, dim3(256), 0, st, ws->score.as<int>(), h, w, ws->cand.as<Cand>(), cand_cap, d_small,
+                       d_small + W_HIST);
+    hipLaunchKernelGGL(fast_threshold_kernel, dim3(1), dim3(64), 0, st, d_small, cand_cap, 2u * want);
+    hipLaunchKernelGGL(split_kernel, dim3((cand_cap + 255u) / 256u), dim3(256), 0, st, ws->cand.as<Cand>(), d_small, 2u * want,
+                       ws->sel1.as<Cand>(), ws->eq.as<Cand>());
+    // ties at the threshold: the first need_eq of them in (y, x) order, placed behind the count(> T) sure ones
+    hipLaunchKernelGGL(rank_tiled_kernel, dim3((cand_cap + 255u) / 256u), dim3(256), 0, st, ws->eq.as<Cand>(), d_small + W_NEQ,
+                       d_small + W_NEED_EQ, 0u, 0, ws->sel1.as<Cand>(), d_small + W_NGT, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(harris_kernel, dim3((2u * want + 255u) / 256u), dim3(256), 0, st, img, w, ws->sel1.as<Cand>(), d_small + W_NSEL1);
+    hipLaunchKernelGGL(rank_tiled_kernel, dim3((2u * want + 255u) / 256u), dim3(256), 0, st, ws->sel1.as<Cand>(), d_small + W_NSEL1,
+                       (const uint32_t*)nullptr, want, 1, ws->sel2.as<Cand>(), (const uint32_t*)nullptr, d_small + 8 + lvl);
     hipLaunchKernelGGL(blur_h_kernel, dim3((h * w + 255u) / 256u), dim3(256), 0, st, img, h, w, ws->tmp.as<uint8_t>());
     hipLaunchKernelGGL(blur_v_kernel, dim3((h * w + 255u) / 256u), dim3(256), 0, st, ws->tmp.as<uint8_t>(), h, w, ws->blur.as<uint8_t>());
     D.img = img; D.blur = ws->blur.as<uint8_t>(); D.w = w; D.sel = ws->sel2.as<Cand>(); D.n_sel = d_small + 8 + lvl;
@@ -356,7 +420,7 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
 void tod_orb_ws_free(todhip_ctx* ctx) {
   if (!ctx->orb_ws) return;
   OrbWs* ws = reinterpret_cast<OrbWs*>(ctx->orb_ws);
-  DevBuf* bufs[] = {&ws->img[0], &ws->img[1], &ws->blur, &ws->tmp, &ws->score, &ws->cand, &ws->sel1, &ws->sel2,
+  DevBuf* bufs[] = {&ws->img[0], &ws->img[1], &ws->blur, &ws->tmp, &ws->score, &ws->cand, &ws->eq, &ws->sel1, &ws->sel2,
                     &ws->small, &ws->pattern, &ws->in_img, &ws->kp_xy, &ws->kp_aux, &ws->desc};
   for (DevBuf* b : bufs) b->release();
   ws->h_out.release();

@@ -35,6 +35,7 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ K6
 __global__ __launch_bounds__(256) void adjacency_kernel(ObjJob job, float span, float err) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t i = blockIdx.x;
   const uint32_t word = blockIdx.y * 4u + (threadIdx.x >> 6);
   if (word >= job.W) return;
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void adjacency_kernel(ObjJob job, float span, 
 }
 
 __global__ __launch_bounds__(256) void finite_kernel(ObjJob job) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   bool f = false;
   if (v < job.n) {
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void finite_kernel(ObjJob job) {
 
 // per round: sample degree inside the valid set, the ">= 7" filter mask (:211-213), |valid|
 __global__ __launch_bounds__(256) void round_prep_kernel(ObjJob job, uint32_t* nvalid) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   bool isv = false;
   uint32_t d = 0;
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(256) void round_prep_kernel(ObjJob job, uint32_t* n
 // ------------------------------------------------------------------------------------------------ K7a
 __global__ __launch_bounds__(256) void draw_table_kernel(ObjJob job, const uint32_t* __restrict__ rnd,
                                                          uint32_t window_len, uint32_t S, DrawEntry* table) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (s >= S) return;
   const uint32_t W = job.W;
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(256) void draw_table_kernel(ObjJob job, const uint3
 // ------------------------------------------------------------------------------------------------ K7b
 __global__ void chain_kernel(const DrawEntry* __restrict__ table, uint32_t S, uint32_t n_req, uint32_t attempts0,
                              uint32_t out_base, uint32_t* iter_samples, uint32_t* iter_pos_after, ChainOut* out) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   uint32_t p = 0, done = 0, attempts = attempts0, flag = 0;
   while (done < n_req) {
@@ -451,6 +456,7 @@ struct EvalArgs {
 // launched with 64 threads; the bound is deliberately larger so that hipcc keeps __syncthreads() as a real,
 // convergent s_barrier (with a 64-thread bound it drops the barrier and may split the lanes of the wave)
 __global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const uint32_t l = lane_id();
   const ObjJob& job = A.job;
@@ -704,6 +710,7 @@ struct GrowthOut {
 __global__ __launch_bounds__(256) void growth_kernel(ObjJob job, uint32_t s0, uint32_t s1, uint32_t s2, float err,
                                                      u64* inl, u64* rest, u64* extra, uint32_t* kp_list,
                                                      u64* kp_bits, uint32_t kp_words, GrowthOut* out) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   __shared__ float sR[9], sT[3];
   __shared__ double sAcc[16];
   __shared__ float sC[6];
@@ -883,6 +890,7 @@ __global__ __launch_bounds__(256) void growth_kernel(ObjJob job, uint32_t s0, ui
 // InvalidateQueryIndices (adjacency_ransac.cpp:93-123): drop every valid match whose keypoint is an inlier
 // keypoint, then InvalidateIndices (:63-89): repeatedly drop valid matches whose sample degree is < 3.
 __global__ __launch_bounds__(1024) void invalidate_kernel(ObjJob job, const u64* kp_bits, u64* scratch) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   __shared__ uint32_t sAny;
   const uint32_t tid = threadIdx.x, W = job.W, n = job.n;
   if (tid == 0) sAny = 0u;
@@ -928,6 +936,7 @@ __global__ __launch_bounds__(256) void cluster_lookup_kernel(const float* __rest
                                                              const float* __restrict__ cloud, uint32_t H, uint32_t Wimg,
                                                              const uint32_t* __restrict__ counts, uint32_t* kept,
                                                              float* qpt, uint32_t* err) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t q = blockIdx.x * 256u + threadIdx.x;
   if (q >= nq) return;
   const int row = (int)kp_xy[2 * q + 1], col = (int)kp_xy[2 * q];        // float -> int truncation (:185)
@@ -943,6 +952,7 @@ __global__ __launch_bounds__(256) void cluster_lookup_kernel(const float* __rest
 
 // exclusive scan of kept[0..nq) into offs[0..nq], one block
 __global__ __launch_bounds__(1024) void cluster_scan_kernel(const uint32_t* __restrict__ kept, uint32_t nq, uint32_t* offs) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   __shared__ uint32_t part[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = (nq + 1023u) / 1024u;
@@ -969,6 +979,7 @@ __global__ __launch_bounds__(256) void cluster_scatter_kernel(const float* __res
                                                               const float* __restrict__ qpt, uint32_t n_objs,
                                                               uint32_t* obj_of, uint32_t* hist, float* ftrain,
                                                               float* fquery, uint32_t* fqidx, float* fkp, uint32_t* err) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t q = t / k, j = t % k;
   if (q >= nq || j >= kept[q]) return;
@@ -991,6 +1002,7 @@ __global__ __launch_bounds__(256) void cluster_group_kernel(uint32_t n_all, cons
                                                             const uint32_t* __restrict__ fqidx,
                                                             const float* __restrict__ fkp, float* train, float* query,
                                                             uint32_t* qidx, float* kpxy) {
+  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t f = blockIdx.x * 256u + threadIdx.x;
   if (f >= n_all) return;
   const uint32_t o = obj_of[f];
@@ -1007,7 +1019,7 @@ struct VerifyWs {
   DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, rnd, table, iter_samples, iter_pos, counts, gate_m,
       small, deferred, stacks, kp_list, kp_bits, clique_adj, c_kept, c_offs, c_qpt, c_obj, c_hist, c_goff, f_train,
       f_query, f_qidx, f_kp;
-  HostBuf h_small, h_counts, h_pos, h_kp;
+  HostBuf h_small, h_counts, h_pos, h_kp, h_trip, h_goff;
   std::vector<uint32_t> rnd_host;
 };
 
@@ -1074,6 +1086,7 @@ int ransac_round(todhip_ctx* ctx, VerifyWs* ws, const ObjJob& job, uint32_t nq, 
   TOD_HIP(ws->deferred.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
   TOD_HIP(ws->h_counts.reserve((size_t)(total_iters + 1) * sizeof(int32_t)));
   TOD_HIP(ws->h_pos.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
+  TOD_HIP(ws->h_trip.reserve((size_t)(total_iters + 1) * 3 * sizeof(uint32_t)));
   TOD_HIP(ws->stacks.reserve((size_t)kMaxEvalWaves * kStackCap * sizeof(uint16_t)));
 
   // ---- computeModel (ransac.h:80-143): speculative draws in batches, evaluation, host replay
@@ -1107,16 +1120,19 @@ int ransac_round(todhip_ctx* ctx, VerifyWs* ws, const ObjJob& job, uint32_t nq, 
       hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, st, ws->table.as<DrawEntry>(), S, want - got,
                          attempts_carry, it_begin + got, ws->iter_samples.as<uint32_t>(), ws->iter_pos.as<uint32_t>(),
                          reinterpret_cast<ChainOut*>(d_small + 1));
+      const uint32_t req = want - got;
       TOD_HIP(hipMemcpyAsync(h_small + 1, d_small + 1, sizeof(ChainOut), hipMemcpyDeviceToHost, st));
+      TOD_HIP(hipMemcpyAsync(ws->h_pos.as<uint32_t>() + it_begin + got, ws->iter_pos.as<uint32_t>() + it_begin + got,
+                             (size_t)req * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      TOD_HIP(hipMemcpyAsync(ws->h_trip.as<uint32_t>() + 3 * (size_t)(it_begin + got),
+                             ws->iter_samples.as<uint32_t>() + 3 * (size_t)(it_begin + got),
+                             (size_t)req * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       TOD_HIP(hipStreamSynchronize(st));
       const ChainOut co = *reinterpret_cast<ChainOut*>(h_small + 1);
       TOD_DBG("  draw window: S=%u len=%u -> done=%u pos_end=%u attempts=%u flag=%u", S, window_len, co.n_done, co.pos_end,
               co.attempts, co.flag);
-      // iter_pos entries of this walk are relative to the window: make them absolute on the host later
-      if (co.n_done) {
-        TOD_HIP(hipMemcpyAsync(ws->h_pos.as<uint32_t>() + it_begin + got, ws->iter_pos.as<uint32_t>() + it_begin + got,
-                               (size_t)co.n_done * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        TOD_HIP(hipStreamSynchronize(st));
+      // positions of this walk are relative to the window start
+      {
         uint32_t* hp = ws->h_pos.as<uint32_t>();
         for (uint32_t i = 0; i < co.n_done; ++i) hp[it_begin + got + i] += (uint32_t)consumed;
       }
@@ -1144,6 +1160,8 @@ int ransac_round(todhip_ctx* ctx, VerifyWs* ws, const ObjJob& job, uint32_t nq, 
       TOD_DBG("  eval: iterations [%u,%u) on %u waves", it_begin, it_drawn, waves);
       hipLaunchKernelGGL(eval_kernel, dim3(waves), dim3(64), kEvalLdsSmall, st, A);
       TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      TOD_HIP(hipMemcpyAsync(ws->h_counts.as<int32_t>() + it_begin, ws->counts.as<int32_t>() + it_begin,
+                             (size_t)got * sizeof(int32_t), hipMemcpyDeviceToHost, st));
       TOD_HIP(hipStreamSynchronize(st));
       if (h_small[12] != 0) {
         if (getenv("TODHIP_DEBUG"))
@@ -1161,10 +1179,10 @@ int ransac_round(todhip_ctx* ctx, VerifyWs* ws, const ObjJob& job, uint32_t nq, 
         TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         TOD_HIP(hipStreamSynchronize(st));
         if (h_small[12] != 0) return TODHIP_ESCRATCH;
+        TOD_HIP(hipMemcpyAsync(ws->h_counts.as<int32_t>() + it_begin, ws->counts.as<int32_t>() + it_begin,
+                               (size_t)got * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        TOD_HIP(hipStreamSynchronize(st));
       }
-      TOD_HIP(hipMemcpyAsync(ws->h_counts.as<int32_t>() + it_begin, ws->counts.as<int32_t>() + it_begin,
-                             (size_t)got * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      TOD_HIP(hipStreamSynchronize(st));
       ctx->counters.last_hypotheses += got;
     }
     // ---- replay ransac.h:95-135 over the iterations known so far
@@ -1205,20 +1223,15 @@ int ransac_round(todhip_ctx* ctx, VerifyWs* ws, const ObjJob& job, uint32_t nq, 
   TOD_HIP(ws->h_kp.reserve((size_t)std::max(nq, 1u) * sizeof(uint32_t) + sizeof(GrowthOut)));
   u64* d_bits = ws->bits.as<u64>();                       // finite | valid | deg7 | inl | rest | extra | scratch
   const uint32_t W = job.W;
-  uint32_t trip[3];
-  TOD_HIP(hipMemcpyAsync(trip, ws->iter_samples.as<uint32_t>() + 3 * best_it, sizeof(trip), hipMemcpyDeviceToHost, st));
-  TOD_HIP(hipStreamSynchronize(st));
+  const uint32_t* trip = ws->h_trip.as<uint32_t>() + 3 * (size_t)best_it;
   GrowthOut* d_go = reinterpret_cast<GrowthOut*>(d_small + 32);
   hipLaunchKernelGGL(growth_kernel, dim3(1), dim3(256), 0, st, job, trip[0], trip[1], trip[2], err, d_bits + 3 * W,
                      d_bits + 4 * W, d_bits + 5 * W, ws->kp_list.as<uint32_t>(), ws->kp_bits.as<u64>(), kp_words, d_go);
   GrowthOut* h_go = reinterpret_cast<GrowthOut*>(ws->h_kp.as<unsigned char>());
-  TOD_HIP(hipMemcpyAsync(h_go, d_go, sizeof(GrowthOut), hipMemcpyDeviceToHost, st));
-  TOD_HIP(hipStreamSynchronize(st));
   uint32_t* h_list = reinterpret_cast<uint32_t*>(ws->h_kp.as<unsigned char>() + sizeof(GrowthOut));
-  if (h_go->n_kp_inliers) {
-    TOD_HIP(hipMemcpyAsync(h_list, ws->kp_list.p, (size_t)h_go->n_kp_inliers * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    TOD_HIP(hipStreamSynchronize(st));
-  }
+  TOD_HIP(hipMemcpyAsync(h_go, d_go, sizeof(GrowthOut), hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipMemcpyAsync(h_list, ws->kp_list.p, (size_t)std::min(nq, job.n) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
   TOD_DBG("  growth: model=%u matches=%u kps=%u passes=%u", h_go->n_model_inliers, h_go->n_match_inliers,
           h_go->n_kp_inliers, h_go->passes);
   res->have_pose = true;
@@ -1238,7 +1251,8 @@ void tod_verify_ws_free(todhip_ctx* ctx) {
                     &ws->deferred, &ws->stacks, &ws->kp_list, &ws->kp_bits, &ws->clique_adj, &ws->c_kept, &ws->c_offs,
                     &ws->c_qpt, &ws->c_obj, &ws->c_hist, &ws->c_goff, &ws->f_train, &ws->f_query, &ws->f_qidx, &ws->f_kp};
   for (DevBuf* b : bufs) b->release();
-  ws->h_small.release(); ws->h_counts.release(); ws->h_pos.release(); ws->h_kp.release();
+  ws->h_small.release(); ws->h_counts.release(); ws->h_pos.release(); ws->h_kp.release(); ws->h_trip.release();
+  ws->h_goff.release();
   delete ws;
   ctx->verify_ws = nullptr;
 }
@@ -1441,20 +1455,20 @@ int todhip_verify_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, cons
   const uint32_t n_all = h[201];
   if (n_all == 0) return TODHIP_OK;
   std::vector<ObjSpan> spans_list;
-  std::vector<uint32_t> goff(n_objs, 0u);
+  TOD_HIP(ws->h_goff.reserve((size_t)n_objs * 4));
+  uint32_t* goff = ws->h_goff.as<uint32_t>();           // pinned and owned by the workspace: no sync needed
   uint32_t total = 0;
   for (uint32_t o = 0; o < n_objs; ++o) {
     goff[o] = total;
     if (h[256 + o]) spans_list.push_back({o, total, h[256 + o]});
     total += h[256 + o];
   }
-  TOD_HIP(hipMemcpyAsync(ws->c_goff.p, goff.data(), (size_t)n_objs * 4, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->c_goff.p, goff, (size_t)n_objs * 4, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(cluster_group_kernel, dim3((n_all + 255u) / 256u), dim3(256), 0, st, n_all, ws->c_obj.as<uint32_t>(),
                      ws->c_goff.as<uint32_t>(), ws->f_train.as<float>(), ws->f_query.as<float>(),
                      ws->f_qidx.as<uint32_t>(), ws->f_kp.as<float>(), ws->train.as<float>(), ws->query.as<float>(),
                      ws->qidx.as<uint32_t>(), ws->kpxy.as<float>());
   TOD_HIP(hipGetLastError());
-  TOD_HIP(hipStreamSynchronize(st));   // goff lives on this stack frame
   return verify_grouped(ctx, ws, spans_list, nq, spans, prm, rng, poses, pose_cap, n_poses, inlier_kp, kp_cap, n_inlier_kp);
 }
 
