@@ -80,7 +80,7 @@ struct todhip_ctx {
   std::vector<float> h_spans;
 
   // ---- matcher workspaces
-  DevBuf m_q, m_part, m_keys, m_counts, m_matches, m_xyz;
+  DevBuf m_q, m_part, m_keys, m_counts, m_matches, m_xyz, m_bound;
   HostBuf h_stage;
   // optional HIP-event bracketing of the dominant matcher kernel: a ring of event pairs that is
   // drained lazily, so timing never adds a host sync inside the timed region

@@ -25,7 +25,8 @@ constexpr int kLocalBits = 22;     // tile-local row index bits in a partial key
 constexpr uint32_t kLocalMask = (1u << kLocalBits) - 1u;
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kWavesPerCU = 16;    // grid is sized to be fully resident: 4 blocks of 4 waves per CU
+constexpr int kWavesPerCU = 24;    // grid is sized to be fully resident: 6 blocks of 4 waves per CU (<= 112 SGPRs)
+constexpr uint32_t kSharePeriod = 128;   // groups between two exchanges of the per-query distance bound
 constexpr int kMergeGroups = 16;   // stage-1 merge fan-in
 
 template <int K>
@@ -78,15 +79,18 @@ __device__ __forceinline__ uint32_t hamming256_mem(const uint32_t (&q)[kWords], 
   return d;
 }
 
+// `limit` = min(own k-th best distance, 1 + the smallest k-th best distance any tile has published for this
+// query): a row at or above it cannot be among the k nearest of the whole DB (ties with a foreign bound are kept
+// because a smaller row index could still win them), so skipping it keeps the merged result exact.
 template <int K>
 __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], const RowGroup& g, uint32_t r,
-                                              uint32_t (&best)[K], uint32_t& worst_d) {
+                                              uint32_t (&best)[K], uint32_t& worst_d, uint32_t& limit, uint32_t foreign) {
   uint32_t d0 = hamming256<0>(qd, g.lo);
   uint32_t d1 = hamming256<1>(qd, g.lo);
   uint32_t d2 = hamming256<0>(qd, g.hi);
   uint32_t d3 = hamming256<1>(qd, g.hi);
   uint32_t dmin = min(min(d0, d1), min(d2, d3));
-  if (__builtin_amdgcn_ballot_w64(dmin < worst_d) != 0ull) {
+  if (__builtin_amdgcn_ballot_w64(dmin < limit) != 0ull) {
     // rows are visited in ascending order, so a later row never displaces an equal distance:
     // "key < best[K-1]" is exactly "d < worst_d" and insertion order inside the group is free.
     topk_insert<K>(best, (d0 << kLocalBits) | r);
@@ -94,6 +98,7 @@ __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], cons
     topk_insert<K>(best, (d2 << kLocalBits) | (r + 2));
     topk_insert<K>(best, (d3 << kLocalBits) | (r + 3));
     worst_d = best[K - 1] >> kLocalBits;
+    limit = min(worst_d, foreign);
   }
 }
 
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
                                                              uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
                                                              uint32_t n_tiles, uint32_t n_qw,
                                                              uint32_t blocks_per_xcd,
-                                                             uint32_t* __restrict__ part) {
+                                                             uint32_t* __restrict__ part, uint32_t* bound) {
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t vblock = xcd * blocks_per_xcd + slot;                 // XCD-contiguous virtual block id
   const uint32_t item = __builtin_amdgcn_readfirstlane(vblock * kWavesPerBlock + (threadIdx.x >> 6));
@@ -136,24 +141,34 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
   // ping-pong SGPR groups: the load of group g+1 is in flight while group g is consumed
   const uint32_t n_groups = n_local / kGroupRows;
   uint32_t r = 0;
+  uint32_t foreign = 0xFFFFFFFFu, limit = worst_d;         // foreign = 1 + smallest published k-th best distance
+  uint32_t* my_bound = bound + (qi < nq ? qi : nq - 1);
   if (n_groups > 0) {
     constexpr uint32_t kStride = kGroupRows * kWords;
     RowGroup ga, gb;
     issue_rows(ga, base);
     wait_rows(ga);
-    uint32_t g = 0;
+    uint32_t g = 0, next_share = 16;                        // first exchange early: the tile's own list is full by then
     for (; g + 2 <= n_groups; g += 2) {
       issue_rows(gb, base + (size_t)(g + 1) * kStride);
-      consume_group<K>(qd, ga, r, best, worst_d);
+      consume_group<K>(qd, ga, r, best, worst_d, limit, foreign);
       wait_rows(gb);
       const uint32_t gn = (g + 2 < n_groups) ? g + 2 : g;      // the last pair re-reads an in-bounds group
       issue_rows(ga, base + (size_t)gn * kStride);
-      consume_group<K>(qd, gb, r + kGroupRows, best, worst_d);
+      consume_group<K>(qd, gb, r + kGroupRows, best, worst_d, limit, foreign);
       wait_rows(ga);
       r += 2 * kGroupRows;
+      if (g >= next_share) {                                // wave-uniform
+        next_share += kSharePeriod;
+        // publish this tile's bound (only once its list is full), pick up the smallest bound published so far
+        uint32_t seen = __hip_atomic_load(my_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (worst_d < seen) { atomicMin(my_bound, worst_d); seen = worst_d; }   // publish only a real improvement
+        foreign = seen == 0xFFFFFFFFu ? seen : seen + 1u;
+        limit = min(worst_d, foreign);
+      }
     }
     if (g < n_groups) {                                         // odd group count: ga holds group g
-      consume_group<K>(qd, ga, r, best, worst_d);
+      consume_group<K>(qd, ga, r, best, worst_d, limit, foreign);
       r += kGroupRows;
     }
   }
@@ -309,11 +324,13 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint64_t* d_l
   const uint32_t blocks_per_xcd = (blocks + 7u) / 8u;
   const uint32_t groups = n_tiles < (uint32_t)kMergeGroups ? n_tiles : (uint32_t)kMergeGroups;
   TOD_HIP(ctx->m_part.reserve((size_t)n_tiles * K * nq_pad * sizeof(uint32_t)));
+  TOD_HIP(ctx->m_bound.reserve((size_t)nq_pad * sizeof(uint32_t)));
+  TOD_HIP(hipMemsetAsync(ctx->m_bound.p, 0xFF, (size_t)nq_pad * sizeof(uint32_t), ctx->stream));
   int slot = -1;
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(hamming_topk_tiles<K>, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw,
-                     blocks_per_xcd, ctx->m_part.as<uint32_t>());
+                     blocks_per_xcd, ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>());
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
                      ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
