@@ -59,6 +59,8 @@ def cpu_baseline(desc, pts, off, frames, k, radius, budget_s, stages, iterations
     t_total, n = 0.0, 0
     for fr in frames:
         t0 = time.perf_counter()
+        if "orb" in stages:
+            O.orb(fr["image"], frames[0]["q_desc"].shape[0], 3, 1.2)
         rc, row_ptr, m, xyz = O.match(desc, off, pts, fr["q_desc"], k, radius)
         if "verify" in stages:
             rng = O.rng_new(1)
@@ -68,8 +70,8 @@ def cpu_baseline(desc, pts, off, frames, k, radius, budget_s, stages, iterations
         if t_total > budget_s:
             break
     return dict(value=n / t_total, unit="frames/s", cores=1, kind="port",
-                sample="%d whole frame(s) of the same workload (%d queries x %d DB rows each), oracle/tod_oracle.cpp, 1 thread"
-                       % (n, frames[0]["q_desc"].shape[0], desc.shape[0]))
+                sample="%d whole frame(s) of the same workload, stages %s (%d queries x %d DB rows each), oracle/*.c*, 1 thread"
+                       % (n, "+".join(stages), frames[0]["q_desc"].shape[0], desc.shape[0]))
 
 
 def main():
@@ -102,6 +104,8 @@ def main():
     desc, pts, off = synth.make_db(args.objects)
     frames = [synth.make_frame(desc, pts, off, args.nq, frame=f, visible_object=(17 * f + 3) % args.objects)
               for f in range(args.frames)]
+    for f, fr in enumerate(frames):
+        fr["image"] = synth.make_image(f)
 
     # one explicit stream for everything: libtodhip kernels, torch copies and the RCCL collectives (which order
     # themselves against torch's current stream). The default stream's handle is 0 == "create your own" for
@@ -128,7 +132,7 @@ def main():
     # (random-image ORB descriptors cannot match a synthetic DB; the frame's planted descriptors do that), but its
     # work is part of every frame: it runs on the frame's worker context, overlapped with the next batch's matching.
     my_ids = [f for f in range(len(frames)) if f % world == rank] or [rank % len(frames)]
-    d_img = [torch.from_numpy(synth.make_image(f)).cuda() for f in my_ids] if do_orb else []
+    d_img = [torch.from_numpy(frames[f]["image"]).cuda() for f in my_ids] if do_orb else []
     H, W = frames[0]["cloud"].shape[:2]
     # matcher outputs, double buffered: the verifiers of step s read set (s % 2) while step s+1 fills the other
     outs = [[dict(counts=torch.empty(nq, dtype=torch.int32, device="cuda"),
@@ -248,6 +252,14 @@ def main():
     distances = float(nq) * world * frames_per_launch * info["shard_rows"]
     valu_frac = LANEOPS_PER_DISTANCE * distances / (k4_ms * 1e-3) / VALU_PEAK_LANEOPS if k4_ms > 0 else 0.0
 
+    # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, collected in their own
+    # rocprofv3 runs by tools/profile_k4.sh and committed as profiles/r01_k4_pmc.json); only quoted for the
+    # workload it was measured on
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_k4_pmc.json")
+    if world == 1 and nq == 1000 and k == 2 and info["shard_rows"] == 1000000 and os.path.exists(pmc_path):
+        traffic = json.load(open(pmc_path))["hbm_traffic_bytes_per_launch"]
+        traffic_src = "profiles/r01_k4_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     if rank == 0:
         out = {
             "metric": "frames/sec @ 640x480, 1M-descriptor DB; achieved HBM GB/s on BF-matcher",
@@ -267,7 +279,7 @@ def main():
                        "parallelism": ("DB rows sharded x%d (object aligned), one frame per rank per step, RCCL all-gather of "
                                        "descriptors and of per-shard candidates" % world) if world > 1 else "1 GPU"},
             "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,
                          "note": "at Q=%d queries per DB pass this kernel is bound by integer VALU issue, not HBM "
                                  "(SURVEY F11): see valu_roofline" % nq},
