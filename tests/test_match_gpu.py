@@ -197,3 +197,28 @@ def test_shard_layout_matches_python_mirror(ctx):
             lo, hi, row_lo, row_hi = sharded.shard_bounds(off, r, world)
             assert (info["shard_first"], info["shard_rows"]) == (row_lo, row_hi - row_lo)
             c.close()
+
+
+def test_c5_shape_1080p_orb2000_2m_rows(ctx):
+    """BASELINE configs[4] on one GPU: ORB-2000 frame vs a 2M-descriptor DB (400 objects x 5000), k=5, radius 35.
+    Size-independent properties for all queries, the oracle for a subset."""
+    desc, pts, off = synth.make_db(400)
+    fr = synth.make_frame(desc, pts, off, 2000, frame=9, visible_object=321, H=1080, W=1920, f=1400.0)
+    ctx.db_load(desc, pts, off)
+    row_ptr, m, xyz = ctx.match(fr["q_desc"], 5, 35)
+    rows = off[m["imgIdx"]].astype(np.int64) + m["trainIdx"]
+    lut = np.array([bin(i).count("1") for i in range(256)], np.uint32)
+    true_d = lut[np.bitwise_xor(desc[rows], fr["q_desc"][m["queryIdx"]])].sum(axis=1)
+    assert np.array_equal(true_d.astype(np.float32), m["distance"]) and (m["distance"] <= 35).all()
+    planted = np.flatnonzero(fr["truth_rows"] >= 0)
+    has = np.diff(row_ptr.astype(np.int64))[planted] >= 1            # 8 % bit flips: a few planted rows end up > radius
+    assert has.mean() > 0.99
+    first = rows[row_ptr[planted[has]]]                              # planted queries: the source row comes first
+    assert np.array_equal(first, fr["truth_rows"][planted[has]])
+    assert np.array_equal(xyz, pts[rows])
+    sub = np.arange(0, 2000, 125)                                    # 16 queries against all 2M rows on the CPU
+    keys = O.knn_keys(desc, fr["q_desc"][sub], 5)
+    for i, q in enumerate(sub):
+        want = [int(kk) for kk in keys[i] if (int(kk) >> 32) <= 35]
+        got = [(int(d) << 32) | int(r) for d, r in zip(m["distance"][row_ptr[q]:row_ptr[q + 1]], rows[row_ptr[q]:row_ptr[q + 1]])]
+        assert got == want

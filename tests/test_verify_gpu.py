@@ -290,3 +290,23 @@ def test_two_rank_step_in_process(ctx):
         assert np.array_equal(poses[0]["inliers"], want[0]["inliers"]) and np.array_equal(poses[0]["R"], want[0]["R"])
     for c in ctxs + [single]:
         c.close()
+
+
+def test_large_dense_object_uses_big_lds_pass(ctx):
+    """> 330 mutually consistent matches on one object: the induced graph no longer fits the 48 KB LDS carve of the
+    first evaluation pass and goes through the deferred 160 KB pass; results must still equal the oracle"""
+    sc = synth.make_verify_scene(1300, n_objects=2, per_object=1000, visible=((1, 0.55),), matches_per_kp=1, seed=77,
+                                 nan_frac=0.0)
+    poses, rounds = _compare_frame(ctx, sc, 8, 60)
+    assert len(poses) == 1 and len(poses[0]["inliers"]) > 500
+
+
+def test_object_too_large_is_reported_not_wrong(ctx):
+    """the clique gate's graph is limited by one CU's LDS (~1050 vertices): beyond that the call fails with
+    TODHIP_ESCRATCH instead of returning something different from the reference"""
+    sc = synth.make_verify_scene(2600, n_objects=2, per_object=2000, visible=((1, 0.6),), matches_per_kp=1, seed=78,
+                                 nan_frac=0.0)
+    rng = capi.rng_new(1)
+    with pytest.raises(capi.TodError) as e:
+        ctx.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 20, 0.01, rng)
+    assert e.value.status == capi.ESCRATCH
