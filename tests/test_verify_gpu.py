@@ -301,12 +301,10 @@ def test_large_dense_object_uses_big_lds_pass(ctx):
     assert len(poses) == 1 and len(poses[0]["inliers"]) > 500
 
 
-def test_object_too_large_is_reported_not_wrong(ctx):
-    """the clique gate's graph is limited by one CU's LDS (~1050 vertices): beyond that the call fails with
-    TODHIP_ESCRATCH instead of returning something different from the reference"""
+def test_very_large_object_falls_back_to_global_adjacency(ctx):
+    """~1500 consistent matches: the induced graph exceeds one CU's LDS, so the gate keeps its adjacency matrix in
+    global scratch (third tier). Slow, but the result must still equal the oracle."""
     sc = synth.make_verify_scene(2600, n_objects=2, per_object=2000, visible=((1, 0.6),), matches_per_kp=1, seed=78,
                                  nan_frac=0.0)
-    rng = capi.rng_new(1)
-    with pytest.raises(capi.TodError) as e:
-        ctx.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 20, 0.01, rng)
-    assert e.value.status == capi.ESCRATCH
+    poses, rounds = _compare_frame(ctx, sc, 8, 12)
+    assert len(poses) == 1 and len(poses[0]["inliers"]) > 1400

@@ -193,10 +193,16 @@ __host__ __device__ inline uint32_t gate_lds_bytes(uint32_t m) {
   const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;      // ma >= m + 2
   return 8u * m * MW + 8u * MW + 8u * 4u * ma + 4u * 2u * ma + 64u;
 }
-__device__ inline GateLds gate_carve(unsigned char* base, uint32_t m) {
+__host__ __device__ inline uint32_t gate_small_bytes(uint32_t m) {           // everything except the adjacency matrix
+  const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;
+  return 8u * MW + 8u * 4u * ma + 4u * 2u * ma + 64u;
+}
+// ext_adjc != nullptr: the m x MW matrix lives in global scratch (graphs beyond one CU's LDS); same code path,
+// the pointers are generic
+__device__ inline GateLds gate_carve(unsigned char* base, uint32_t m, u64* ext_adjc = nullptr) {
   const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;
   GateLds L;
-  L.adjc = reinterpret_cast<u64*>(base); base += 8u * m * MW;
+  if (ext_adjc) { L.adjc = ext_adjc; } else { L.adjc = reinterpret_cast<u64*>(base); base += 8u * m * MW; }
   L.mask = reinterpret_cast<u64*>(base); base += 8u * MW;
   L.C = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
   L.deg = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
@@ -434,6 +440,8 @@ __device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, 
   return qmax;
 }
 
+constexpr uint32_t kAdjcScratchWords = 256u * 1024u;   // 2 MB per deferred hypothesis: m * ceil(m/64) <= 262144 -> m <= 4064
+
 struct EvalArgs {
   ObjJob job;
   const uint32_t* iter_samples;   // 3 per iteration
@@ -448,6 +456,7 @@ struct EvalArgs {
   uint32_t lds_bytes;
   uint32_t from_deferred;         // 1: the work list is `deferred`
   uint32_t n_deferred;
+  u64* adjc_scratch;              // deferred pass only: kAdjcScratchWords u64 per block for graphs beyond the LDS
   uint32_t* dbg;                  // optional: per iteration dbg_stride words {cnt, m, F members...}
   uint32_t dbg_stride;
   uint32_t stop_level;            // 0 = full evaluation, 1 = stop before the clique search (diagnostics)
@@ -492,16 +501,19 @@ __global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
       m_diag = m;
       if (m <= kGateMinimal) {
         result = 0;                                        // :214-218
-      } else if (gate_lds_bytes(m) > A.lds_bytes) {
+      } else if (gate_lds_bytes(m) > A.lds_bytes &&
+                 !(A.from_deferred && A.adjc_scratch && gate_small_bytes(m) <= A.lds_bytes &&
+                   m * ((m + 63u) / 64u) <= kAdjcScratchWords)) {
         if (A.from_deferred) {
-          if (l == 0) atomicExch(&A.status[0], 2u);        // graph too large even for the big-LDS pass
+          if (l == 0) atomicExch(&A.status[0], 2u);        // graph too large even with the adjacency in global memory
           result = INT_MIN;
         } else {
           if (l == 0) A.deferred[atomicAdd(&A.status[2], 1u)] = it;
           result = INT_MIN + 1;                            // filled in by the second pass
         }
       } else {
-        GateLds L = gate_carve(lds_raw, m);
+        const bool ext = gate_lds_bytes(m) > A.lds_bytes;   // third tier: adjacency matrix in global scratch
+        GateLds L = gate_carve(lds_raw, m, ext ? A.adjc_scratch + (size_t)blockIdx.x * kAdjcScratchWords : nullptr);
         const uint32_t MW = (m + 63u) / 64u;
         const long long t_start = A.dbg ? clock64() : 0;   // phase stamps (diagnostics builds of the call only)
         // F in ascending order (:219) -> graph index = rank (:241-243)
@@ -1017,7 +1029,7 @@ __global__ __launch_bounds__(256) void cluster_group_kernel(uint32_t n_all, cons
 // ------------------------------------------------------------------------------------------------ host side
 struct VerifyWs {
   DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, rnd, table, iter_samples, iter_pos, counts, gate_m,
-      small, deferred, stacks, kp_list, kp_bits, clique_adj, c_kept, c_offs, c_qpt, c_obj, c_hist, c_goff, f_train,
+      small, deferred, stacks, kp_list, kp_bits, clique_adj, adjc_scratch, c_kept, c_offs, c_qpt, c_obj, c_hist, c_goff, f_train,
       f_query, f_qidx, f_kp;
   HostBuf h_small, h_counts, h_pos, h_kp, h_trip, h_goff;
   std::vector<uint32_t> rnd_host;
@@ -1154,7 +1166,7 @@ int ransac_round(todhip_ctx* ctx, VerifyWs* ws, const ObjJob& job, uint32_t nq, 
       A.counts = ws->counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
       A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>(); A.stacks = ws->stacks.as<uint16_t>();
       A.stack_cap = kStackCap; A.lds_bytes = kEvalLdsSmall; A.from_deferred = 0; A.n_deferred = 0;
-      A.dbg = nullptr; A.dbg_stride = 0; A.stop_level = 0;
+      A.adjc_scratch = nullptr; A.dbg = nullptr; A.dbg_stride = 0; A.stop_level = 0;
       TOD_HIP(hipMemsetAsync(d_small + 8, 0, 12 * sizeof(uint32_t), st));
       const uint32_t waves = got;                         // one block per hypothesis; batches are <= 1024
       TOD_DBG("  eval: iterations [%u,%u) on %u waves", it_begin, it_drawn, waves);
@@ -1174,6 +1186,8 @@ int ransac_round(todhip_ctx* ctx, VerifyWs* ws, const ObjJob& job, uint32_t nq, 
       ctx->counters.last_gate_calls += h_small[13];
       if (n_def > 0) {                                    // graphs that need the whole LDS of a CU
         A.lds_bytes = kEvalLdsBig; A.from_deferred = 1; A.n_deferred = n_def;
+        TOD_HIP(ws->adjc_scratch.reserve((size_t)n_def * kAdjcScratchWords * sizeof(u64)));
+        A.adjc_scratch = ws->adjc_scratch.as<u64>();
         TOD_HIP(hipMemsetAsync(d_small + 8, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(eval_kernel, dim3(n_def), dim3(64), kEvalLdsBig, st, A);
         TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1248,7 +1262,7 @@ void tod_verify_ws_free(todhip_ctx* ctx) {
   VerifyWs* ws = reinterpret_cast<VerifyWs*>(ctx->verify_ws);
   DevBuf* bufs[] = {&ws->train, &ws->query, &ws->qidx, &ws->kpxy, &ws->phys, &ws->samp, &ws->bits, &ws->sampdeg,
                     &ws->rnd, &ws->table, &ws->iter_samples, &ws->iter_pos, &ws->counts, &ws->gate_m, &ws->small,
-                    &ws->deferred, &ws->stacks, &ws->kp_list, &ws->kp_bits, &ws->clique_adj, &ws->c_kept, &ws->c_offs,
+                    &ws->deferred, &ws->stacks, &ws->kp_list, &ws->kp_bits, &ws->clique_adj, &ws->adjc_scratch, &ws->c_kept, &ws->c_offs,
                     &ws->c_qpt, &ws->c_obj, &ws->c_hist, &ws->c_goff, &ws->f_train, &ws->f_query, &ws->f_qidx, &ws->f_kp};
   for (DevBuf* b : bufs) b->release();
   ws->h_small.release(); ws->h_counts.release(); ws->h_pos.release(); ws->h_kp.release(); ws->h_trip.release();
@@ -1553,6 +1567,7 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   A.counts = ws->counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
   A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>(); A.stacks = ws->stacks.as<uint16_t>();
   A.stack_cap = kStackCap; A.lds_bytes = kEvalLdsSmall; A.from_deferred = 0; A.n_deferred = 0;
+  A.adjc_scratch = nullptr;
   A.dbg = dbg ? ws->table.as<uint32_t>() : nullptr; A.dbg_stride = dbg_stride; A.stop_level = stop_level;
   if (n_triples > kMaxEvalWaves) return TODHIP_EINVAL;
   hipLaunchKernelGGL(eval_kernel, dim3(n_triples), dim3(64), kEvalLdsSmall, st, A);
@@ -1562,6 +1577,8 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   const uint32_t status = h_small[12], n_def = h_small[14];
   if (status == 0 && n_def > 0) {
     A.lds_bytes = kEvalLdsBig; A.from_deferred = 1; A.n_deferred = n_def;
+    TOD_HIP(ws->adjc_scratch.reserve((size_t)n_def * kAdjcScratchWords * sizeof(u64)));
+    A.adjc_scratch = ws->adjc_scratch.as<u64>();
     TOD_HIP(hipMemsetAsync(d_small + 8, 0, sizeof(uint32_t), st));
     hipLaunchKernelGGL(eval_kernel, dim3(n_def), dim3(64), kEvalLdsBig, st, A);
     TOD_HIP(hipGetLastError());
