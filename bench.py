@@ -145,6 +145,8 @@ def main():
     # high-priority streams: the verifier's short kernels must not queue behind the matcher's full-chip launches
     vstreams = [torch.cuda.Stream(priority=-1) for _ in range(n_workers)]
     vctx = [capi.Context(local_rank, vs.cuda_stream) for vs in vstreams]
+    for c, vs in zip(vctx, vstreams):
+        c.tstream = vs
     pool = ThreadPoolExecutor(n_workers) if n_workers else None
     import queue
     free_ctx = queue.Queue()                          # one call in flight per context
@@ -154,7 +156,8 @@ def main():
         free_ctx.put(c)
     n_kp_total = [0]
     n_pose_total = [0]
-    pending = []
+    from collections import deque
+    pending = deque()                                  # one list of futures per step in flight
 
     def alloc(shape, dtype_name):
         return torch.empty(shape, dtype=getattr(torch, dtype_name), device="cuda")
@@ -167,31 +170,40 @@ def main():
             dist.all_gather(parts, inp.contiguous().view(-1).cpu())
             out.view(-1).copy_(torch.cat(parts).to(out.device))
 
-    def verify_task(f, o):
+    def verify_task(f, o, ev):
         c = free_ctx.get()
         try:
+            c.tstream.wait_event(ev)                   # this step's matcher outputs (recorded on the main stream)
             n_kp = 0
+            t_a = time.perf_counter()
             if do_orb:
                 n_kp = c.orb_device(d_img[f].data_ptr(), H, W, W, args.nq, 3, 1.2, c.orb_out[0].data_ptr(),
                                               c.orb_out[1].data_ptr(), c.orb_out[2].data_ptr(), args.nq)
             poses = []
+            t_b = time.perf_counter()
             if do_verify:
                 rng = capi.rng_new(1)                 # rand() restarts per frame (decision D4)
                 poses = c.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), H, W, o["counts"].data_ptr(),
                                         o["matches"].data_ptr(), o["xyz"].data_ptr(), k, db_spans, args.min_inliers,
                                         args.iterations, 0.01, rng)
+            t_c = time.perf_counter()
+            c.t_orb = getattr(c, "t_orb", 0.0) + (t_b - t_a)
+            c.t_verify = getattr(c, "t_verify", 0.0) + (t_c - t_b)
+            c.n_frames = getattr(c, "n_frames", 0) + 1
         finally:
             free_ctx.put(c)
         return len(poses), n_kp
 
-    def drain():
-        for fut in pending:
-            n_p, n_k = fut.result()
-            n_pose_total[0] += n_p
-            n_kp_total[0] += n_k
-        del pending[:]
+    def drain(keep=0):
+        while len(pending) > keep:
+            for fut in pending.popleft():
+                n_p, n_k = fut.result()
+                n_pose_total[0] += n_p
+                n_kp_total[0] += n_k
 
     def step(i):
+        if n_workers:
+            drain(keep=1)                              # buffers of step i-2 are free again; step i-1 keeps running
         buf = outs[i % 2]
         fidx = [(i * B + b) % len(d_q) for b in range(B)]
         if world == 1:
@@ -212,10 +224,9 @@ def main():
                 ctx.merge_shards_device(km.data_ptr(), world, nq, k, args.radius, buf[b]["counts"].data_ptr(),
                                         buf[b]["matches"].data_ptr(), buf[b]["xyz"].data_ptr())
         if n_workers:
-            stream.synchronize()                       # the matcher outputs of this step are complete
-            drain()                                    # verifiers of the previous step (ran beside this step's matching)
-            for b in range(B):
-                pending.append(pool.submit(verify_task, fidx[b], buf[b]))
+            ev = torch.cuda.Event()
+            ev.record(stream)                          # the matcher outputs of this step are complete after this
+            pending.append([pool.submit(verify_task, fidx[b], buf[b], ev) for b in range(B)])
 
     def fence():
         if n_workers:
@@ -273,11 +284,15 @@ def main():
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
                        "poses_per_frame_rank0": n_pose_total[0] / max((args.steps + args.warmup) * B, 1),
                        "frames_per_rank_per_step": B, "verify_workers": n_workers,
+                       "worker_ms_per_frame": {"orb": 1e3 * sum(getattr(c, "t_orb", 0.0) for c in vctx) /
+                                               max(sum(getattr(c, "n_frames", 0) for c in vctx), 1),
+                                               "verify": 1e3 * sum(getattr(c, "t_verify", 0.0) for c in vctx) /
+                                               max(sum(getattr(c, "n_frames", 0) for c in vctx), 1)} if n_workers else None,
                        "orb": "ORB-%d, 3 levels, scale 1.2 on the 8(d) synthetic image; %.0f keypoints/frame" %
                               (args.nq, n_kp_total[0] / max((args.steps + args.warmup) * B, 1)) if do_orb else None,
                        "frames_per_step": world * B,
-                       "parallelism": ("DB rows sharded x%d (object aligned), one frame per rank per step, RCCL all-gather of "
-                                       "descriptors and of per-shard candidates" % world) if world > 1 else "1 GPU"},
+                       "parallelism": ("DB rows sharded x%d (object aligned), %d frames per rank per step, RCCL all-gather of "
+                                       "descriptors and of per-shard candidates" % (world, B)) if world > 1 else "1 GPU"},
             "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,

@@ -314,6 +314,10 @@ struct OrbWs {
   DevBuf img[2], blur, tmp, score, cand, eq, sel1, sel2, small, pattern, in_img, kp_xy, kp_aux, desc;
   HostBuf h_out;
   bool pattern_is_default = false;
+  // the per-frame launch sequence is static for a given geometry and output buffers: captured once, replayed
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  struct Key { uint32_t H, W, n_features, n_levels, cap; float sf; const void *kp, *aux, *desc, *img0; } key = {};
 };
 
 OrbWs* ows_of(todhip_ctx* ctx) {
@@ -366,6 +370,15 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
   TOD_HIP(hipMemsetAsync(d_small, 0, 512 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, st, d_gray, stride,
                      ws->img[0].as<uint8_t>(), H, W);
+  OrbWs::Key key = {H, W, n_features, n_levels, cap, scale_factor, d_kp_xy, d_kp_aux, d_desc, ws->img[0].p};
+  const bool reuse = ws->graph_exec && std::memcmp(&key, &ws->key, sizeof(key)) == 0;
+  if (!reuse) {
+    if (ws->graph_exec) { (void)hipGraphExecDestroy(ws->graph_exec); ws->graph_exec = nullptr; }
+    if (ws->graph) { (void)hipGraphDestroy(ws->graph); ws->graph = nullptr; }
+    // thread-local capture: other host threads keep using the runtime while this one records
+    TOD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int cap_rc = TODHIP_OK;
+    {
   DescribeArgs D;
   disc_umax(D.umax);
   uint32_t ph = H, pw = W;
@@ -384,8 +397,8 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
     const dim3 grid2((w + 63u) / 64u, (h + 3u) / 4u);
     const uint32_t want = per_level[lvl];
     if (want == 0) continue;
-    TOD_HIP(hipMemsetAsync(d_small, 0, 8 * sizeof(uint32_t), st));
-    TOD_HIP(hipMemsetAsync(d_small + W_HIST, 0, 256 * sizeof(uint32_t), st));
+    if (hipMemsetAsync(d_small, 0, 8 * sizeof(uint32_t), st) != hipSuccess) cap_rc = TODHIP_EHIP;
+    if (hipMemsetAsync(d_small + W_HIST, 0, 256 * sizeof(uint32_t), st) != hipSuccess) cap_rc = TODHIP_EHIP;
     hipLaunchKernelGGL(fast_score_kernel, grid2, dim3(256), 0, st, img, h, w, ws->score.as<int>());
     hipLaunchKernelGGL(nms_kernel, grid2, dim3(256), 0, st, ws->score.as<int>(), h, w, ws->cand.as<Cand>(), cand_cap, d_small,
                        d_small + W_HIST);
@@ -404,8 +417,16 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
     D.level_counts = d_small + 8; D.level = lvl; D.scale = scale; D.cap = cap; D.pattern = ws->pattern.as<int8_t>();
     D.kp_xy = d_kp_xy; D.kp_aux = d_kp_aux; D.desc = d_desc;
     hipLaunchKernelGGL(describe_kernel, dim3((want + 3u) / 4u), dim3(256), 0, st, D);
-    TOD_HIP(hipGetLastError());
   }
+    }
+    hipGraph_t g = nullptr;
+    const hipError_t ee = hipStreamEndCapture(st, &g);
+    if (ee != hipSuccess || cap_rc != TODHIP_OK || !g) { ctx->last_hip_error = (int)ee; return TODHIP_EHIP; }
+    ws->graph = g;
+    TOD_HIP(hipGraphInstantiate(&ws->graph_exec, ws->graph, nullptr, nullptr, 0));
+    ws->key = key;
+  }
+  TOD_HIP(hipGraphLaunch(ws->graph_exec, st));
   uint32_t* h_counts = ws->h_out.as<uint32_t>();
   TOD_HIP(hipMemcpyAsync(h_counts, d_small + 8, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   TOD_HIP(hipStreamSynchronize(st));
@@ -423,6 +444,8 @@ void tod_orb_ws_free(todhip_ctx* ctx) {
   DevBuf* bufs[] = {&ws->img[0], &ws->img[1], &ws->blur, &ws->tmp, &ws->score, &ws->cand, &ws->eq, &ws->sel1, &ws->sel2,
                     &ws->small, &ws->pattern, &ws->in_img, &ws->kp_xy, &ws->kp_aux, &ws->desc};
   for (DevBuf* b : bufs) b->release();
+  if (ws->graph_exec) (void)hipGraphExecDestroy(ws->graph_exec);
+  if (ws->graph) (void)hipGraphDestroy(ws->graph);
   ws->h_out.release();
   delete ws;
   ctx->orb_ws = nullptr;
