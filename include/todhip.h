@@ -123,6 +123,16 @@ int todhip_verify_device(todhip_ctx*, const void* d_kp_xy, uint32_t nq, const vo
                          const float* spans, uint32_t n_objs, const todhip_verify_params*, todhip_rng* rng,
                          todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp);
 
+/* Same, but the query points are back-projected from the registered depth image instead of being read from a
+ * materialised H x W x 3 cloud (replaces RescaledRegisteredDepth -> DepthTo3d ->
+ * GuessGenerator's cloud lookup, detector.py:26,62,66-69 + adjacency_ransac.cpp:184-185). d_depth: H x W, float
+ * metres (NaN = no depth) or, with depth_is_u16, uint16 millimetres (0 = no depth). K9: row-major 3x3 intrinsics. */
+int todhip_verify_device_depth(todhip_ctx*, const void* d_kp_xy, uint32_t nq, const void* d_depth, int depth_is_u16,
+                               uint32_t H, uint32_t W, const float* K9, const void* d_counts, const void* d_matches,
+                               const void* d_matches_xyz, uint32_t k, const float* spans, uint32_t n_objs,
+                               const todhip_verify_params*, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
+                               uint32_t* inlier_kp, uint32_t* n_inlier_kp);
+
 /* ---- stage A: ORB features (ecto_opencv FeatureDescriptor -> cv::ORB; detector.py:10,27) --------- */
 /* gray: H x W u8, row stride `stride`. Outputs up to n_features keypoints: kp_xy (x,y level-0 pixels),
  * kp_aux (size, angle_deg, response, octave) and 32-byte rBRIEF descriptors. *n_out: capacity in, count out.

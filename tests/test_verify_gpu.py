@@ -308,3 +308,41 @@ def test_very_large_object_falls_back_to_global_adjacency(ctx):
                                  nan_frac=0.0)
     poses, rounds = _compare_frame(ctx, sc, 8, 12)
     assert len(poses) == 1 and len(poses[0]["inliers"]) > 1400
+
+
+@pytest.mark.parametrize("u16", [False, True])
+def test_depth_image_form_equals_cloud_form(ctx, u16):
+    """N3: back-projecting only the keypoints from the depth image == looking them up in the full cloud that the
+    same back-projection produces (cv::depthTo3d convention), for float metres and uint16 millimetres"""
+    import torch
+    desc, pts, off = synth.make_db(2, per_object=3000)
+    fr = synth.make_frame(desc, pts, off, 500, frame=6, visible_object=0)
+    H, W, f = 480, 640, 525.0
+    K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]], np.float32)
+    z = fr["cloud"][:, :, 2].copy()
+    if u16:
+        d16 = np.where(np.isnan(z), 0, np.rint(z * 1000.0)).astype(np.uint16)
+        z = np.where(d16 == 0, np.nan, d16.astype(np.float32) * np.float32(0.001)).astype(np.float32)
+        depth = d16
+    else:
+        depth = z
+    u, v = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    cloud = np.stack([(u - K[0, 2]) * z / K[0, 0], (v - K[1, 2]) * z / K[1, 1], z], axis=2).astype(np.float32)
+    spans = ctx.db_load(desc, pts, off)
+    nq, k = 500, 5
+    d_q = torch.from_numpy(fr["q_desc"]).cuda()
+    d_counts = torch.empty(nq, dtype=torch.int32, device="cuda")
+    d_m = torch.empty((nq * k, 4), dtype=torch.int32, device="cuda")
+    d_xyz = torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")
+    d_kp = torch.from_numpy(fr["kp_xy"]).cuda()
+    d_cloud = torch.from_numpy(cloud).cuda()
+    d_depth = torch.from_numpy(depth.view(np.int16) if u16 else depth).cuda()
+    torch.cuda.synchronize()
+    ctx.match_device(d_q.data_ptr(), nq, k, 35, d_counts.data_ptr(), d_m.data_ptr(), d_xyz.data_ptr())
+    r1, r2 = capi.rng_new(1), capi.rng_new(1)
+    a = ctx.verify_device(d_kp.data_ptr(), nq, d_cloud.data_ptr(), H, W, d_counts.data_ptr(), d_m.data_ptr(),
+                          d_xyz.data_ptr(), k, spans, 8, 1000, 0.01, r1)
+    b = ctx.verify_device_depth(d_kp.data_ptr(), nq, d_depth.data_ptr(), u16, H, W, K, d_counts.data_ptr(),
+                                d_m.data_ptr(), d_xyz.data_ptr(), k, spans, 8, 1000, 0.01, r2)
+    assert len(a) == len(b) == 1 and r1.draws == r2.draws
+    assert np.array_equal(a[0]["inliers"], b[0]["inliers"]) and np.array_equal(a[0]["R"], b[0]["R"]) and np.array_equal(a[0]["t"], b[0]["t"])

@@ -56,7 +56,7 @@ EXPORTS = [
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device",
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
-    "todhip_orb_device",
+    "todhip_orb_device", "todhip_verify_device_depth",
 ]
 
 _lib = None
@@ -246,6 +246,27 @@ class Context:
             out.append(dict(object=int(p.object), R=np.array(p.R[:], np.float32).reshape(3, 3),
                             t=np.array(p.t[:], np.float32), inliers=inl[p.inlier_begin:p.inlier_end].copy()))
         return out
+
+    def verify_device_depth(self, d_kp_xy, nq, d_depth, depth_is_u16, H, W, K, d_counts, d_matches, d_xyz, k, spans,
+                            min_inliers, n_iter, err, rng, max_poses=64):
+        sp = np.ascontiguousarray(spans, np.float32)
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        prm = VerifyParams(min_inliers, n_iter, err)
+        poses = (Pose * max_poses)()
+        n_poses = C.c_uint32(max_poses)
+        cap = max(nq, 1) * max_poses
+        inl = np.zeros(cap, np.uint32)
+        n_inl = C.c_uint32(cap)
+        rc = lib().todhip_verify_device_depth(self._h, C.c_void_p(d_kp_xy), C.c_uint32(nq), C.c_void_p(d_depth),
+                                              C.c_int(1 if depth_is_u16 else 0), C.c_uint32(H), C.c_uint32(W),
+                                              _np_ptr(K9), C.c_void_p(d_counts), C.c_void_p(d_matches),
+                                              C.c_void_p(d_xyz), C.c_uint32(k), _np_ptr(sp), C.c_uint32(len(sp)),
+                                              C.byref(prm), C.byref(rng), poses, C.byref(n_poses), _np_ptr(inl),
+                                              C.byref(n_inl))
+        _check(rc, "todhip_verify_device_depth")
+        return [dict(object=int(poses[i].object), R=np.array(poses[i].R[:], np.float32).reshape(3, 3),
+                     t=np.array(poses[i].t[:], np.float32),
+                     inliers=inl[poses[i].inlier_begin:poses[i].inlier_end].copy()) for i in range(n_poses.value)]
 
     def verify_trace(self, cap=4096):
         arr = (RoundTrace * cap)()

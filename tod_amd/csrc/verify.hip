@@ -962,6 +962,37 @@ __global__ __launch_bounds__(256) void cluster_lookup_kernel(const float* __rest
   kept[q] = isnan(p[0]) ? 0u : counts[q];                                // only .x is tested (:189)
 }
 
+// N3: the reference back-projects the WHOLE registered depth image to an H x W x 3 cloud
+// (ecto_opencv DepthTo3d, python/object_recognition_tod/detector.py:26,62,66-69) and then reads Q points of it
+// (adjacency_ransac.cpp:184-185). Here the Q points are computed directly: same pixel truncation, same pinhole
+// back-projection as cv::depthTo3d (x = (u - cx) z / fx, y = (v - cy) z / fy), uint16 depth in millimetres with 0 = no
+// measurement -> NaN as cv::rescaleDepth does (third-party conventions, recalled; parity unpinned).
+__global__ __launch_bounds__(256) void cluster_lookup_depth_kernel(const float* __restrict__ kp_xy, uint32_t nq,
+                                                                   const void* __restrict__ depth, int depth_is_u16,
+                                                                   uint32_t H, uint32_t Wimg, float fx, float fy, float cx,
+                                                                   float cy, const uint32_t* __restrict__ counts,
+                                                                   uint32_t* kept, float* qpt, uint32_t* err) {
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= nq) return;
+  const int row = (int)kp_xy[2 * q + 1], col = (int)kp_xy[2 * q];
+  if (row < 0 || col < 0 || (uint32_t)row >= H || (uint32_t)col >= Wimg) {
+    atomicExch(err, 1u);
+    kept[q] = 0;
+    return;
+  }
+  float z;
+  if (depth_is_u16) {
+    const uint16_t d = reinterpret_cast<const uint16_t*>(depth)[(size_t)row * Wimg + col];
+    z = d == 0 ? __builtin_nanf("") : (float)d * 0.001f;
+  } else {
+    z = reinterpret_cast<const float*>(depth)[(size_t)row * Wimg + col];
+  }
+  const float x = ((float)col - cx) * z / fx, y = ((float)row - cy) * z / fy;
+  qpt[3 * q] = x; qpt[3 * q + 1] = y; qpt[3 * q + 2] = z;
+  kept[q] = isnan(x) ? 0u : counts[q];
+}
+
 // exclusive scan of kept[0..nq) into offs[0..nq], one block
 __global__ __launch_bounds__(1024) void cluster_scan_kernel(const uint32_t* __restrict__ kept, uint32_t nq, uint32_t* offs) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
@@ -1421,15 +1452,18 @@ int todhip_verify(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float*
 
 // Device-resident form: keypoints, cloud and the matcher's fixed-stride outputs (counts[nq], matches[nq*k],
 // matches_xyz[nq*k*3], see todhip_match_device) are already in HBM; only poses come back to the host.
-int todhip_verify_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const void* d_cloud, uint32_t H,
-                         uint32_t Wimg, const void* d_counts, const void* d_matches, const void* d_mxyz, uint32_t k,
-                         const float* spans, uint32_t n_objs, const todhip_verify_params* prm, todhip_rng* rng,
-                         todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+struct DepthInput { const void* d_depth; int is_u16; float fx, fy, cx, cy; };
+
+static int verify_device_impl(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const void* d_cloud, const DepthInput* dep,
+                              uint32_t H, uint32_t Wimg, const void* d_counts, const void* d_matches, const void* d_mxyz,
+                              uint32_t k, const float* spans, uint32_t n_objs, const todhip_verify_params* prm,
+                              todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp,
+                              uint32_t* n_inlier_kp) {
   int rc = verify_prologue(ctx, prm, rng, poses, n_poses, inlier_kp, n_inlier_kp);
   if (rc != TODHIP_OK) return rc;
   const uint32_t pose_cap = *n_poses, kp_cap = *n_inlier_kp;
   *n_poses = 0; *n_inlier_kp = 0;
-  if (!d_cloud || H == 0 || Wimg == 0) return TODHIP_OK;
+  if ((!d_cloud && !dep) || H == 0 || Wimg == 0) return TODHIP_OK;
   if (nq == 0 || n_objs == 0) return TODHIP_OK;
   if (!d_kp_xy || !d_counts || !d_matches || !d_mxyz || !spans || k == 0) return TODHIP_EINVAL;
   TOD_HIP(hipSetDevice(ctx->device));
@@ -1450,9 +1484,14 @@ int todhip_verify_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, cons
   uint32_t* d_small = ws->small.as<uint32_t>();
   TOD_HIP(hipMemsetAsync(d_small + 60, 0, sizeof(uint32_t), st));
   TOD_HIP(hipMemsetAsync(ws->c_hist.p, 0, (size_t)n_objs * 4, st));
-  hipLaunchKernelGGL(cluster_lookup_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, st, (const float*)d_kp_xy, nq,
-                     (const float*)d_cloud, H, Wimg, (const uint32_t*)d_counts, ws->c_kept.as<uint32_t>(),
-                     ws->c_qpt.as<float>(), d_small + 60);
+  if (dep)
+    hipLaunchKernelGGL(cluster_lookup_depth_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, st, (const float*)d_kp_xy, nq,
+                       dep->d_depth, dep->is_u16, H, Wimg, dep->fx, dep->fy, dep->cx, dep->cy, (const uint32_t*)d_counts,
+                       ws->c_kept.as<uint32_t>(), ws->c_qpt.as<float>(), d_small + 60);
+  else
+    hipLaunchKernelGGL(cluster_lookup_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, st, (const float*)d_kp_xy, nq,
+                       (const float*)d_cloud, H, Wimg, (const uint32_t*)d_counts, ws->c_kept.as<uint32_t>(),
+                       ws->c_qpt.as<float>(), d_small + 60);
   hipLaunchKernelGGL(cluster_scan_kernel, dim3(1), dim3(1024), 0, st, ws->c_kept.as<uint32_t>(), nq, ws->c_offs.as<uint32_t>());
   hipLaunchKernelGGL(cluster_scatter_kernel, dim3((uint32_t)((cap + 255u) / 256u)), dim3(256), 0, st, (const float*)d_kp_xy, nq, k,
                      (const todhip_dmatch*)d_matches, (const float*)d_mxyz, ws->c_kept.as<uint32_t>(),
@@ -1484,6 +1523,25 @@ int todhip_verify_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, cons
                      ws->qidx.as<uint32_t>(), ws->kpxy.as<float>());
   TOD_HIP(hipGetLastError());
   return verify_grouped(ctx, ws, spans_list, nq, spans, prm, rng, poses, pose_cap, n_poses, inlier_kp, kp_cap, n_inlier_kp);
+}
+
+int todhip_verify_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const void* d_cloud, uint32_t H,
+                         uint32_t Wimg, const void* d_counts, const void* d_matches, const void* d_mxyz, uint32_t k,
+                         const float* spans, uint32_t n_objs, const todhip_verify_params* prm, todhip_rng* rng,
+                         todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  return verify_device_impl(ctx, d_kp_xy, nq, d_cloud, nullptr, H, Wimg, d_counts, d_matches, d_mxyz, k, spans, n_objs,
+                            prm, rng, poses, n_poses, inlier_kp, n_inlier_kp);
+}
+
+int todhip_verify_device_depth(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const void* d_depth, int depth_is_u16,
+                               uint32_t H, uint32_t Wimg, const float* K9, const void* d_counts, const void* d_matches,
+                               const void* d_mxyz, uint32_t k, const float* spans, uint32_t n_objs,
+                               const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
+                               uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  if (!d_depth || !K9) return TODHIP_EINVAL;
+  DepthInput dep = {d_depth, depth_is_u16, K9[0], K9[4], K9[2], K9[5]};
+  return verify_device_impl(ctx, d_kp_xy, nq, nullptr, &dep, H, Wimg, d_counts, d_matches, d_mxyz, k, spans, n_objs, prm,
+                            rng, poses, n_poses, inlier_kp, n_inlier_kp);
 }
 
 int todhip_verify_trace(const todhip_ctx* ctx, todhip_round_trace* out, uint32_t* n) {
