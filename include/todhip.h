@@ -147,6 +147,23 @@ int todhip_orb_device(todhip_ctx*, const void* d_gray, uint32_t H, uint32_t W, u
                       uint32_t n_levels, float scale_factor, const int8_t* pattern, void* d_kp_xy, void* d_kp_aux,
                       void* d_desc, uint32_t* n_out);
 
+/* ---- training ----------------------------------------------------------------- */
+/* Per-observation arithmetic of the reference's Trainer cell (src/training/Trainer.cpp:121-187, training.cpp:57-195):
+ * ORB on the masked view (the reference uses cv::ORB defaults: 500 features, 8 levels, scale 1.2 -- :148-149),
+ * validateKeyPoints (mask eroded 4x, +-2 pixel rescue, depth validity), depthTo3dSparse, cameraToWorld, mergePoints.
+ * A model is accumulated on the device; its rows are what todhip_db_load ingests (ModelFiller.cpp:23-24). */
+typedef struct todhip_model todhip_model;
+int  todhip_model_begin(todhip_ctx*, uint32_t capacity_rows, todhip_model** out);
+/* gray/mask: H x W u8 (mask != 0 = object); depth: H x W float metres (NaN = none) or uint16 millimetres (0 = none),
+ * same size as the image (rescale_depth's equal-size branch, Trainer.cpp:63-72); K9, R9 row-major; T3. */
+int  todhip_model_add_observation(todhip_ctx*, todhip_model*, const uint8_t* gray, const uint8_t* mask, const void* depth,
+                                  int depth_is_u16, uint32_t H, uint32_t W, const float* K9, const float* R9, const float* T3,
+                                  uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern,
+                                  uint32_t* n_added);
+/* *n: capacity in rows in, rows out. desc: rows x 32, pts_xyz: rows x 3 (object/world frame). */
+int  todhip_model_finish(todhip_ctx*, todhip_model*, uint8_t* desc, float* pts_xyz, uint32_t* n);
+void todhip_model_free(todhip_ctx*, todhip_model*);
+
 /* ---- diagnostics --------------------------------------------------------------------------------- */
 /* Per-RANSAC-round trace of the last todhip_verify call (what GuessGenerator.cpp:202 prints, plus the
  * rand() stream position): `iterations` = iterations_ at loop exit (ransac.h:95-135). */

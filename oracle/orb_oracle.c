@@ -175,9 +175,22 @@ static void disc_umax(int* umax) {
 
 /* kp_xy: (x,y) level-0 pixels; kp_aux: (size, angle_deg, response, octave); desc: 32 bytes each.
  * kp_lvl_xy (optional): integer coordinates inside the level. Returns the number of keypoints. */
+uint32_t orb_detect_masked(const uint8_t* gray, const uint8_t* mask, uint32_t H, uint32_t W, uint32_t stride,
+                           uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, uint32_t cap,
+                           float* kp_xy, float* kp_aux, uint8_t* desc, int32_t* kp_lvl_xy);
+
 uint32_t orb_detect(const uint8_t* gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features, uint32_t n_levels,
                     float scale_factor, const int8_t* pattern, uint32_t cap, float* kp_xy, float* kp_aux, uint8_t* desc,
                     int32_t* kp_lvl_xy) {
+  return orb_detect_masked(gray, 0, H, W, stride, n_features, n_levels, scale_factor, pattern, cap, kp_xy, kp_aux, desc,
+                           kp_lvl_xy);
+}
+
+/* mask (optional, H x W u8, row stride W): a candidate at level pixel (x, y) needs
+ * mask[min(H-1, floor((y + 0.5) * H / h))][min(W-1, floor((x + 0.5) * W / w))] != 0 */
+uint32_t orb_detect_masked(const uint8_t* gray, const uint8_t* mask, uint32_t H, uint32_t W, uint32_t stride,
+                           uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, uint32_t cap,
+                           float* kp_xy, float* kp_aux, uint8_t* desc, int32_t* kp_lvl_xy) {
   int8_t defpat[1024];
   if (!pattern) { orb_default_pattern(defpat); pattern = defpat; }
   int umax[ORB_HALF_PATCH + 2];
@@ -216,6 +229,12 @@ uint32_t orb_detect(const uint8_t* gray, uint32_t H, uint32_t W, uint32_t stride
         for (int dy = -1; dy <= 1 && ismax; ++dy)
           for (int dx = -1; dx <= 1; ++dx)
             if ((dx || dy) && score[(y + dy) * w + (x + dx)] >= s) { ismax = 0; break; }
+        if (ismax && mask) {
+          uint32_t my = (uint32_t)floorf(((float)y + 0.5f) * (float)H / (float)h), mx = (uint32_t)floorf(((float)x + 0.5f) * (float)W / (float)w);
+          if (my > H - 1) my = H - 1;
+          if (mx > W - 1) mx = W - 1;
+          if (!mask[(size_t)my * W + mx]) ismax = 0;
+        }
         if (ismax) { cand[nc].x = (int)x; cand[nc].y = (int)y; cand[nc].score = s; cand[nc].harris = 0.f; ++nc; }
       }
     free(score);

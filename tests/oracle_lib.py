@@ -54,7 +54,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("tod_oracle.cpp", "orb_oracle.c", "tod_oracle.h")]
+    srcs = [os.path.join(_ORACLE_DIR, f) for f in ("tod_oracle.cpp", "orb_oracle.c", "train_oracle.c", "tod_oracle.h")]
     if not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         build()
     L = C.CDLL(_LIB_PATH)
@@ -70,6 +70,8 @@ def lib():
     L.orc_verify.restype = C.c_int
     L.orc_cluster_kabsch.restype = C.c_int
     L.orb_detect.restype = C.c_uint32
+    L.orb_detect_masked.restype = C.c_uint32
+    L.train_observation.restype = C.c_uint32
     _lib = L
     return L
 
@@ -240,7 +242,7 @@ def verify(kp_xy, cloud, row_ptr, matches, matches_xyz, spans_per_obj, min_inlie
 
 
 # ------------------------------------------------------------------------------------------ stage A
-def orb(gray, n_features=1000, n_levels=3, scale_factor=1.2, pattern=None):
+def orb(gray, n_features=1000, n_levels=3, scale_factor=1.2, pattern=None, mask=None):
     """oracle/orb_oracle.c. Returns kp_xy f32[n,2], aux f32[n,4] (size, angle, response, octave), desc u8[n,32],
     lvl_xy i32[n,2] (integer position inside the level)."""
     g = np.ascontiguousarray(gray, np.uint8)
@@ -251,9 +253,11 @@ def orb(gray, n_features=1000, n_levels=3, scale_factor=1.2, pattern=None):
     desc = np.zeros((cap, 32), np.uint8)
     lvl = np.zeros((cap, 2), np.int32)
     pat = None if pattern is None else np.ascontiguousarray(pattern, np.int8)
-    n = lib().orb_detect(_p(g, C.c_uint8), C.c_uint32(H), C.c_uint32(W), C.c_uint32(W), C.c_uint32(n_features),
-                         C.c_uint32(n_levels), C.c_float(scale_factor), None if pat is None else _p(pat, C.c_int8),
-                         C.c_uint32(cap), _p(kp, C.c_float), _p(aux, C.c_float), _p(desc, C.c_uint8), _p(lvl, C.c_int32))
+    mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    n = lib().orb_detect_masked(_p(g, C.c_uint8), None if mk is None else _p(mk, C.c_uint8), C.c_uint32(H), C.c_uint32(W),
+                                C.c_uint32(W), C.c_uint32(n_features), C.c_uint32(n_levels), C.c_float(scale_factor),
+                                None if pat is None else _p(pat, C.c_int8), C.c_uint32(cap), _p(kp, C.c_float),
+                                _p(aux, C.c_float), _p(desc, C.c_uint8), _p(lvl, C.c_int32))
     return kp[:n].copy(), aux[:n].copy(), desc[:n].copy(), lvl[:n].copy()
 
 
@@ -261,3 +265,29 @@ def orb_default_pattern():
     pat = np.zeros((256, 4), np.int8)
     lib().orb_default_pattern(_p(pat, C.c_int8))
     return pat
+
+
+# ------------------------------------------------------------------------------------------ N2: training
+def train_observation(kp_xy, desc, mask, depth_m, K, R, T):
+    kp = np.ascontiguousarray(kp_xy, np.float32)
+    d = np.ascontiguousarray(desc, np.uint8)
+    mk = np.ascontiguousarray(mask, np.uint8)
+    dm = np.ascontiguousarray(depth_m, np.float32)
+    H, W = mk.shape
+    K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+    R9 = np.ascontiguousarray(R, np.float32).reshape(9)
+    T3 = np.ascontiguousarray(T, np.float32).reshape(3)
+    od = np.zeros((max(len(kp), 1), 32), np.uint8)
+    op = np.zeros((max(len(kp), 1), 3), np.float32)
+    src = np.zeros(max(len(kp), 1), np.uint32)
+    n = lib().train_observation(_p(kp, C.c_float), _p(d, C.c_uint8), C.c_uint32(len(kp)), _p(mk, C.c_uint8),
+                                _p(dm, C.c_float), C.c_uint32(H), C.c_uint32(W), _p(K9, C.c_float), _p(R9, C.c_float),
+                                _p(T3, C.c_float), _p(od, C.c_uint8), _p(op, C.c_float), _p(src, C.c_uint32))
+    return od[:n].copy(), op[:n].copy(), src[:n].copy()
+
+
+def train_erode4(mask):
+    mk = np.ascontiguousarray(mask, np.uint8)
+    out = np.zeros_like(mk)
+    lib().train_erode4(_p(mk, C.c_uint8), C.c_uint32(mk.shape[0]), C.c_uint32(mk.shape[1]), _p(out, C.c_uint8))
+    return out

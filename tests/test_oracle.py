@@ -146,3 +146,32 @@ def test_verify_recovers_known_pose():
     assert np.abs(poses[0]["R"] - synth.pose_R()).max() < 0.03      # 2 mm noise on a 0.2 m object
     assert np.abs(poses[0]["t"] - synth.POSE_T).max() < 0.01
     assert rounds[0].draws_after > rounds[0].draws_before
+
+
+def test_train_observation_against_numpy():
+    """validateKeyPoints + depthTo3dSparse + cameraToWorld (training.cpp:57-195, Trainer.cpp:166-178) on a hand case,
+    checked with independent numpy arithmetic. PARITY UNPINNED w.r.t. the reference (no fixture for this path)."""
+    H, W = 48, 64
+    mask = np.zeros((H, W), np.uint8)
+    mask[8:40, 10:50] = 255
+    depth = np.full((H, W), 0.8, np.float32)
+    depth[20, 30] = np.nan
+    K = np.array([[100, 0, 31.5], [0, 100, 23.5], [0, 0, 1]], np.float32)
+    R = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], np.float32)
+    T = np.array([0.1, 0.2, 0.3], np.float32)
+    kp = np.array([[30.2, 24.6],     # inside the eroded mask, valid depth -> kept
+                   [30.0, 20.0],     # depth NaN at the pixel -> rescued by a neighbour within +-2 or dropped
+                   [2.0, 2.0],       # outside the mask -> dropped
+                   [11.0, 24.0],     # inside the mask but within 4 px of its border -> eroded away
+                   [45.0, 12.0]], np.float32)
+    desc = np.arange(5 * 32, dtype=np.uint8).reshape(5, 32)
+    od, op, src = O.train_observation(kp, desc, mask, depth, K, R, T)
+    assert src[0] == 0 and 2 not in src and 3 not in src
+    assert np.array_equal(od, desc[src])
+    er = O.train_erode4(mask)
+    assert er[12, 14] == 255 and er[11, 14] == 0 and er[12, 13] == 0 and er.sum() // 255 == 24 * 32
+    for row, s in zip(op, src):
+        # the world point maps back through R, T and K to a pixel within the +-2 rescue window of the keypoint
+        cam = R @ row + T
+        u, v = cam[0] / cam[2] * 100 + 31.5, cam[1] / cam[2] * 100 + 23.5
+        assert abs(cam[2] - 0.8) < 1e-5 and abs(u - kp[s, 0]) <= 2.5 and abs(v - kp[s, 1]) <= 2.5

@@ -1,0 +1,63 @@
+"""GPU parity of the training path (Trainer.cpp:121-187, training.cpp:57-195) against the CPU
+restatement (oracle/train_oracle.c + the masked ORB restatement). PARITY UNPINNED w.r.t. the reference (no fixture,
+third-party cv::ORB / erode / rescaleDepth / depthTo3dSparse)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from tod_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _observation(view, u16):
+    img = synth.make_image(40 + view)
+    rng = np.random.Generator(np.random.PCG64(900 + view))
+    mask = np.zeros((480, 640), np.uint8)
+    mask[60 + 10 * view:420, 120:560 - 15 * view] = 255
+    mask[200:230, 300:340] = 0                                  # a hole: exercises the +-2 pixel rescue and the erosion
+    z = (0.7 + 0.2 * rng.random((480, 640))).astype(np.float32)
+    z[rng.random((480, 640)) < 0.05] = np.nan
+    if u16:
+        d16 = np.where(np.isnan(z), 0, np.rint(z * 1000)).astype(np.uint16)
+        z = np.where(d16 == 0, np.nan, d16.astype(np.float32) * np.float32(0.001)).astype(np.float32)
+        depth = d16
+    else:
+        depth = z
+    a = 0.3 * view
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]], np.float32)
+    T = np.array([0.1 * view, -0.05, 0.6], np.float32)
+    K = np.array([[525, 0, 319.5], [0, 525, 239.5], [0, 0, 1]], np.float32)
+    return img, mask, depth, z, K, R, T
+
+
+@pytest.mark.parametrize("u16", [False, True])
+def test_model_from_three_observations(u16):
+    ctx = capi.Context(0)
+    model = capi.Model(ctx, 5000)
+    want_d, want_p = [], []
+    for view in range(3):
+        img, mask, depth, z, K, R, T = _observation(view, u16)
+        n = model.add_observation(img, mask, depth, K, R, T)                    # cv::ORB defaults: 500, 8 levels, 1.2
+        kp, aux, desc, _ = O.orb(img, 500, 8, 1.2, mask=mask)
+        od, op, src = O.train_observation(kp, desc, mask, z, K, R, T)
+        assert n == len(od) and 300 < n <= 500
+        want_d.append(od); want_p.append(op)
+    desc, pts = model.finish()
+    assert np.array_equal(desc, np.concatenate(want_d)) and np.array_equal(pts, np.concatenate(want_p))   # mergePoints order
+    model.close()
+    # the trained rows are a valid DB for the matcher: a view of the object matches its own model
+    off = np.array([0, len(desc)], np.uint32)
+    ctx.db_load(desc, pts, off)
+    row_ptr, m, xyz = ctx.match(want_d[1][:50], 1, 35)
+    assert (np.diff(row_ptr.astype(np.int64)) == 1).all() and (m["distance"] == 0).all()
+    ctx.close()
+
+
+def test_masked_orb_only_returns_keypoints_inside_the_mask():
+    ctx = capi.Context(0)
+    img, mask, depth, z, K, R, T = _observation(0, False)
+    model = capi.Model(ctx, 1000)
+    n = model.add_observation(img, np.zeros_like(mask), depth, K, R, T)
+    assert n == 0
+    model.close(); ctx.close()

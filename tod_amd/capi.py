@@ -57,6 +57,7 @@ EXPORTS = [
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
     "todhip_orb_device", "todhip_verify_device_depth",
+    "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
 ]
 
 _lib = None
@@ -84,6 +85,7 @@ def lib():
         L.todhip_stream.restype = C.c_void_p
         L.todhip_destroy.restype = None
         L.todhip_rng_seed.restype = None
+        L.todhip_model_free.restype = None
         _lib = L
     return _lib
 
@@ -337,6 +339,45 @@ def _orb_device(self, d_gray, H, W, stride, n_features, n_levels, scale_factor, 
 
 
 Context.orb_device = _orb_device
+
+
+class Model:
+    """One object's model being trained (todhip_model): add observations, then finish() -> (desc, pts)."""
+
+    def __init__(self, ctx, capacity_rows=100000):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        self._cap = capacity_rows
+        _check(lib().todhip_model_begin(ctx._h, C.c_uint32(capacity_rows), C.byref(self._h)), "todhip_model_begin")
+
+    def add_observation(self, gray, mask, depth, K, R, T, n_features=500, n_levels=8, scale_factor=1.2):
+        g = np.ascontiguousarray(gray, np.uint8)
+        mk = np.ascontiguousarray(mask, np.uint8)
+        u16 = depth.dtype == np.uint16
+        d = np.ascontiguousarray(depth, np.uint16 if u16 else np.float32)
+        H, W = g.shape
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        R9 = np.ascontiguousarray(R, np.float32).reshape(9)
+        T3 = np.ascontiguousarray(T, np.float32).reshape(3)
+        n = C.c_uint32(0)
+        rc = lib().todhip_model_add_observation(self._ctx._h, self._h, _np_ptr(g), _np_ptr(mk), _np_ptr(d),
+                                                C.c_int(1 if u16 else 0), C.c_uint32(H), C.c_uint32(W), _np_ptr(K9),
+                                                _np_ptr(R9), _np_ptr(T3), C.c_uint32(n_features), C.c_uint32(n_levels),
+                                                C.c_float(scale_factor), None, C.byref(n))
+        _check(rc, "todhip_model_add_observation")
+        return n.value
+
+    def finish(self):
+        desc = np.zeros((self._cap, 32), np.uint8)
+        pts = np.zeros((self._cap, 3), np.float32)
+        n = C.c_uint32(self._cap)
+        _check(lib().todhip_model_finish(self._ctx._h, self._h, _np_ptr(desc), _np_ptr(pts), C.byref(n)), "todhip_model_finish")
+        return desc[:n.value].copy(), pts[:n.value].copy()
+
+    def close(self):
+        if self._h:
+            lib().todhip_model_free(self._ctx._h, self._h)
+            self._h = C.c_void_p()
 
 
 def rng_new(seed=1):

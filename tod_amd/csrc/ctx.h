@@ -109,3 +109,6 @@ int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_s
 // verify.hip / orb.hip
 void tod_verify_ws_free(todhip_ctx* ctx);
 void tod_orb_ws_free(todhip_ctx* ctx);
+int tod_orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, uint32_t H, uint32_t W, uint32_t stride,
+                   uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, float* d_kp_xy,
+                   float* d_kp_aux, uint8_t* d_desc, uint32_t cap, uint32_t* n_out);

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restri
 
 // 3x3 strict non-maximum suppression + compaction (order is fixed later by the ranking)
 __global__ __launch_bounds__(256) void nms_kernel(const int* __restrict__ score, uint32_t h, uint32_t w, Cand* cand,
-                                                  uint32_t cap, uint32_t* counter, uint32_t* hist) {
+                                                  uint32_t cap, uint32_t* counter, uint32_t* hist,
+                                                  const uint8_t* __restrict__ mask, uint32_t H0, uint32_t W0) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
   if (x < (uint32_t)kEdge || x >= w - kEdge || y < (uint32_t)kEdge || y >= h - kEdge) return;
@@ -131,6 +132,11 @@ __global__ __launch_bounds__(256) void nms_kernel(const int* __restrict__ score,
   for (int dy = -1; dy <= 1; ++dy)
     for (int dx = -1; dx <= 1; ++dx)
       if ((dx || dy) && score[(size_t)(y + dy) * w + (x + dx)] >= s) return;
+  if (mask) {   // level-0 mask sampled at the nearest pixel (the training cell passes obs.mask to the detector, Trainer.cpp:144-150)
+    uint32_t my = (uint32_t)floorf(((float)y + 0.5f) * (float)H0 / (float)h), mx = (uint32_t)floorf(((float)x + 0.5f) * (float)W0 / (float)w);
+    my = min(my, H0 - 1u); mx = min(mx, W0 - 1u);
+    if (!mask[(size_t)my * W0 + mx]) return;
+  }
   const uint32_t i = atomicAdd(counter, 1u);
   if (i < cap) { Cand c; c.x = (int)x; c.y = (int)y; c.score = s; c.harris = 0.f; cand[i] = c; atomicAdd(&hist[s & 255], 1u); }
 }
@@ -317,7 +323,7 @@ struct OrbWs {
   // the per-frame launch sequence is static for a given geometry and output buffers: captured once, replayed
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
-  struct Key { uint32_t H, W, n_features, n_levels, cap; float sf; const void *kp, *aux, *desc, *img0; } key = {};
+  struct Key { uint32_t H, W, n_features, n_levels, cap; float sf; const void *kp, *aux, *desc, *img0, *mask; } key = {};
 };
 
 OrbWs* ows_of(todhip_ctx* ctx) {
@@ -339,9 +345,9 @@ void features_per_level(uint32_t n_features, uint32_t n_levels, float scale_fact
 }
 
 // d_gray: H x W u8 on the device (row stride `stride`). Results stay on the device; *n_out is read back.
-int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
-               uint32_t n_levels, float scale_factor, const int8_t* pattern, float* d_kp_xy, float* d_kp_aux,
-               uint8_t* d_desc, uint32_t cap, uint32_t* n_out) {
+int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, uint32_t H, uint32_t W, uint32_t stride,
+               uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, float* d_kp_xy,
+               float* d_kp_aux, uint8_t* d_desc, uint32_t cap, uint32_t* n_out) {
   if (n_levels == 0 || n_levels > (uint32_t)kMaxLevels || scale_factor <= 1.f || H < 8 || W < 8 || n_features == 0)
     return TODHIP_EINVAL;
   OrbWs* ws = ows_of(ctx);
@@ -370,7 +376,7 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
   TOD_HIP(hipMemsetAsync(d_small, 0, 512 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, st, d_gray, stride,
                      ws->img[0].as<uint8_t>(), H, W);
-  OrbWs::Key key = {H, W, n_features, n_levels, cap, scale_factor, d_kp_xy, d_kp_aux, d_desc, ws->img[0].p};
+  OrbWs::Key key = {H, W, n_features, n_levels, cap, scale_factor, d_kp_xy, d_kp_aux, d_desc, ws->img[0].p, d_mask};
   const bool reuse = ws->graph_exec && std::memcmp(&key, &ws->key, sizeof(key)) == 0;
   if (!reuse) {
     if (ws->graph_exec) { (void)hipGraphExecDestroy(ws->graph_exec); ws->graph_exec = nullptr; }
@@ -401,7 +407,7 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
     if (hipMemsetAsync(d_small + W_HIST, 0, 256 * sizeof(uint32_t), st) != hipSuccess) cap_rc = TODHIP_EHIP;
     hipLaunchKernelGGL(fast_score_kernel, grid2, dim3(256), 0, st, img, h, w, ws->score.as<int>());
     hipLaunchKernelGGL(nms_kernel, grid2, dim3(256), 0, st, ws->score.as<int>(), h, w, ws->cand.as<Cand>(), cand_cap, d_small,
-                       d_small + W_HIST);
+                       d_small + W_HIST, d_mask, H, W);
     hipLaunchKernelGGL(fast_threshold_kernel, dim3(1), dim3(64), 0, st, d_small, cand_cap, 2u * want);
     hipLaunchKernelGGL(split_kernel, dim3((cand_cap + 255u) / 256u), dim3(256), 0, st, ws->cand.as<Cand>(), d_small, 2u * want,
                        ws->sel1.as<Cand>(), ws->eq.as<Cand>());
@@ -438,6 +444,14 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, uint32_t H, uint32_t W, u
 
 }  // namespace
 
+// used by train.hip: ORB with a level-0 mask on device-resident inputs
+int tod_orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, uint32_t H, uint32_t W, uint32_t stride,
+                   uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, float* d_kp_xy,
+                   float* d_kp_aux, uint8_t* d_desc, uint32_t cap, uint32_t* n_out) {
+  return orb_device(ctx, d_gray, d_mask, H, W, stride, n_features, n_levels, scale_factor, pattern, d_kp_xy, d_kp_aux, d_desc,
+                    cap, n_out);
+}
+
 void tod_orb_ws_free(todhip_ctx* ctx) {
   if (!ctx->orb_ws) return;
   OrbWs* ws = reinterpret_cast<OrbWs*>(ctx->orb_ws);
@@ -460,7 +474,7 @@ int todhip_orb_device(todhip_ctx* ctx, const void* d_gray, uint32_t H, uint32_t 
   TOD_HIP(hipSetDevice(ctx->device));
   const uint32_t cap = *n_out;
   *n_out = 0;
-  return orb_device(ctx, reinterpret_cast<const uint8_t*>(d_gray), H, W, stride, n_features, n_levels, scale_factor, pattern,
+  return orb_device(ctx, reinterpret_cast<const uint8_t*>(d_gray), nullptr, H, W, stride, n_features, n_levels, scale_factor, pattern,
                     reinterpret_cast<float*>(d_kp_xy), reinterpret_cast<float*>(d_kp_aux), reinterpret_cast<uint8_t*>(d_desc),
                     cap, n_out);
 }
@@ -478,7 +492,7 @@ int todhip_orb(todhip_ctx* ctx, const uint8_t* gray, uint32_t H, uint32_t W, uin
   TOD_HIP(ws->kp_xy.reserve((size_t)cap * 8)); TOD_HIP(ws->kp_aux.reserve((size_t)cap * 16)); TOD_HIP(ws->desc.reserve((size_t)cap * 32));
   TOD_HIP(hipMemcpyAsync(ws->in_img.p, gray, (size_t)H * stride, hipMemcpyHostToDevice, ctx->stream));
   uint32_t n = 0;
-  const int rc = orb_device(ctx, ws->in_img.as<uint8_t>(), H, W, stride, n_features, n_levels, scale_factor, pattern,
+  const int rc = orb_device(ctx, ws->in_img.as<uint8_t>(), nullptr, H, W, stride, n_features, n_levels, scale_factor, pattern,
                             ws->kp_xy.as<float>(), ws->kp_aux.as<float>(), ws->desc.as<uint8_t>(), cap, &n);
   if (rc != TODHIP_OK) return rc;
   if (n) {
