@@ -23,6 +23,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The HIP runtime maps a process's streams onto 4 hardware queues unless told otherwise, so at most ~4 of the
+# per-frame ORB/verifier streams would overlap (tools/stream_concurrency.py: 4 by default, 8 with 16 queues).
+# Must be in the environment before the runtime is loaded (i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) issue at 16 lanes/clk/SIMD on gfx950: 4 cycles per
 # wave64 instruction, measured with tools/valu_peak.hip (profiles/r01_valu_peak_microbench.txt: 38-40 T lane-op/s).
@@ -216,7 +221,7 @@ def main():
             mine = torch.stack([d_q[f] for f in fidx])                              # [B, Q, 32]
             q_all = alloc((world, B, nq, 32), "uint8")
             all_gather(q_all, mine)
-            ctx.match_shard_device(q_all.data_ptr(), world * B * nq, k, d_keys.data_ptr())
+            ctx.match_shard_device(q_all.data_ptr(), world * B * nq, k, args.radius, d_keys.data_ptr())
             keys_all = alloc((world, world, B, nq, k), "int64")                     # [shard][rank][b][Q][k]
             all_gather(keys_all, d_keys)
             for b in range(B):

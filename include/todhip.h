@@ -97,8 +97,10 @@ int todhip_match_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t
                         void* d_counts, void* d_matches, void* d_matches_xyz);
 
 /* Sharded form, step 1: this shard's top-k per query as keys (distance << 32 | global_row), ascending,
- * UINT64_MAX padded; d_keys[nq*k]. The ranks exchange these with one RCCL all-gather. */
-int todhip_match_shard_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t k, void* d_keys);
+ * UINT64_MAX padded; d_keys[nq*k]. The ranks exchange these with one RCCL all-gather. `radius` is the radius of
+ * step 2: rows farther away never survive the truncation of DescriptorMatcher.cpp:212-220, so the search is
+ * allowed to leave them out of the keys (it is not obliged to); pass >= 256 to get the plain top-k. */
+int todhip_match_shard_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t k, uint32_t radius, void* d_keys);
 /* Sharded form, step 2: merge n_shards key sets (layout [shard][nq][k]) with the total order
  * (distance asc, global row asc), apply the radius cut, resolve (imgIdx, trainIdx), gather 3D. */
 int todhip_merge_shards_device(todhip_ctx*, const void* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,

@@ -118,7 +118,7 @@ def _shard_merge(desc, pts, off, q, k, radius, n_shards):
     for s in range(n_shards):
         c = capi.Context(0)
         c.db_load(desc, pts, off, shard_rank=s, shard_count=n_shards)
-        c.match_shard_device(d_q.data_ptr(), nq, k, keys_all[s].data_ptr())
+        c.match_shard_device(d_q.data_ptr(), nq, k, radius, keys_all[s].data_ptr())
         c.synchronize()
         ctxs.append(c)
     counts = torch.empty(nq, dtype=torch.int32, device="cuda")

@@ -263,7 +263,7 @@ def test_two_rank_step_in_process(ctx):
     keys = []
     for r in range(world):
         kk = torch.empty((world * nq, k), dtype=torch.int64, device="cuda")
-        ctxs[r].match_shard_device(q_all.data_ptr(), world * nq, k, kk.data_ptr())
+        ctxs[r].match_shard_device(q_all.data_ptr(), world * nq, k, radius, kk.data_ptr())
         ctxs[r].synchronize()
         keys.append(kk.reshape(world, nq, k))
     keys_all = torch.stack(keys)                                        # [shard][frame][Q][k]

@@ -184,8 +184,8 @@ class Context:
                                        C.c_void_p(d_counts), C.c_void_p(d_matches), C.c_void_p(d_xyz))
         _check(rc, "todhip_match_device")
 
-    def match_shard_device(self, d_q, nq, k, d_keys):
-        rc = lib().todhip_match_shard_device(self._h, C.c_void_p(d_q), C.c_uint32(nq), C.c_uint32(k),
+    def match_shard_device(self, d_q, nq, k, radius, d_keys):
+        rc = lib().todhip_match_shard_device(self._h, C.c_void_p(d_q), C.c_uint32(nq), C.c_uint32(k), C.c_uint32(radius),
                                              C.c_void_p(d_keys))
         _check(rc, "todhip_match_shard_device")
 

@@ -170,10 +170,11 @@ int todhip_db_info(const todhip_ctx* ctx, uint64_t* total_rows, uint64_t* shard_
   return TODHIP_OK;
 }
 
-int todhip_match_shard_device(todhip_ctx* ctx, const void* d_q_desc, uint32_t nq, uint32_t k, void* d_keys) {
-  if (!ctx || !d_q_desc || !d_keys || k == 0 || k > 8) return TODHIP_EINVAL;
+int todhip_match_shard_device(todhip_ctx* ctx, const void* d_q_desc, uint32_t nq, uint32_t k, uint32_t radius,
+                              void* d_keys) {
+  if (!ctx || !d_q_desc || !d_keys || k == 0 || k > 8 || radius == 0) return TODHIP_EINVAL;
   if (ctx->total_rows == 0) return TODHIP_ENODB;
-  return tod_match_shard_keys(ctx, d_q_desc, nq, k, reinterpret_cast<uint64_t*>(d_keys));
+  return tod_match_shard_keys(ctx, d_q_desc, nq, k, radius, reinterpret_cast<uint64_t*>(d_keys));
 }
 
 int todhip_merge_shards_device(todhip_ctx* ctx, const void* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
@@ -196,7 +197,7 @@ int todhip_match_device(todhip_ctx* ctx, const void* d_q_desc, uint32_t nq, uint
   // single device: the stage-1 merge lists go straight into the finalize kernel (lists == "shards")
   TOD_HIP(ctx->m_keys.reserve(tod_match_lists_bytes(nq, k)));
   uint32_t n_lists = 0;
-  int rc = tod_match_lists(ctx, d_q_desc, nq, k, ctx->m_keys.as<uint64_t>(), &n_lists);
+  int rc = tod_match_lists(ctx, d_q_desc, nq, k, radius, ctx->m_keys.as<uint64_t>(), &n_lists);
   if (rc != TODHIP_OK) return rc;
   rc = tod_match_finalize(ctx, ctx->m_keys.as<uint64_t>(), n_lists, nq, k, radius,
                           reinterpret_cast<uint32_t*>(d_counts), reinterpret_cast<todhip_dmatch*>(d_matches),

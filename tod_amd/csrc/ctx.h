@@ -101,9 +101,10 @@ struct todhip_ctx {
 int tod_timing_begin(todhip_ctx* ctx, int* slot);
 int tod_timing_end(todhip_ctx* ctx, int slot);
 int tod_timing_drain(todhip_ctx* ctx, uint64_t keep);
-int tod_match_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_lists, uint32_t* n_lists);
+int tod_match_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint32_t radius, uint64_t* d_lists,
+                    uint32_t* n_lists);
 size_t tod_match_lists_bytes(uint32_t nq, uint32_t k);
-int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_keys);
+int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint32_t radius, uint64_t* d_keys);
 int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
                        uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz);
 // verify.hip / orb.hip

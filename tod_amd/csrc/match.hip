@@ -11,6 +11,13 @@
 //                          no LDS traffic and no cross-lane work in the inner loop. Each lane keeps
 //                          its k best (distance, row) keys in registers; four rows share one
 //                          min3/min/compare so the top-k test costs 0.75 VALU op per pair.
+//                          Partial-distance elimination: the distance over the first 128 bits is a lower
+//                          bound of the full one, so when it already reaches the running limit (k-th best so
+//                          far, a bound published by another tile, or radius + 1 -- rows beyond the radius
+//                          never survive DescriptorMatcher.cpp:212-220) for all 4 rows x 64 queries of a
+//                          group, the second half of those rows is never touched. Exact for any data; how
+//                          often it fires depends on the data (always, but for ~1e-4 of the groups, on
+//                          descriptors with independent bits and radius 35).
 // K4m merge_tiles_kernel   per query: merge the per-tile lists into k global keys.
 // K4f finalize_kernel      per query: merge shard lists, radius cut, object lookup, 3D gather.
 #include <cstdlib>
@@ -64,12 +71,12 @@ __device__ __forceinline__ void wait_rows(RowGroup& g) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(g.lo), "+s"(g.hi));
 }
 
-template <int HALF>
-__device__ __forceinline__ uint32_t hamming256(const uint32_t (&q)[kWords], const u32x16& rows) {
-  uint32_t d = 0;
+// bits [32 W0, 32 W0 + 128) of row HALF of a 2-row SGPR block, accumulated onto acc
+template <int HALF, int W0>
+__device__ __forceinline__ uint32_t hamming128(const uint32_t (&q)[kWords], const u32x16& rows, uint32_t acc) {
 #pragma unroll
-  for (int w = 0; w < kWords; ++w) d = bcnt_acc(q[w] ^ rows[HALF * kWords + w], d);
-  return d;
+  for (int w = W0; w < W0 + 4; ++w) acc = bcnt_acc(q[w] ^ rows[HALF * kWords + w], acc);
+  return acc;
 }
 
 __device__ __forceinline__ uint32_t hamming256_mem(const uint32_t (&q)[kWords], const uint32_t* row) {
@@ -85,11 +92,17 @@ __device__ __forceinline__ uint32_t hamming256_mem(const uint32_t (&q)[kWords], 
 template <int K>
 __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], const RowGroup& g, uint32_t r,
                                               uint32_t (&best)[K], uint32_t& worst_d, uint32_t& limit, uint32_t foreign) {
-  uint32_t d0 = hamming256<0>(qd, g.lo);
-  uint32_t d1 = hamming256<1>(qd, g.lo);
-  uint32_t d2 = hamming256<0>(qd, g.hi);
-  uint32_t d3 = hamming256<1>(qd, g.hi);
+  uint32_t d0 = hamming128<0, 0>(qd, g.lo, 0u);
+  uint32_t d1 = hamming128<1, 0>(qd, g.lo, 0u);
+  uint32_t d2 = hamming128<0, 0>(qd, g.hi, 0u);
+  uint32_t d3 = hamming128<1, 0>(qd, g.hi, 0u);
   uint32_t dmin = min(min(d0, d1), min(d2, d3));
+  if (__builtin_amdgcn_ballot_w64(dmin < limit) == 0ull) return;      // lower bounds already out: skip the second half
+  d0 = hamming128<0, 4>(qd, g.lo, d0);
+  d1 = hamming128<1, 4>(qd, g.lo, d1);
+  d2 = hamming128<0, 4>(qd, g.hi, d2);
+  d3 = hamming128<1, 4>(qd, g.hi, d3);
+  dmin = min(min(d0, d1), min(d2, d3));
   if (__builtin_amdgcn_ballot_w64(dmin < limit) != 0ull) {
     // rows are visited in ascending order, so a later row never displaces an equal distance:
     // "key < best[K-1]" is exactly "d < worst_d" and insertion order inside the group is free.
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
                                                              const uint32_t* __restrict__ q, uint32_t n_rows,
                                                              uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
                                                              uint32_t n_tiles, uint32_t n_qw,
-                                                             uint32_t blocks_per_xcd,
+                                                             uint32_t blocks_per_xcd, uint32_t cut,
                                                              uint32_t* __restrict__ part, uint32_t* bound) {
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t vblock = xcd * blocks_per_xcd + slot;                 // XCD-contiguous virtual block id
@@ -141,7 +154,9 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
   // ping-pong SGPR groups: the load of group g+1 is in flight while group g is consumed
   const uint32_t n_groups = n_local / kGroupRows;
   uint32_t r = 0;
-  uint32_t foreign = 0xFFFFFFFFu, limit = worst_d;         // foreign = 1 + smallest published k-th best distance
+  // foreign = min(1 + smallest published k-th best distance, cut); cut = radius + 1: a row at distance > radius is
+  // dropped by the radius truncation whatever its rank, so the search may drop it as well
+  uint32_t foreign = cut, limit = min(worst_d, foreign);
   uint32_t* my_bound = bound + (qi < nq ? qi : nq - 1);
   if (n_groups > 0) {
     constexpr uint32_t kStride = kGroupRows * kWords;
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
         // publish this tile's bound (only once its list is full), pick up the smallest bound published so far
         uint32_t seen = __hip_atomic_load(my_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (worst_d < seen) { atomicMin(my_bound, worst_d); seen = worst_d; }   // publish only a real improvement
-        foreign = seen == 0xFFFFFFFFu ? seen : seen + 1u;
+        foreign = seen == 0xFFFFFFFFu ? cut : min(cut, seen + 1u);
         limit = min(worst_d, foreign);
       }
     }
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
   }
   for (; r < n_local; ++r) {
     uint32_t d = hamming256_mem(qd, base + (size_t)r * kWords);
-    topk_insert<K>(best, (d << kLocalBits) | r);
+    if (d < cut) topk_insert<K>(best, (d << kLocalBits) | r);
   }
   if (qi < nq) {
 #pragma unroll
@@ -305,7 +320,8 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __rest
 }
 
 template <int K>
-int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint64_t* d_lists, uint32_t* n_lists) {
+int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radius, uint64_t* d_lists, uint32_t* n_lists) {
+  const uint32_t cut = radius >= 256u ? 0xFFFFFFFFu : radius + 1u;   // distances are <= 256: no cut beyond that
   const uint32_t n_rows = (uint32_t)ctx->shard_rows;
   const uint32_t n_qw = (nq + 63u) / 64u;
   const uint32_t nq_pad = n_qw * 64u;
@@ -330,7 +346,7 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint64_t* d_l
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(hamming_topk_tiles<K>, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw,
-                     blocks_per_xcd, ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>());
+                     blocks_per_xcd, cut, ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>());
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
                      ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
@@ -369,25 +385,26 @@ int tod_timing_end(todhip_ctx* ctx, int slot) {
 }
 
 // Per-query candidate lists of this shard: d_lists[n_lists][nq][k] (each ascending). n_lists <= kMergeGroups.
-int tod_match_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_lists, uint32_t* n_lists) {
+int tod_match_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint32_t radius, uint64_t* d_lists,
+                    uint32_t* n_lists) {
   if (ctx->desc_bytes != 32) return TODHIP_EINVAL;
   const uint32_t* q = reinterpret_cast<const uint32_t*>(d_q);
   switch (k) {
-    case 1: return launch_topk<1>(ctx, q, nq, d_lists, n_lists);
-    case 2: return launch_topk<2>(ctx, q, nq, d_lists, n_lists);
-    case 3: return launch_topk<3>(ctx, q, nq, d_lists, n_lists);
-    case 4: return launch_topk<4>(ctx, q, nq, d_lists, n_lists);
-    case 5: return launch_topk<5>(ctx, q, nq, d_lists, n_lists);
-    case 6: return launch_topk<6>(ctx, q, nq, d_lists, n_lists);
-    case 7: return launch_topk<7>(ctx, q, nq, d_lists, n_lists);
-    case 8: return launch_topk<8>(ctx, q, nq, d_lists, n_lists);
+    case 1: return launch_topk<1>(ctx, q, nq, radius, d_lists, n_lists);
+    case 2: return launch_topk<2>(ctx, q, nq, radius, d_lists, n_lists);
+    case 3: return launch_topk<3>(ctx, q, nq, radius, d_lists, n_lists);
+    case 4: return launch_topk<4>(ctx, q, nq, radius, d_lists, n_lists);
+    case 5: return launch_topk<5>(ctx, q, nq, radius, d_lists, n_lists);
+    case 6: return launch_topk<6>(ctx, q, nq, radius, d_lists, n_lists);
+    case 7: return launch_topk<7>(ctx, q, nq, radius, d_lists, n_lists);
+    case 8: return launch_topk<8>(ctx, q, nq, radius, d_lists, n_lists);
     default: return TODHIP_EINVAL;
   }
 }
 
 size_t tod_match_lists_bytes(uint32_t nq, uint32_t k) { return (size_t)kMergeGroups * nq * k * sizeof(uint64_t); }
 
-int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_keys) {
+int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint32_t radius, uint64_t* d_keys) {
   if (nq == 0) return TODHIP_OK;
   if (ctx->shard_rows == 0) {   // an empty shard contributes only padding keys
     TOD_HIP(hipMemsetAsync(d_keys, 0xFF, (size_t)nq * k * sizeof(uint64_t), ctx->stream));
@@ -395,7 +412,7 @@ int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t
   }
   TOD_HIP(ctx->m_keys.reserve(tod_match_lists_bytes(nq, k)));
   uint32_t n_lists = 0;
-  int rc = tod_match_lists(ctx, d_q, nq, k, ctx->m_keys.as<uint64_t>(), &n_lists);
+  int rc = tod_match_lists(ctx, d_q, nq, k, radius, ctx->m_keys.as<uint64_t>(), &n_lists);
   if (rc != TODHIP_OK) return rc;
   hipLaunchKernelGGL(select_keys_kernel, dim3((nq + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
                      ctx->m_keys.as<uint64_t>(), n_lists, nq, k, d_keys);

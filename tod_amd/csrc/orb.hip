@@ -316,11 +316,27 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs A) {
   }
 }
 
+// the graph writes keypoints into workspace buffers; this kernel hands the first min(total, cap) of them to the caller
+__global__ __launch_bounds__(256) void copy_out_kernel(const uint32_t* __restrict__ level_counts, uint32_t n_levels, uint32_t cap,
+                                                       const float* __restrict__ s_xy, const float* __restrict__ s_aux,
+                                                       const uint32_t* __restrict__ s_desc, float* __restrict__ d_xy,
+                                                       float* __restrict__ d_aux, uint32_t* __restrict__ d_desc) {
+  uint32_t total = 0;
+  for (uint32_t l = 0; l < n_levels; ++l) total += level_counts[l];
+  const uint32_t n = min(total, cap);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;      // one dword each: 2 + 4 + 8 dwords per keypoint
+  if (i < 2u * n) d_xy[i] = s_xy[i];
+  if (i < 4u * n) d_aux[i] = s_aux[i];
+  if (i < 8u * n) d_desc[i] = s_desc[i];
+}
+
 struct OrbWs {
-  DevBuf img[2], blur, tmp, score, cand, eq, sel1, sel2, small, pattern, in_img, kp_xy, kp_aux, desc;
+  DevBuf img[2], blur, tmp, score, cand, eq, sel1, sel2, small, pattern, in_img, kp_xy, kp_aux, desc, o_xy, o_aux, o_desc, maskbuf;
   HostBuf h_out;
   bool pattern_is_default = false;
-  // the per-frame launch sequence is static for a given geometry and output buffers: captured once, replayed
+  // the per-frame launch sequence is static for a given geometry: captured once per context, replayed. It reads
+  // and writes workspace buffers only (image and mask are copied in, keypoints copied out), so the caller's
+  // pointers may change from call to call without a re-capture.
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   struct Key { uint32_t H, W, n_features, n_levels, cap; float sf; const void *kp, *aux, *desc, *img0, *mask; } key = {};
@@ -350,6 +366,7 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, ui
                float* d_kp_aux, uint8_t* d_desc, uint32_t cap, uint32_t* n_out) {
   if (n_levels == 0 || n_levels > (uint32_t)kMaxLevels || scale_factor <= 1.f || H < 8 || W < 8 || n_features == 0)
     return TODHIP_EINVAL;
+  if (cap == 0) return TODHIP_ECAPACITY;
   OrbWs* ws = ows_of(ctx);
   hipStream_t st = ctx->stream;
   const size_t px = (size_t)H * W;
@@ -363,6 +380,10 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, ui
   TOD_HIP(ws->small.reserve(1024 * sizeof(uint32_t)));
   TOD_HIP(ws->pattern.reserve(1024));
   TOD_HIP(ws->h_out.reserve(64));
+  TOD_HIP(ws->o_xy.reserve((size_t)cap * 8)); TOD_HIP(ws->o_aux.reserve((size_t)cap * 16)); TOD_HIP(ws->o_desc.reserve((size_t)cap * 32));
+  if (d_mask) TOD_HIP(ws->maskbuf.reserve(px));
+  float* const u_kp_xy = d_kp_xy; float* const u_kp_aux = d_kp_aux; uint8_t* const u_desc = d_desc;   // the caller's
+  d_kp_xy = ws->o_xy.as<float>(); d_kp_aux = ws->o_aux.as<float>(); d_desc = ws->o_desc.as<uint8_t>();
   int8_t hpat[1024];
   if (pattern) { std::memcpy(hpat, pattern, 1024); ws->pattern_is_default = false; }
   if (pattern || !ws->pattern_is_default) {
@@ -376,13 +397,18 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, ui
   TOD_HIP(hipMemsetAsync(d_small, 0, 512 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, st, d_gray, stride,
                      ws->img[0].as<uint8_t>(), H, W);
+  if (d_mask) {
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, st, d_mask, W, ws->maskbuf.as<uint8_t>(), H, W);
+    d_mask = ws->maskbuf.as<uint8_t>();
+  }
   OrbWs::Key key = {H, W, n_features, n_levels, cap, scale_factor, d_kp_xy, d_kp_aux, d_desc, ws->img[0].p, d_mask};
-  const bool reuse = ws->graph_exec && std::memcmp(&key, &ws->key, sizeof(key)) == 0;
+  static const bool use_graph = getenv("TODHIP_ORB_NO_GRAPH") == nullptr;
+  const bool reuse = use_graph && ws->graph_exec && std::memcmp(&key, &ws->key, sizeof(key)) == 0;
   if (!reuse) {
     if (ws->graph_exec) { (void)hipGraphExecDestroy(ws->graph_exec); ws->graph_exec = nullptr; }
     if (ws->graph) { (void)hipGraphDestroy(ws->graph); ws->graph = nullptr; }
     // thread-local capture: other host threads keep using the runtime while this one records
-    TOD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    if (use_graph) TOD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int cap_rc = TODHIP_OK;
     {
   DescribeArgs D;
@@ -425,14 +451,20 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, ui
     hipLaunchKernelGGL(describe_kernel, dim3((want + 3u) / 4u), dim3(256), 0, st, D);
   }
     }
-    hipGraph_t g = nullptr;
-    const hipError_t ee = hipStreamEndCapture(st, &g);
-    if (ee != hipSuccess || cap_rc != TODHIP_OK || !g) { ctx->last_hip_error = (int)ee; return TODHIP_EHIP; }
-    ws->graph = g;
-    TOD_HIP(hipGraphInstantiate(&ws->graph_exec, ws->graph, nullptr, nullptr, 0));
-    ws->key = key;
+    if (use_graph) {
+      hipGraph_t g = nullptr;
+      const hipError_t ee = hipStreamEndCapture(st, &g);
+      if (ee != hipSuccess || cap_rc != TODHIP_OK || !g) { ctx->last_hip_error = (int)ee; return TODHIP_EHIP; }
+      ws->graph = g;
+      TOD_HIP(hipGraphInstantiate(&ws->graph_exec, ws->graph, nullptr, nullptr, 0));
+      ws->key = key;
+    } else if (cap_rc != TODHIP_OK) {
+      return cap_rc;
+    }
   }
-  TOD_HIP(hipGraphLaunch(ws->graph_exec, st));
+  if (use_graph) TOD_HIP(hipGraphLaunch(ws->graph_exec, st));
+  hipLaunchKernelGGL(copy_out_kernel, dim3((8u * cap + 255u) / 256u), dim3(256), 0, st, d_small + 8, n_levels, cap, d_kp_xy, d_kp_aux,
+                     reinterpret_cast<const uint32_t*>(d_desc), u_kp_xy, u_kp_aux, reinterpret_cast<uint32_t*>(u_desc));
   uint32_t* h_counts = ws->h_out.as<uint32_t>();
   TOD_HIP(hipMemcpyAsync(h_counts, d_small + 8, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   TOD_HIP(hipStreamSynchronize(st));
@@ -456,7 +488,8 @@ void tod_orb_ws_free(todhip_ctx* ctx) {
   if (!ctx->orb_ws) return;
   OrbWs* ws = reinterpret_cast<OrbWs*>(ctx->orb_ws);
   DevBuf* bufs[] = {&ws->img[0], &ws->img[1], &ws->blur, &ws->tmp, &ws->score, &ws->cand, &ws->eq, &ws->sel1, &ws->sel2,
-                    &ws->small, &ws->pattern, &ws->in_img, &ws->kp_xy, &ws->kp_aux, &ws->desc};
+                    &ws->small, &ws->pattern, &ws->in_img, &ws->kp_xy, &ws->kp_aux, &ws->desc, &ws->o_xy, &ws->o_aux, &ws->o_desc,
+                    &ws->maskbuf};
   for (DevBuf* b : bufs) b->release();
   if (ws->graph_exec) (void)hipGraphExecDestroy(ws->graph_exec);
   if (ws->graph) (void)hipGraphDestroy(ws->graph);

@@ -188,6 +188,9 @@ struct GateLds {
   uint16_t *flist, *cur, *nxt, *tmp;           // m each
   uint32_t *C, *deg, *keys;                    // m each
   uint32_t *S, *SOld, *lbase, *lsize, *lcap;   // m + 2 each
+  u64* aprime;                                 // m x MW position-space adjacency of the list being coloured, or nullptr
+  uint16_t* lstack;                            // LDS part of the per-level vertex lists (the rest is in global memory)
+  uint32_t lstack_cap;
 };
 __host__ __device__ inline uint32_t gate_lds_bytes(uint32_t m) {
   const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;      // ma >= m + 2
@@ -199,8 +202,9 @@ __host__ __device__ inline uint32_t gate_small_bytes(uint32_t m) {           // 
 }
 // ext_adjc != nullptr: the m x MW matrix lives in global scratch (graphs beyond one CU's LDS); same code path,
 // the pointers are generic
-__device__ inline GateLds gate_carve(unsigned char* base, uint32_t m, u64* ext_adjc = nullptr) {
+__device__ inline GateLds gate_carve(unsigned char* base, uint32_t m, uint32_t lds_bytes, u64* ext_adjc = nullptr) {
   const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;
+  unsigned char* const base0 = base;
   GateLds L;
   if (ext_adjc) { L.adjc = ext_adjc; } else { L.adjc = reinterpret_cast<u64*>(base); base += 8u * m * MW; }
   L.mask = reinterpret_cast<u64*>(base); base += 8u * MW;
@@ -215,8 +219,27 @@ __device__ inline GateLds gate_carve(unsigned char* base, uint32_t m, u64* ext_a
   L.flist = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
   L.cur = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
   L.nxt = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
-  L.tmp = reinterpret_cast<uint16_t*>(base);
+  L.tmp = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
+  // whatever the launch's LDS allocation has left: colouring scratch first (lists of <= 512 vertices), then the stack
+  uint32_t used = ((uint32_t)(base - base0) + 15u) & ~15u;
+  L.aprime = nullptr;
+  const uint32_t ap_bytes = 8u * m * MW;
+  if (m > 64u && m <= 512u && used + ap_bytes <= lds_bytes) {
+    L.aprime = reinterpret_cast<u64*>(base0 + used);
+    used += (ap_bytes + 15u) & ~15u;
+  }
+  L.lstack = reinterpret_cast<uint16_t*>(base0 + used);
+  L.lstack_cap = lds_bytes > used ? (lds_bytes - used) / 2u : 0u;
   return L;
+}
+
+// per-level vertex lists: entry i lives in LDS while it fits, in the wave's global stack beyond
+struct LevelStack { uint16_t* lds; uint32_t lds_cap; uint16_t* glob; };
+__device__ __forceinline__ uint16_t stk_get(const LevelStack& s, uint32_t i) {
+  return i < s.lds_cap ? s.lds[i] : s.glob[i - s.lds_cap];
+}
+__device__ __forceinline__ void stk_put(const LevelStack& s, uint32_t i, uint16_t v) {
+  if (i < s.lds_cap) s.lds[i] = v; else s.glob[i - s.lds_cap] = v;
 }
 
 __device__ __forceinline__ bool row_test(u64 roww, uint32_t h) {   // roww: lane l holds word l of the row
@@ -224,10 +247,47 @@ __device__ __forceinline__ bool row_test(u64 roww, uint32_t h) {   // roww: lane
   return (wv >> (h & 63u)) & 1ull;
 }
 
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) {    // lane is wave-uniform: v_readlane_b32
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+__device__ __forceinline__ u64 rdlane64(u64 v, uint32_t lane) {
+  return ((u64)rdlane((uint32_t)(v >> 32), lane) << 32) | rdlane((uint32_t)v, lane);
+}
+
+constexpr uint32_t kRegChunks = 8;                         // register paths cover lists of up to 512 vertices
+
 // DegreeSort (maximum_clique.cpp:263-284): (degree inside the list, vertex) ascending, then reversed.
 // deg[] must hold the degree of list[i] at position i. Rank by counting; keys are unique.
-__device__ void rank_sort_desc(uint16_t* list, uint16_t* tmp, const uint32_t* deg, uint32_t r, uint32_t* keys) {
+__device__ __forceinline__ void rank_sort_desc(uint16_t* list, uint16_t* tmp, const uint32_t* deg, uint32_t r, uint32_t* keys) {
   const uint32_t l = lane_id();
+  if (r <= kRegChunks * 64u) {
+    // keys stay in registers (lane l: positions l, l + 64, ...); every key is broadcast once with v_readlane
+    const uint32_t nch = (r + 63u) / 64u;
+    uint32_t kreg[kRegChunks], rank[kRegChunks];
+#pragma unroll
+    for (uint32_t c = 0; c < kRegChunks; ++c) {
+      const uint32_t i = c * 64u + l;
+      kreg[c] = i < r ? ((deg[i] << 16) | list[i]) : 0u;
+      rank[c] = 0u;
+    }
+#pragma unroll
+    for (uint32_t cj = 0; cj < kRegChunks; ++cj) {
+      if (cj < nch) {                                      // wave-uniform
+        const uint32_t cnt = min(64u, r - cj * 64u);
+        for (uint32_t lj = 0; lj < cnt; ++lj) {
+          const uint32_t kj = rdlane(kreg[cj], lj);
+#pragma unroll
+          for (uint32_t c = 0; c < kRegChunks; ++c) rank[c] += (kj > kreg[c]) ? 1u : 0u;
+        }
+      }
+    }
+    __syncthreads();                                       // every lane holds its keys: the list can be overwritten
+#pragma unroll
+    for (uint32_t c = 0; c < kRegChunks; ++c)
+      if (c * 64u + l < r) list[rank[c]] = (uint16_t)(kreg[c] & 0xFFFFu);
+    __syncthreads();
+    return;
+  }
   for (uint32_t i = l; i < r; i += 64u) keys[i] = (deg[i] << 16) | list[i];
   __syncthreads();
   for (uint32_t i0 = 0; i0 < r; i0 += 64u) {
@@ -243,7 +303,7 @@ __device__ void rank_sort_desc(uint16_t* list, uint16_t* tmp, const uint32_t* de
 }
 
 // degrees of the members of list[0..r) inside the list, into L.deg[0..r)
-__device__ void degrees_in_list(const GateLds& L, const uint16_t* list, uint32_t r, uint32_t MW) {
+__device__ __forceinline__ void degrees_in_list(const GateLds& L, const uint16_t* list, uint32_t r, uint32_t MW) {
   const uint32_t l = lane_id();
   if (l < MW) L.mask[l] = 0ull;
   __syncthreads();
@@ -263,7 +323,188 @@ __device__ void degrees_in_list(const GateLds& L, const uint16_t* list, uint32_t
 // equals colouring class by class (each class = greedy independent set in list order), which is what the
 // bit-parallel loop below does. With min_k >= 2 class 1 is never filled (:242-245), so every vertex gets
 // k = 1 < min_k, the order is unchanged and only C[r-1] = 0 is written (:247-248).
-__device__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW, uint32_t qmax, uint32_t qsz) {
+// Register form of the class-by-class colouring for lists of up to 64 * NCH vertices. Phase 1 builds the
+// adjacency of the list in POSITION space (row i = bits over list positions), one ballot per (row, chunk), with no
+// dependency between rows, so the LDS reads pipeline; row i lives in lane (i & 63), chunk-row (i >> 6). Phase 2 is
+// the sequential greedy pass: the candidate set Q and the uncoloured set are wave-uniform scalars, a pick costs a
+// find-first-set, NCH v_readlane pairs and NCH and-not operations -- no LDS read on the critical path.
+template <int NCH>
+__device__ __forceinline__ void colour_sort_regs(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW) {
+  const uint32_t l = lane_id();
+  const uint32_t nch = (r + 63u) / 64u;
+  uint32_t hreg[NCH];
+  u64 arow[NCH][NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    hreg[c] = (c * 64u + l) < r ? list[c * 64u + l] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int c2 = 0; c2 < NCH; ++c2) arow[c][c2] = 0ull;
+  }
+  constexpr uint32_t kInFlight = 4;
+#pragma unroll
+  for (int ci = 0; ci < NCH; ++ci) {
+    if ((uint32_t)ci < nch) {                              // wave-uniform
+      const uint32_t cnt = min(64u, r - ci * 64u);
+      for (uint32_t li0 = 0; li0 < cnt; li0 += kInFlight) {
+        u64 wv[kInFlight][NCH];
+#pragma unroll
+        for (uint32_t jj = 0; jj < kInFlight; ++jj) {
+          const uint32_t gi = rdlane(hreg[ci], min(li0 + jj, cnt - 1u));
+          const u64* grow = L.adjc + (size_t)gi * MW;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c)
+            wv[jj][c] = ((uint32_t)c < nch && hreg[c] != 0xFFFFFFFFu) ? grow[hreg[c] >> 6] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t jj = 0; jj < kInFlight; ++jj) {
+          const uint32_t li = li0 + jj;
+          if (li < cnt) {                                  // wave-uniform
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+              if ((uint32_t)c < nch) {
+                const u64 bal = __ballot(((wv[jj][c] >> (hreg[c] & 63u)) & 1ull) != 0ull);
+                if (l == li) arow[ci][c] = bal;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  u64 uncol[NCH], Q[NCH];                                  // wave-uniform
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    uncol[c] = (uint32_t)c < nch ? ((c * 64u + 64u <= r) ? ~0ull : ((1ull << (r - c * 64u)) - 1ull)) : 0ull;
+  uint32_t k = 1, outpos = 0;
+  while (true) {
+    u64 any = 0ull;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { any |= uncol[c]; Q[c] = uncol[c]; }
+    if (any == 0ull) break;
+    while (true) {
+      int wi = -1;
+      u64 wq = 0ull;
+#pragma unroll
+      for (int c = NCH - 1; c >= 0; --c)
+        if (Q[c] != 0ull) { wi = c; wq = Q[c]; }
+      if (wi < 0) break;
+      const uint32_t bit = (uint32_t)__ffsll((long long)wq) - 1u;
+      uint32_t g = 0;
+      u64 row[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) row[c] = 0ull;
+#pragma unroll
+      for (int ci = 0; ci < NCH; ++ci) {
+        if (wi == ci) {                                    // wave-uniform
+          g = rdlane(hreg[ci], bit);
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) row[c] = rdlane64(arow[ci][c], bit);
+        }
+      }
+      if (l == 0) { L.tmp[outpos] = (uint16_t)g; L.C[outpos] = k; }
+      ++outpos;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const u64 self = (c == wi) ? (1ull << bit) : 0ull;
+        Q[c] &= ~(row[c] | self);                          // neighbours cannot join this class
+        uncol[c] &= ~self;
+      }
+    }
+    ++k;
+  }
+  __syncthreads();
+  for (uint32_t i = l; i < r; i += 64u) list[i] = L.tmp[i];
+  __syncthreads();
+}
+
+// Same colouring for lists of 65..512 vertices when the launch has LDS to spare: the position-space rows go to
+// LDS (ap[i * nch + c]), Q and the uncoloured set are spread over the lanes (lane c = positions 64c..64c+63). A pick
+// is a ballot, two find-first-set, one LDS row read and an and-not, whatever the list length.
+__device__ __forceinline__ void colour_sort_rows(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW) {
+  const uint32_t l = lane_id();
+  const uint32_t nch = (r + 63u) / 64u;
+  u64* ap = L.aprime;
+  uint32_t hoff[kRegChunks], hbit[kRegChunks];             // word offset and bit of this lane's member of every chunk
+#pragma unroll
+  for (uint32_t c = 0; c < kRegChunks; ++c) {
+    const uint32_t h = (c * 64u + l) < r ? list[c * 64u + l] : 0xFFFFFFFFu;
+    hoff[c] = h == 0xFFFFFFFFu ? 0xFFFFFFFFu : (h >> 6);
+    hbit[c] = h & 63u;
+  }
+  constexpr uint32_t kInFlight = 4;
+  for (uint32_t ci = 0; ci < nch; ++ci) {
+    const uint32_t cnt = min(64u, r - ci * 64u);
+    const uint32_t myv = (ci * 64u + l) < r ? list[ci * 64u + l] : 0u;
+    uint32_t acc_lo[kRegChunks], acc_hi[kRegChunks];        // row (64 ci + l)
+#pragma unroll
+    for (uint32_t c = 0; c < kRegChunks; ++c) { acc_lo[c] = 0u; acc_hi[c] = 0u; }
+    for (uint32_t li0 = 0; li0 < cnt; li0 += kInFlight) {
+      u64 wv[kInFlight][kRegChunks];
+#pragma unroll
+      for (uint32_t jj = 0; jj < kInFlight; ++jj) {
+        const uint32_t gi = rdlane(myv, min(li0 + jj, cnt - 1u));
+        const u64* grow = L.adjc + (size_t)gi * MW;
+#pragma unroll
+        for (uint32_t c = 0; c < kRegChunks; ++c)
+          wv[jj][c] = (c < nch && hoff[c] != 0xFFFFFFFFu) ? grow[hoff[c]] : 0ull;
+      }
+#pragma unroll
+      for (uint32_t jj = 0; jj < kInFlight; ++jj) {
+        const uint32_t li = li0 + jj;
+        if (li < cnt) {                                    // wave-uniform
+#pragma unroll
+          for (uint32_t c = 0; c < kRegChunks; ++c) {
+            if (c < nch) {
+              const u64 bal = __ballot(((wv[jj][c] >> hbit[c]) & 1ull) != 0ull);
+              if (l == li) { acc_lo[c] = (uint32_t)bal; acc_hi[c] = (uint32_t)(bal >> 32); }
+            }
+          }
+        }
+      }
+    }
+    if (ci * 64u + l < r) {
+#pragma unroll
+      for (uint32_t c = 0; c < kRegChunks; ++c)
+        if (c < nch) ap[(size_t)(ci * 64u + l) * nch + c] = ((u64)acc_hi[c] << 32) | acc_lo[c];
+    }
+  }
+  __syncthreads();
+  u64 uncol = 0ull;
+  if (l < nch) uncol = (l * 64u + 64u <= r) ? ~0ull : ((1ull << (r - l * 64u)) - 1ull);
+  uint32_t k = 1, outpos = 0;
+  uint32_t mypos = 0, myk = 0;                             // lane (outpos & 63) records a pick; flushed every 64 picks
+  while (__ballot(uncol != 0ull) != 0ull) {
+    u64 Q = uncol;
+    while (true) {
+      const u64 balQ = __ballot(Q != 0ull);
+      if (balQ == 0ull) break;
+      const uint32_t ll = (uint32_t)__ffsll((long long)balQ) - 1u;
+      const u64 wq = rdlane64(Q, ll);
+      const uint32_t bit = (uint32_t)__ffsll((long long)wq) - 1u;
+      const uint32_t pos = ll * 64u + bit;
+      const u64 rowc = l < nch ? ap[(size_t)pos * nch + l] : 0ull;
+      const u64 self = (l == ll) ? (1ull << bit) : 0ull;
+      uncol &= ~self;
+      Q &= ~(rowc | self);                                 // neighbours cannot join this class
+      if (l == (outpos & 63u)) { mypos = pos; myk = k; }
+      ++outpos;
+      if ((outpos & 63u) == 0u) { L.keys[outpos - 64u + l] = mypos; L.C[outpos - 64u + l] = myk; }
+    }
+    ++k;
+  }
+  if (l < (outpos & 63u)) { L.keys[(outpos & ~63u) + l] = mypos; L.C[(outpos & ~63u) + l] = myk; }
+  __syncthreads();
+  uint16_t moved[kRegChunks];
+#pragma unroll
+  for (uint32_t c = 0; c < kRegChunks; ++c) moved[c] = (c * 64u + l) < r ? list[L.keys[c * 64u + l]] : (uint16_t)0;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t c = 0; c < kRegChunks; ++c)
+    if ((c * 64u + l) < r) list[c * 64u + l] = moved[c];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW, uint32_t qmax, uint32_t qsz) {
   const uint32_t l = lane_id();
   const int min_k = max(1, (int)qmax - (int)qsz + 1);
   if (min_k >= 2) {
@@ -271,15 +512,13 @@ __device__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32
     __syncthreads();
     return;
   }
+  if (r <= 64u) { colour_sort_regs<1>(L, list, r, MW); return; }
+  if (r <= 512u && L.aprime) { colour_sort_rows(L, list, r, MW); return; }
+  if (r <= 256u) { colour_sort_regs<4>(L, list, r, MW); return; }
+  if (r <= 512u) { colour_sort_regs<8>(L, list, r, MW); return; }
   const uint32_t nchunks = (r + 63u) / 64u;
   u64 uncol = 0ull;                                        // lane c holds positions [64c, 64c + 64)
   if (l < nchunks) uncol = (l * 64u + 64u <= r) ? ~0ull : ((1ull << (r - l * 64u)) - 1ull);
-  // the list does not change during the pass: keep this lane's member of every 64-position chunk in registers
-  constexpr uint32_t kRegChunks = 8;                       // lists of up to 512 vertices
-  const bool in_regs = nchunks <= kRegChunks;
-  uint32_t hreg[kRegChunks];
-#pragma unroll
-  for (uint32_t c = 0; c < kRegChunks; ++c) hreg[c] = (c * 64u + l) < r ? list[c * 64u + l] : 0xFFFFFFFFu;
   uint32_t k = 1, outpos = 0;
   while (__ballot(uncol != 0ull) != 0ull) {
     u64 Q = uncol;
@@ -294,28 +533,13 @@ __device__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32
       ++outpos;
       if (l == ll) { uncol &= ~(1ull << bit); Q &= ~(1ull << bit); }
       const u64* grow = L.adjc + (size_t)g * MW;
-      if (in_regs) {
-        // one LDS read per chunk straight at the word that holds the bit; all reads are issued before any is used
-        u64 wv[kRegChunks];
-#pragma unroll
-        for (uint32_t c = 0; c < kRegChunks; ++c)
-          wv[c] = (c < nchunks && hreg[c] != 0xFFFFFFFFu) ? grow[hreg[c] >> 6] : 0ull;
-#pragma unroll
-        for (uint32_t c = 0; c < kRegChunks; ++c) {
-          if (c < nchunks && ((balQ >> c) & 1ull)) {       // wave-uniform
-            const u64 bal = __ballot(((wv[c] >> (hreg[c] & 63u)) & 1ull) != 0ull);
-            if (l == c) Q &= ~bal;                         // neighbours cannot join this class
-          }
-        }
-      } else {
-        for (uint32_t c = 0; c < nchunks; ++c) {
-          if (!((balQ >> c) & 1ull)) continue;             // wave-uniform
-          const uint32_t pos = c * 64u + l;
-          bool adj = false;
-          if (pos < r) { const uint32_t h = list[pos]; adj = (grow[h >> 6] >> (h & 63u)) & 1ull; }
-          const u64 bal = __ballot(adj);
-          if (l == c) Q &= ~bal;
-        }
+      for (uint32_t c = 0; c < nchunks; ++c) {
+        if (!((balQ >> c) & 1ull)) continue;               // wave-uniform
+        const uint32_t pos = c * 64u + l;
+        bool adj = false;
+        if (pos < r) { const uint32_t h = list[pos]; adj = (grow[h >> 6] >> (h & 63u)) & 1ull; }
+        const u64 bal = __ballot(adj);
+        if (l == c) Q &= ~bal;                             // neighbours cannot join this class
       }
     }
     ++k;
@@ -327,9 +551,11 @@ __device__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32
 
 // FindClique + MaxCliqueDyn (maximum_clique.cpp:286-369) as an explicit state machine over one wave.
 // Returns QMax.size(); *err != 0 when the per-wave stack is too small.
-__device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, uint16_t* stack, uint32_t stack_cap,
-                                  int* err, uint32_t* steps_out) {
+__device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, uint16_t* gstack, uint32_t stack_cap,
+                                  int* err, uint32_t* steps_out, uint32_t* prof = nullptr) {
   const uint32_t l = lane_id();
+  const LevelStack stack = {L.lstack, L.lstack_cap, gstack};
+  stack_cap += L.lstack_cap;
   const uint32_t MW = (m + 63u) / 64u;
   // R = all vertices, DegreeSort(R); L.deg holds the degree of graph vertex g at index g
   for (uint32_t i = l; i < m; i += 64u) L.cur[i] = (uint16_t)i;
@@ -339,12 +565,14 @@ __device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, 
   __syncthreads();
   for (uint32_t i = l; i < m; i += 64u) L.C[i] = i < max_degree ? i + 1u : max_degree + 1u;     // :356-361
   for (uint32_t i = l; i < m + 2u; i += 64u) { L.S[i] = 0u; L.SOld[i] = 0u; }
-  for (uint32_t i = l; i < m; i += 64u) stack[i] = L.cur[i];
+  for (uint32_t i = l; i < m; i += 64u) stk_put(stack, i, L.cur[i]);
   if (l == 0) { L.lbase[1] = 0u; L.lsize[1] = m; L.lcap[1] = m; }
   __syncthreads();
 
   uint32_t level = 1, qsz = 0, qmax = 0, top = m;
   int all_steps = 1;
+  // optional phase profile (diagnostics): cycles in intersection / degree re-sort / colouring, and their counts
+  uint32_t pf_isect = 0, pf_sort = 0, pf_col = 0, pf_nsort = 0, pf_nfull = 0, pf_vfull = 0, pf_big = 0, pf_vbig = 0;
   uint16_t* cur = L.cur;
   uint16_t* nxt = L.nxt;
   bool reload = false;
@@ -353,7 +581,7 @@ __device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, 
     const uint32_t sz = uni(L.lsize[level]);
     if (reload) {
       const uint32_t b = uni(L.lbase[level]);
-      for (uint32_t i = l; i < sz; i += 64u) cur[i] = stack[b + i];
+      for (uint32_t i = l; i < sz; i += 64u) cur[i] = stk_get(stack, b + i);
       __syncthreads();
       reload = false;
     }
@@ -367,6 +595,7 @@ __device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, 
         ++qsz;                                             // Q.push_back(p)
         // Intersection(p, R, Rp), :209-217 -- order preserving compaction
         const u64* prow = L.adjc + (size_t)p * MW;
+        const long long pt0 = prof ? clock64() : 0;
         uint32_t rp = 0;
         for (uint32_t i0 = 0; i0 < sz; i0 += 64u) {
           const uint32_t i = i0 + l;
@@ -379,12 +608,24 @@ __device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, 
         }
         rp = uni(rp);
         __syncthreads();
+        const long long pt1 = prof ? clock64() : 0;
+        pf_isect += (uint32_t)(pt1 - pt0);
         if (rp > 0u) {
-          if ((double)uni(L.S[level]) / (double)all_steps < 0.025) {   // :313
+          // :313 is (double)S[level] / all_steps_ < 0.025. With all_steps <= 100001 a quotient other than 1/40
+          // differs from 1/40 by more than 1e-7, and 1/40 itself rounds to the literal: the test is 40 S < all_steps
+          if ((uint64_t)uni(L.S[level]) * 40ull < (uint64_t)all_steps) {
             degrees_in_list(L, nxt, rp, MW);
             rank_sort_desc(nxt, L.tmp, L.deg, rp, L.keys);
+            ++pf_nsort;
           }
+          const long long pt2 = prof ? clock64() : 0;
+          pf_sort += (uint32_t)(pt2 - pt1);
           colour_sort(L, nxt, rp, MW, qmax, qsz);
+          if (prof) {
+            const uint32_t dt = (uint32_t)(clock64() - pt2);
+            pf_col += dt;
+            if ((int)qmax - (int)qsz + 1 < 2) { ++pf_nfull; pf_vfull += rp; if (rp > 64u) { pf_big += dt; pf_vbig += rp; } }
+          }
           if (l == 0) L.S[level] += 1u;
           ++all_steps;
           __syncthreads();
@@ -393,7 +634,7 @@ __device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, 
           } else {
             const uint32_t nb = uni(L.lbase[level]) + uni(L.lcap[level]);
             if (nb + rp > stack_cap) { *err = 1; break; }
-            for (uint32_t i = l; i < rp; i += 64u) stack[nb + i] = nxt[i];
+            for (uint32_t i = l; i < rp; i += 64u) stk_put(stack, nb + i, nxt[i]);
             ++level;
             if (l == 0) { L.lbase[level] = nb; L.lsize[level] = rp; L.lcap[level] = rp; }
             uint16_t* t = cur; cur = nxt; nxt = t;
@@ -437,6 +678,7 @@ __device__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, 
     __syncthreads();
   }
   if (steps_out) *steps_out = (uint32_t)all_steps;
+  if (prof && l == 0) { prof[0] = pf_isect; prof[1] = pf_sort; prof[2] = pf_col; prof[3] = pf_big; prof[4] = pf_vbig; prof[5] = pf_vfull; }
   return qmax;
 }
 
@@ -513,7 +755,7 @@ __global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
         }
       } else {
         const bool ext = gate_lds_bytes(m) > A.lds_bytes;   // third tier: adjacency matrix in global scratch
-        GateLds L = gate_carve(lds_raw, m, ext ? A.adjc_scratch + (size_t)blockIdx.x * kAdjcScratchWords : nullptr);
+        GateLds L = gate_carve(lds_raw, m, A.lds_bytes, ext ? A.adjc_scratch + (size_t)blockIdx.x * kAdjcScratchWords : nullptr);
         const uint32_t MW = (m + 63u) / 64u;
         const long long t_start = A.dbg ? clock64() : 0;   // phase stamps (diagnostics builds of the call only)
         // F in ascending order (:219) -> graph index = rank (:241-243)
@@ -539,7 +781,56 @@ __global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
         bad_index = __ballot(bad_index) != 0ull;           // never dereference an unchecked index
         if (bad_index && l == 0) { atomicExch(&A.status[0], 4u); A.status[6] = m; A.status[7] = it; }
         if (!bad_index && A.stop_level != 3u) {
-          if (W <= 64u) {
+          if (W <= 8u) {
+            // n <= 512: lane = one row of the induced graph, its whole sample row (<= 16 dwords) in registers;
+            // the members of F are walked once per 64 rows, one v_readlane + bit-field extract + shift-or each.
+            // F is ascending, so the source dword only ever moves forward.
+            uint32_t fl[kRegChunks];
+#pragma unroll
+            for (uint32_t c = 0; c < kRegChunks; ++c) fl[c] = (c * 64u + l) < m ? L.flist[c * 64u + l] : 0u;
+            for (uint32_t rc = 0; rc < MW; ++rc) {
+              const uint32_t grow = rc * 64u + l;
+              const bool have = grow < m;
+              const uint32_t myv = have ? (uint32_t)L.flist[grow] : 0u;
+              uint32_t rw[16];
+              {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(job.samp + (size_t)myv * W);
+#pragma unroll
+                for (uint32_t w = 0; w < 16u; ++w) rw[w] = (have && w < 2u * W) ? src[w] : 0u;
+              }
+              uint32_t out[2u * kRegChunks];
+#pragma unroll
+              for (uint32_t c = 0; c < 2u * kRegChunks; ++c) out[c] = 0u;
+              uint32_t wcur = 0xFFFFFFFFu, word = 0u;
+#pragma unroll
+              for (uint32_t cj = 0; cj < 2u * kRegChunks; ++cj) {      // 32 positions per step: the target dword is static
+                if (cj * 32u < m) {                                     // wave-uniform
+                  const uint32_t cnt = min(32u, m - cj * 32u);
+                  for (uint32_t lj = 0; lj < cnt; ++lj) {
+                    const uint32_t h = rdlane(fl[cj >> 1], (cj & 1u) * 32u + lj);
+                    if ((h >> 5) != wcur) {                             // wave-uniform, at most 2 W times per 64 rows
+                      wcur = h >> 5;
+#pragma unroll
+                      for (uint32_t w = 0; w < 16u; ++w) if (wcur == w) word = rw[w];
+                    }
+                    out[cj] |= ((word >> (h & 31u)) & 1u) << lj;
+                  }
+                }
+              }
+              if (have) {
+                uint32_t d = 0;
+#pragma unroll
+                for (uint32_t c = 0; c < kRegChunks; ++c) {
+                  if (c < MW) {
+                    const u64 wv = ((u64)out[2u * c + 1u] << 32) | out[2u * c];
+                    L.adjc[(size_t)grow * MW + c] = wv;
+                    d += (uint32_t)__popcll(wv);
+                  }
+                }
+                L.deg[grow] = d;
+              }
+            }
+          } else if (W <= 64u) {
             // lane l holds word l of a row; kRows rows are in flight so the global latency is paid once per group
             constexpr uint32_t kRows = 8;
             for (uint32_t g0 = 0; g0 < m; g0 += kRows) {
@@ -601,7 +892,8 @@ __global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
         } else {
           int err = 0;
           uint32_t steps = 0;
-          const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, &steps);
+          uint32_t* prof = (A.dbg && A.dbg_stride >= 16u) ? A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 12u) : nullptr;
+          const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, &steps, prof);
           if (A.dbg && l == 0 && A.dbg_stride >= 8u) {
             uint32_t* d = A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 6u);
             d[0] = (uint32_t)(t_flist - t_start); d[1] = (uint32_t)(t_adjc - t_flist);
@@ -628,10 +920,11 @@ __global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
 // stand-alone clique search on an explicit graph (the reference's test/test_maximum_clique.cpp shape):
 // adj = m x MW bit matrix in global memory. One block of 64 threads.
 __global__ __launch_bounds__(128) void clique_test_kernel(const u64* adj, uint32_t m, uint32_t minimal_size,
-                                                         uint16_t* stack, uint32_t stack_cap, uint32_t* out) {
+                                                         uint16_t* stack, uint32_t stack_cap, uint32_t lds_bytes,
+                                                         uint32_t* out) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const uint32_t l = lane_id();
-  GateLds L = gate_carve(lds_raw, m);
+  GateLds L = gate_carve(lds_raw, m, lds_bytes);
   const uint32_t MW = (m + 63u) / 64u;
   for (uint32_t i = l; i < m * MW; i += 64u) L.adjc[i] = adj[i];
   __syncthreads();
@@ -1674,10 +1967,10 @@ int todhip_test_clique(todhip_ctx* ctx, uint32_t m, const uint32_t* edges, uint3
   TOD_HIP(ws->stacks.reserve((size_t)kStackCap * sizeof(uint16_t)));
   TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
   TOD_HIP(hipMemcpyAsync(ws->clique_adj.p, adj.data(), adj.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-  const uint32_t lds = gate_lds_bytes(m);
-  if (lds > kEvalLdsBig) return TODHIP_ESCRATCH;
+  if (gate_lds_bytes(m) > kEvalLdsBig) return TODHIP_ESCRATCH;
+  const uint32_t lds = gate_lds_bytes(m) <= kEvalLdsSmall ? kEvalLdsSmall : kEvalLdsBig;   // the two LDS tiers of eval_kernel
   hipLaunchKernelGGL(clique_test_kernel, dim3(1), dim3(64), lds, ctx->stream, ws->clique_adj.as<u64>(), m, minimal_size,
-                     ws->stacks.as<uint16_t>(), kStackCap, ws->small.as<uint32_t>());
+                     ws->stacks.as<uint16_t>(), kStackCap, lds, ws->small.as<uint32_t>());
   TOD_HIP(hipGetLastError());
   TOD_HIP(hipMemcpyAsync(out3, ws->small.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   TOD_HIP(hipStreamSynchronize(ctx->stream));
