@@ -24,16 +24,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # The HIP runtime maps a process's streams onto 4 hardware queues unless told otherwise, so at most ~4 of the
-# per-frame ORB/verifier streams would overlap (tools/stream_concurrency.py: 4 by default, 8 with 16 queues).
+# per-frame ORB/verifier streams would overlap (tools/stream_concurrency.py: 4 by default, 8 with more queues;
+# beyond 8 busy queues the driver time-slices them and every launch stalls, so 8 it is).
 # Must be in the environment before the runtime is loaded (i.e. before torch is imported).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) issue at 16 lanes/clk/SIMD on gfx950: 4 cycles per
 # wave64 instruction, measured with tools/valu_peak.hip (profiles/r01_valu_peak_microbench.txt: 38-40 T lane-op/s).
 # Only f32 FMA is dual-rate, so SURVEY F11's 78.6 T figure does not apply to this kernel.
 VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9            # 39.3 T lane-op/s
-LANEOPS_PER_DISTANCE = 16                           # 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 per 256-bit pair
+LANEOPS_DENSE = 16                                  # 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 per full 256-bit pair
 
 
 def parse():
@@ -48,7 +49,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
     ap.add_argument("--stages", default="orb,match,verify", help="comma list of: orb,match,verify")
     ap.add_argument("--batch", type=int, default=16, help="frames per rank per step")
-    ap.add_argument("--verify-workers", type=int, default=4, help="ORB + verifier contexts (frames in flight beside the matcher)")
+    ap.add_argument("--verify-workers", type=int, default=6, help="ORB + verifier contexts (frames in flight beside the matcher)")
     ap.add_argument("--iterations", type=int, default=2500, help="n_ransac_iterations (conf/detection.ork:38)")
     ap.add_argument("--min-inliers", type=int, default=8, help="min_inliers (conf/detection.ork:39)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
@@ -266,16 +267,24 @@ def main():
     achieved = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
     frames_per_launch = B if world > 1 else 1                      # sharded: one launch matches world*B frames
     distances = float(nq) * world * frames_per_launch * info["shard_rows"]
-    valu_frac = LANEOPS_PER_DISTANCE * distances / (k4_ms * 1e-3) / VALU_PEAK_LANEOPS if k4_ms > 0 else 0.0
 
     # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, collected in their own
     # rocprofv3 runs by tools/profile_k4.sh and committed as profiles/r01_k4_pmc.json); only quoted for the
     # workload it was measured on
     traffic, traffic_src = None, None
+    # VALU instructions the kernel EXECUTES per (row, query) pair: 16 for a full distance, about half of that when the
+    # 128-bit lower bound prunes the row (data dependent). Taken from the same PMC passes (SQ_INSTS_VALU) when the
+    # workload is the profiled one, else the dense count is used and the figure is an upper bound.
+    laneops, laneops_src = float(LANEOPS_DENSE), "dense instruction count (upper bound)"
     pmc_path = os.path.join(ROOT, "profiles", "r01_k4_pmc.json")
-    if world == 1 and nq == 1000 and k == 2 and info["shard_rows"] == 1000000 and os.path.exists(pmc_path):
-        traffic = json.load(open(pmc_path))["hbm_traffic_bytes_per_launch"]
+    if world == 1 and nq == 1000 and k == 2 and info["shard_rows"] == 1000000 and args.radius == 35 and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        traffic = pmc["hbm_traffic_bytes_per_launch"]
         traffic_src = "profiles/r01_k4_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        if "valu_insts_per_row_and_wave" in pmc:
+            laneops = float(pmc["valu_insts_per_row_and_wave"])
+            laneops_src = "profiles/r01_k4_pmc.json (SQ_INSTS_VALU per row and 64-query wave)"
+    valu_frac = laneops * distances / (k4_ms * 1e-3) / VALU_PEAK_LANEOPS if k4_ms > 0 else 0.0
     if rank == 0:
         out = {
             "metric": "frames/sec @ 640x480, 1M-descriptor DB; achieved HBM GB/s on BF-matcher",
@@ -303,9 +312,10 @@ def main():
                          "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,
                          "note": "at Q=%d queries per DB pass this kernel is bound by integer VALU issue, not HBM "
                                  "(SURVEY F11): see valu_roofline" % nq},
-            "valu_roofline": {"bound": "valu", "achieved": LANEOPS_PER_DISTANCE * distances / (k4_ms * 1e-3) / 1e12
+            "valu_roofline": {"bound": "valu", "achieved": laneops * distances / (k4_ms * 1e-3) / 1e12
                               if k4_ms > 0 else 0.0, "peak": VALU_PEAK_LANEOPS / 1e12, "unit": "T lane-op/s",
-                              "frac": valu_frac, "distances_per_launch": distances},
+                              "frac": valu_frac, "distances_per_launch": distances, "valu_ops_per_distance": laneops,
+                              "valu_ops_source": laneops_src, "dense_ops_per_distance": LANEOPS_DENSE},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,

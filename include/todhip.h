@@ -149,6 +149,13 @@ int todhip_orb_device(todhip_ctx*, const void* d_gray, uint32_t H, uint32_t W, u
                       uint32_t n_levels, float scale_factor, const int8_t* pattern, void* d_kp_xy, void* d_kp_aux,
                       void* d_desc, uint32_t* n_out);
 
+/* A batch of n_frames device-resident frames (frame f at d_gray + f * frame_stride bytes) in the launches of one:
+ * frame f's keypoints land at row f * cap of d_kp_xy[n_frames*cap*2], d_kp_aux[n_frames*cap*4], d_desc[n_frames*cap*32];
+ * n_out[n_frames] comes back. Each frame's result equals todhip_orb_device's on that frame. */
+int todhip_orb_batch_device(todhip_ctx*, const void* d_gray, uint32_t n_frames, uint64_t frame_stride, uint32_t H, uint32_t W,
+                            uint32_t stride, uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern,
+                            void* d_kp_xy, void* d_kp_aux, void* d_desc, uint32_t cap, uint32_t* n_out);
+
 /* ---- training ----------------------------------------------------------------- */
 /* Per-observation arithmetic of the reference's Trainer cell (src/training/Trainer.cpp:121-187, training.cpp:57-195):
  * ORB on the masked view (the reference uses cv::ORB defaults: 500 features, 8 levels, scale 1.2 -- :148-149),

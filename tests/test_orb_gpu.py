@@ -64,3 +64,26 @@ def test_descriptor_survives_in_plane_rotation(ctx):
         if j is not None:
             dists.append(int(lut[d0[i] ^ d1[j]].sum()))
     assert len(dists) > 200 and np.median(dists) < 40                # random pairs sit at ~128
+
+
+def test_batch_of_frames_equals_frame_by_frame(ctx):
+    """todhip_orb_batch_device: five different frames (one flat, with no keypoints) in the launches of one; every
+    frame must come out exactly as from the single-frame call and as from the CPU restatement."""
+    import torch
+    imgs = [synth.make_image(10 + i) for i in range(4)] + [np.full((480, 640), 90, np.uint8)]
+    F, cap = len(imgs), 1000
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    kp = torch.zeros((F, cap, 2), device="cuda"); aux = torch.zeros((F, cap, 4), device="cuda")
+    desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
+    n = ctx.orb_batch_device(d.data_ptr(), F, 480 * 640, 480, 640, 640, 1000, 3, 1.2, kp.data_ptr(), aux.data_ptr(),
+                             desc.data_ptr(), cap)
+    assert n == [1000, 1000, 1000, 1000, 0]
+    for f in range(F - 1):
+        o_kp, o_aux, o_desc, _ = O.orb(imgs[f], 1000, 3, 1.2)
+        assert np.array_equal(kp[f].cpu().numpy(), o_kp) and np.array_equal(desc[f].cpu().numpy(), o_desc)
+        s_kp, s_aux, s_desc = ctx.orb(imgs[f], 1000, 3, 1.2)
+        assert np.array_equal(aux[f].cpu().numpy(), s_aux) and np.array_equal(desc[f].cpu().numpy(), s_desc)
+    # a second batch of another size through the same context (graph re-captured for the new batch size)
+    n2 = ctx.orb_batch_device(d[1:3].contiguous().data_ptr(), 2, 480 * 640, 480, 640, 640, 1000, 3, 1.2, kp.data_ptr(),
+                              aux.data_ptr(), desc.data_ptr(), cap)
+    assert n2 == [1000, 1000] and np.array_equal(desc[1].cpu().numpy(), O.orb(imgs[2], 1000, 3, 1.2)[2])

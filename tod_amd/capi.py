@@ -56,7 +56,7 @@ EXPORTS = [
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device",
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
-    "todhip_orb_device", "todhip_verify_device_depth",
+    "todhip_orb_device", "todhip_verify_device_depth", "todhip_orb_batch_device",
     "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
 ]
 
@@ -339,6 +339,20 @@ def _orb_device(self, d_gray, H, W, stride, n_features, n_levels, scale_factor, 
 
 
 Context.orb_device = _orb_device
+
+
+def _orb_batch_device(self, d_gray, n_frames, frame_stride, H, W, stride, n_features, n_levels, scale_factor, d_kp_xy, d_kp_aux,
+                      d_desc, cap):
+    n = (C.c_uint32 * n_frames)()
+    rc = lib().todhip_orb_batch_device(self._h, C.c_void_p(d_gray), C.c_uint32(n_frames), C.c_uint64(frame_stride), C.c_uint32(H),
+                                       C.c_uint32(W), C.c_uint32(stride), C.c_uint32(n_features), C.c_uint32(n_levels),
+                                       C.c_float(scale_factor), None, C.c_void_p(d_kp_xy), C.c_void_p(d_kp_aux),
+                                       C.c_void_p(d_desc), C.c_uint32(cap), n)
+    _check(rc, "todhip_orb_batch_device")
+    return list(n)
+
+
+Context.orb_batch_device = _orb_batch_device
 
 
 class Model:

@@ -8,6 +8,8 @@
 //
 // All images of a 640x480 pyramid are a few hundred KB: every kernel is latency/launch bound, not bandwidth
 // bound; the per-level work is a fixed sequence of small launches with no host round trip until the final count.
+// A batch of frames rides in the last grid dimension of every launch (frame f owns slice f of every workspace
+// buffer), so a batch costs the launches of one frame.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -23,6 +25,11 @@ constexpr int kFastThr = 20;
 constexpr int kMaxLevels = 16;
 
 struct Cand { int x, y, score; float harris; };
+
+// control words of one level and one frame (device): what the selection kernels hand to each other without a
+// host round trip; [8 + l] = keypoints of level l
+enum { W_NCAND = 0, W_NSEL1 = 1, W_THR = 2, W_NEED_EQ = 3, W_NEQ = 4, W_NGT = 5, W_HIST = 32 };
+constexpr uint32_t kCtlWords = 512;
 
 // same generator as the CPU restatement: seeded xorshift, points inside radius 13
 void default_pattern(int8_t* pat) {
@@ -54,8 +61,9 @@ void disc_umax(int* umax) {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restrict__ src, uint32_t stride, uint8_t* dst,
-                                                        uint32_t h, uint32_t w) {
+                                                        uint32_t h, uint32_t w, size_t src_fs, size_t dst_fs) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  src += blockIdx.y * src_fs; dst += blockIdx.y * dst_fs;   // frame
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
   dst[i] = src[(size_t)(i / w) * stride + (i % w)];
@@ -63,8 +71,9 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restric
 
 // 11-bit fixed-point bilinear resize, sample positions (x + 0.5) * sx - 0.5, replicate border
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, uint32_t sh, uint32_t sw, uint8_t* dst,
-                                                     uint32_t dh, uint32_t dw) {
+                                                     uint32_t dh, uint32_t dw, size_t fs) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  src += blockIdx.y * fs; dst += blockIdx.y * fs;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= dh * dw) return;
   const uint32_t x = i % dw, y = i / dw;
@@ -98,8 +107,10 @@ __device__ __forceinline__ int arc9_max(const int (&d)[16]) {
   return best;
 }
 
-__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, uint32_t h, uint32_t w, int* score) {
+__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, uint32_t h, uint32_t w, int* score,
+                                                         size_t fs) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  img += blockIdx.z * fs; score += blockIdx.z * fs;
   const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
   int s = 0;
@@ -123,8 +134,10 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restri
 // 3x3 strict non-maximum suppression + compaction (order is fixed later by the ranking)
 __global__ __launch_bounds__(256) void nms_kernel(const int* __restrict__ score, uint32_t h, uint32_t w, Cand* cand,
                                                   uint32_t cap, uint32_t* counter, uint32_t* hist,
-                                                  const uint8_t* __restrict__ mask, uint32_t H0, uint32_t W0) {
+                                                  const uint8_t* __restrict__ mask, uint32_t H0, uint32_t W0, size_t fs) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  score += blockIdx.z * fs; cand += (size_t)blockIdx.z * cap; counter += blockIdx.z * kCtlWords; hist += blockIdx.z * kCtlWords;
+  if (mask) mask += blockIdx.z * fs;
   const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
   if (x < (uint32_t)kEdge || x >= w - kEdge || y < (uint32_t)kEdge || y >= h - kEdge) return;
   const int s = score[(size_t)y * w + x];
@@ -153,14 +166,19 @@ __device__ __forceinline__ unsigned long long key_of(const Cand& c, bool by_harr
   return ((unsigned long long)hi << 32) | ((unsigned long long)(uint32_t)c.y << 16) | (uint32_t)c.x;
 }
 
-// control words of one level (device): what the selection kernels hand to each other without a host round trip
-enum { W_NCAND = 0, W_NSEL1 = 1, W_THR = 2, W_NEED_EQ = 3, W_NEQ = 4, W_NGT = 5, W_HIST = 32 };
+// zero the per-level control words and the score histogram of every frame (level counts at [8..) stay)
+__global__ __launch_bounds__(256) void level_reset_kernel(uint32_t* ctl) {
+  uint32_t* c = ctl + blockIdx.x * kCtlWords;
+  if (threadIdx.x < 8u) c[threadIdx.x] = 0u;
+  c[W_HIST + threadIdx.x] = 0u;
+}
 
 // "keep the 2n best by FAST score" only defines a SET (the Harris ranking re-orders it), so a 256-bin histogram
 // gives the score threshold T: everything above T is kept, and of the candidates at exactly T the first
 // keep - count(> T) in (y, x) order.
 __global__ void fast_threshold_kernel(uint32_t* ctl, uint32_t cand_cap, uint32_t keep) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  ctl += blockIdx.x * kCtlWords;
   if (threadIdx.x != 0) return;
   const uint32_t n = min(ctl[W_NCAND], cand_cap);
   uint32_t above = 0, thr = 0, need = 0;
@@ -178,8 +196,10 @@ __global__ void fast_threshold_kernel(uint32_t* ctl, uint32_t cand_cap, uint32_t
 }
 
 __global__ __launch_bounds__(256) void split_kernel(const Cand* __restrict__ cand, uint32_t* ctl, uint32_t keep, Cand* sel1,
-                                                    Cand* eq) {
+                                                    Cand* eq, uint32_t cand_cap, uint32_t sel1_cap) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  cand += (size_t)blockIdx.y * cand_cap; eq += (size_t)blockIdx.y * cand_cap; sel1 += (size_t)blockIdx.y * sel1_cap;
+  ctl += blockIdx.y * kCtlWords;
   const uint32_t n = ctl[W_NCAND];
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -194,9 +214,14 @@ constexpr uint32_t kRankTile = 2048;
 __global__ __launch_bounds__(256) void rank_tiled_kernel(const Cand* __restrict__ in, const uint32_t* __restrict__ n_ptr,
                                                          const uint32_t* __restrict__ keep_ptr, uint32_t keep_val,
                                                          int by_harris, Cand* out, const uint32_t* __restrict__ off_ptr,
-                                                         uint32_t* n_out) {
+                                                         uint32_t* n_out, uint32_t in_fs, uint32_t out_fs) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   __shared__ unsigned long long keys[kRankTile];
+  in += (size_t)blockIdx.y * in_fs; out += (size_t)blockIdx.y * out_fs;      // frame: buffers by their strides,
+  n_ptr += blockIdx.y * kCtlWords;                                           // control words by kCtlWords
+  if (keep_ptr) keep_ptr += blockIdx.y * kCtlWords;
+  if (off_ptr) off_ptr += blockIdx.y * kCtlWords;
+  if (n_out) n_out += blockIdx.y * kCtlWords;
   const uint32_t n = *n_ptr;
   const uint32_t keep = keep_ptr ? *keep_ptr : keep_val;
   const uint32_t off = off_ptr ? *off_ptr : 0u;
@@ -218,8 +243,9 @@ __global__ __launch_bounds__(256) void rank_tiled_kernel(const Cand* __restrict_
 }
 
 __global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__ img, uint32_t w, Cand* cand,
-                                                     const uint32_t* __restrict__ n_ptr) {
+                                                     const uint32_t* __restrict__ n_ptr, size_t fs, uint32_t cand_fs) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  img += blockIdx.y * fs; cand += (size_t)blockIdx.y * cand_fs; n_ptr += blockIdx.y * kCtlWords;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= *n_ptr) return;
   const int x = cand[i].x, y = cand[i].y, W = (int)w;
@@ -239,8 +265,9 @@ __global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__
 
 __constant__ int c_gauss7[7] = {18, 33, 49, 56, 49, 33, 18};
 
-__global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst) {
+__global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst, size_t fs) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  src += blockIdx.y * fs; dst += blockIdx.y * fs;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
   const int x = (int)(i % w), y = (int)(i / w);
@@ -249,8 +276,9 @@ __global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__
   for (int k = -3; k <= 3; ++k) s += c_gauss7[k + 3] * src[(size_t)y * w + clampi(x + k, 0, (int)w - 1)];
   dst[i] = (uint8_t)((s + 128) >> 8);
 }
-__global__ __launch_bounds__(256) void blur_v_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst) {
+__global__ __launch_bounds__(256) void blur_v_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst, size_t fs) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  src += blockIdx.y * fs; dst += blockIdx.y * fs;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
   const int x = (int)(i % w), y = (int)(i / w);
@@ -267,11 +295,18 @@ struct DescribeArgs {
   float scale; uint32_t cap;
   const int8_t* pattern; int umax[kHalfPatch + 2];
   float* kp_xy; float* kp_aux; uint8_t* desc;
+  size_t fs; uint32_t sel_fs;                   // frame strides: images; selection (outputs: cap rows, controls: kCtlWords)
 };
 
 // one wave per keypoint: integer moments over the radius-15 disc (lane = row), then 4 tests per lane
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs A) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  {
+    const uint32_t f = blockIdx.y;
+    A.img += f * A.fs; A.blur += f * A.fs; A.sel += (size_t)f * A.sel_fs;
+    A.n_sel += f * kCtlWords; A.level_counts += f * kCtlWords;
+    A.kp_xy += (size_t)f * A.cap * 2; A.kp_aux += (size_t)f * A.cap * 4; A.desc += (size_t)f * A.cap * 32;
+  }
   const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
   if (i >= *A.n_sel) return;
   uint32_t base = 0;
@@ -320,11 +355,17 @@ __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs A) {
 __global__ __launch_bounds__(256) void copy_out_kernel(const uint32_t* __restrict__ level_counts, uint32_t n_levels, uint32_t cap,
                                                        const float* __restrict__ s_xy, const float* __restrict__ s_aux,
                                                        const uint32_t* __restrict__ s_desc, float* __restrict__ d_xy,
-                                                       float* __restrict__ d_aux, uint32_t* __restrict__ d_desc) {
+                                                       float* __restrict__ d_aux, uint32_t* __restrict__ d_desc,
+                                                       uint32_t* __restrict__ totals) {
+  const uint32_t f = blockIdx.y;
+  level_counts += f * kCtlWords;
+  s_xy += (size_t)f * cap * 2; s_aux += (size_t)f * cap * 4; s_desc += (size_t)f * cap * 8;
+  d_xy += (size_t)f * cap * 2; d_aux += (size_t)f * cap * 4; d_desc += (size_t)f * cap * 8;
   uint32_t total = 0;
   for (uint32_t l = 0; l < n_levels; ++l) total += level_counts[l];
   const uint32_t n = min(total, cap);
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;      // one dword each: 2 + 4 + 8 dwords per keypoint
+  if (i == 0) totals[f] = total;
   if (i < 2u * n) d_xy[i] = s_xy[i];
   if (i < 4u * n) d_aux[i] = s_aux[i];
   if (i < 8u * n) d_desc[i] = s_desc[i];
@@ -339,7 +380,7 @@ struct OrbWs {
   // pointers may change from call to call without a re-capture.
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
-  struct Key { uint32_t H, W, n_features, n_levels, cap; float sf; const void *kp, *aux, *desc, *img0, *mask; } key = {};
+  struct Key { uint32_t H, W, n_features, n_levels, cap, F; float sf; const void *kp, *aux, *desc, *img0, *mask; } key = {};
 };
 
 OrbWs* ows_of(todhip_ctx* ctx) {
@@ -360,28 +401,32 @@ void features_per_level(uint32_t n_features, uint32_t n_levels, float scale_fact
   out[n_levels - 1] = rest > 0 ? (uint32_t)rest : 0u;
 }
 
-// d_gray: H x W u8 on the device (row stride `stride`). Results stay on the device; *n_out is read back.
-int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, uint32_t H, uint32_t W, uint32_t stride,
-               uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, float* d_kp_xy,
-               float* d_kp_aux, uint8_t* d_desc, uint32_t cap, uint32_t* n_out) {
-  if (n_levels == 0 || n_levels > (uint32_t)kMaxLevels || scale_factor <= 1.f || H < 8 || W < 8 || n_features == 0)
+// d_gray: F frames of H x W u8 on the device (row stride `stride`, frame stride gray_fs bytes). Results stay on the
+// device: frame f's keypoints at row f * cap of the three outputs; n_out[f] is read back.
+int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, size_t gray_fs, const uint8_t* d_mask, uint32_t F, uint32_t H, uint32_t W,
+               uint32_t stride, uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern,
+               float* d_kp_xy, float* d_kp_aux, uint8_t* d_desc, uint32_t cap, uint32_t* n_out) {
+  if (n_levels == 0 || n_levels > (uint32_t)kMaxLevels || scale_factor <= 1.f || H < 8 || W < 8 || n_features == 0 || F == 0 ||
+      F > 65535u)
     return TODHIP_EINVAL;
   if (cap == 0) return TODHIP_ECAPACITY;
   OrbWs* ws = ows_of(ctx);
   hipStream_t st = ctx->stream;
   const size_t px = (size_t)H * W;
   const uint32_t cand_cap = (uint32_t)(px / 4 + 64);
-  TOD_HIP(ws->img[0].reserve(px)); TOD_HIP(ws->img[1].reserve(px));
-  TOD_HIP(ws->blur.reserve(px)); TOD_HIP(ws->tmp.reserve(px)); TOD_HIP(ws->score.reserve(px * sizeof(int)));
-  TOD_HIP(ws->cand.reserve((size_t)cand_cap * sizeof(Cand)));
-  TOD_HIP(ws->eq.reserve((size_t)cand_cap * sizeof(Cand)));
-  TOD_HIP(ws->sel1.reserve((size_t)2 * n_features * sizeof(Cand) + 64));
-  TOD_HIP(ws->sel2.reserve((size_t)n_features * sizeof(Cand) + 64));
-  TOD_HIP(ws->small.reserve(1024 * sizeof(uint32_t)));
+  const uint32_t sel1_cap = 2u * n_features + 16u, sel2_cap = n_features + 16u;
+  TOD_HIP(ws->img[0].reserve(F * px)); TOD_HIP(ws->img[1].reserve(F * px));
+  TOD_HIP(ws->blur.reserve(F * px)); TOD_HIP(ws->tmp.reserve(F * px)); TOD_HIP(ws->score.reserve(F * px * sizeof(int)));
+  TOD_HIP(ws->cand.reserve((size_t)F * cand_cap * sizeof(Cand)));
+  TOD_HIP(ws->eq.reserve((size_t)F * cand_cap * sizeof(Cand)));
+  TOD_HIP(ws->sel1.reserve((size_t)F * sel1_cap * sizeof(Cand)));
+  TOD_HIP(ws->sel2.reserve((size_t)F * sel2_cap * sizeof(Cand)));
+  TOD_HIP(ws->small.reserve((size_t)(F + 1) * kCtlWords * sizeof(uint32_t)));   // + one row of per-frame totals
   TOD_HIP(ws->pattern.reserve(1024));
-  TOD_HIP(ws->h_out.reserve(64));
-  TOD_HIP(ws->o_xy.reserve((size_t)cap * 8)); TOD_HIP(ws->o_aux.reserve((size_t)cap * 16)); TOD_HIP(ws->o_desc.reserve((size_t)cap * 32));
-  if (d_mask) TOD_HIP(ws->maskbuf.reserve(px));
+  TOD_HIP(ws->h_out.reserve((size_t)F * sizeof(uint32_t) + 64));
+  TOD_HIP(ws->o_xy.reserve((size_t)F * cap * 8)); TOD_HIP(ws->o_aux.reserve((size_t)F * cap * 16));
+  TOD_HIP(ws->o_desc.reserve((size_t)F * cap * 32));
+  if (d_mask) TOD_HIP(ws->maskbuf.reserve(F * px));
   float* const u_kp_xy = d_kp_xy; float* const u_kp_aux = d_kp_aux; uint8_t* const u_desc = d_desc;   // the caller's
   d_kp_xy = ws->o_xy.as<float>(); d_kp_aux = ws->o_aux.as<float>(); d_desc = ws->o_desc.as<uint8_t>();
   int8_t hpat[1024];
@@ -393,15 +438,17 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, ui
   }
   uint32_t per_level[kMaxLevels];
   features_per_level(n_features, n_levels, scale_factor, per_level);
-  uint32_t* d_small = ws->small.as<uint32_t>();           // level control words (W_*), [8 + l] level counts
-  TOD_HIP(hipMemsetAsync(d_small, 0, 512 * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, st, d_gray, stride,
-                     ws->img[0].as<uint8_t>(), H, W);
+  uint32_t* d_small = ws->small.as<uint32_t>();           // per frame: level control words (W_*), [8 + l] level counts
+  uint32_t* d_totals = d_small + (size_t)F * kCtlWords;
+  TOD_HIP(hipMemsetAsync(d_small, 0, (size_t)(F + 1) * kCtlWords * sizeof(uint32_t), st));
+  const uint32_t px_blocks = (uint32_t)((px + 255) / 256);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(px_blocks, F), dim3(256), 0, st, d_gray, stride, ws->img[0].as<uint8_t>(), H, W,
+                     gray_fs, px);
   if (d_mask) {
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, st, d_mask, W, ws->maskbuf.as<uint8_t>(), H, W);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(px_blocks, F), dim3(256), 0, st, d_mask, W, ws->maskbuf.as<uint8_t>(), H, W, px, px);
     d_mask = ws->maskbuf.as<uint8_t>();
   }
-  OrbWs::Key key = {H, W, n_features, n_levels, cap, scale_factor, d_kp_xy, d_kp_aux, d_desc, ws->img[0].p, d_mask};
+  OrbWs::Key key = {H, W, n_features, n_levels, cap, F, scale_factor, d_kp_xy, d_kp_aux, d_desc, ws->img[0].p, d_mask};
   static const bool use_graph = getenv("TODHIP_ORB_NO_GRAPH") == nullptr;
   const bool reuse = use_graph && ws->graph_exec && std::memcmp(&key, &ws->key, sizeof(key)) == 0;
   if (!reuse) {
@@ -409,68 +456,66 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, ui
     if (ws->graph) { (void)hipGraphDestroy(ws->graph); ws->graph = nullptr; }
     // thread-local capture: other host threads keep using the runtime while this one records
     if (use_graph) TOD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int cap_rc = TODHIP_OK;
     {
-  DescribeArgs D;
-  disc_umax(D.umax);
-  uint32_t ph = H, pw = W;
-  int cur = 0;
-  for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
-    float scale = 1.f;
-    for (uint32_t i = 0; i < lvl; ++i) scale = scale * scale_factor;
-    const uint32_t w = (uint32_t)rintf((float)W / scale), h = (uint32_t)rintf((float)H / scale);
-    if (lvl > 0) {
-      hipLaunchKernelGGL(resize_kernel, dim3((h * w + 255u) / 256u), dim3(256), 0, st, ws->img[cur].as<uint8_t>(), ph, pw,
-                         ws->img[cur ^ 1].as<uint8_t>(), h, w);
-      cur ^= 1; ph = h; pw = w;
-    }
-    if (h <= 2u * kEdge || w <= 2u * kEdge) continue;     // level count stays 0
-    const uint8_t* img = ws->img[cur].as<uint8_t>();
-    const dim3 grid2((w + 63u) / 64u, (h + 3u) / 4u);
-    const uint32_t want = per_level[lvl];
-    if (want == 0) continue;
-    if (hipMemsetAsync(d_small, 0, 8 * sizeof(uint32_t), st) != hipSuccess) cap_rc = TODHIP_EHIP;
-    if (hipMemsetAsync(d_small + W_HIST, 0, 256 * sizeof(uint32_t), st) != hipSuccess) cap_rc = TODHIP_EHIP;
-    hipLaunchKernelGGL(fast_score_kernel, grid2, dim3(256), 0, st, img, h, w, ws->score.as<int>());
-    hipLaunchKernelGGL(nms_kernel, grid2, dim3(256), 0, st, ws->score.as<int>(), h, w, ws->cand.as<Cand>(), cand_cap, d_small,
-                       d_small + W_HIST, d_mask, H, W);
-    hipLaunchKernelGGL(fast_threshold_kernel, dim3(1), dim3(64), 0, st, d_small, cand_cap, 2u * want);
-    hipLaunchKernelGGL(split_kernel, dim3((cand_cap + 255u) / 256u), dim3(256), 0, st, ws->cand.as<Cand>(), d_small, 2u * want,
-                       ws->sel1.as<Cand>(), ws->eq.as<Cand>());
-    // ties at the threshold: the first need_eq of them in (y, x) order, placed behind the count(> T) sure ones
-    hipLaunchKernelGGL(rank_tiled_kernel, dim3((cand_cap + 255u) / 256u), dim3(256), 0, st, ws->eq.as<Cand>(), d_small + W_NEQ,
-                       d_small + W_NEED_EQ, 0u, 0, ws->sel1.as<Cand>(), d_small + W_NGT, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(harris_kernel, dim3((2u * want + 255u) / 256u), dim3(256), 0, st, img, w, ws->sel1.as<Cand>(), d_small + W_NSEL1);
-    hipLaunchKernelGGL(rank_tiled_kernel, dim3((2u * want + 255u) / 256u), dim3(256), 0, st, ws->sel1.as<Cand>(), d_small + W_NSEL1,
-                       (const uint32_t*)nullptr, want, 1, ws->sel2.as<Cand>(), (const uint32_t*)nullptr, d_small + 8 + lvl);
-    hipLaunchKernelGGL(blur_h_kernel, dim3((h * w + 255u) / 256u), dim3(256), 0, st, img, h, w, ws->tmp.as<uint8_t>());
-    hipLaunchKernelGGL(blur_v_kernel, dim3((h * w + 255u) / 256u), dim3(256), 0, st, ws->tmp.as<uint8_t>(), h, w, ws->blur.as<uint8_t>());
-    D.img = img; D.blur = ws->blur.as<uint8_t>(); D.w = w; D.sel = ws->sel2.as<Cand>(); D.n_sel = d_small + 8 + lvl;
-    D.level_counts = d_small + 8; D.level = lvl; D.scale = scale; D.cap = cap; D.pattern = ws->pattern.as<int8_t>();
-    D.kp_xy = d_kp_xy; D.kp_aux = d_kp_aux; D.desc = d_desc;
-    hipLaunchKernelGGL(describe_kernel, dim3((want + 3u) / 4u), dim3(256), 0, st, D);
-  }
+      DescribeArgs D;
+      disc_umax(D.umax);
+      uint32_t ph = H, pw = W;
+      int cur = 0;
+      for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
+        float scale = 1.f;
+        for (uint32_t i = 0; i < lvl; ++i) scale = scale * scale_factor;
+        const uint32_t w = (uint32_t)rintf((float)W / scale), h = (uint32_t)rintf((float)H / scale);
+        if (lvl > 0) {
+          hipLaunchKernelGGL(resize_kernel, dim3((h * w + 255u) / 256u, F), dim3(256), 0, st, ws->img[cur].as<uint8_t>(), ph, pw,
+                             ws->img[cur ^ 1].as<uint8_t>(), h, w, px);
+          cur ^= 1; ph = h; pw = w;
+        }
+        if (h <= 2u * kEdge || w <= 2u * kEdge) continue;     // level count stays 0
+        const uint8_t* img = ws->img[cur].as<uint8_t>();
+        const dim3 grid2((w + 63u) / 64u, (h + 3u) / 4u, F);
+        const uint32_t want = per_level[lvl];
+        if (want == 0) continue;
+        hipLaunchKernelGGL(level_reset_kernel, dim3(F), dim3(256), 0, st, d_small);
+        hipLaunchKernelGGL(fast_score_kernel, grid2, dim3(256), 0, st, img, h, w, ws->score.as<int>(), px);
+        hipLaunchKernelGGL(nms_kernel, grid2, dim3(256), 0, st, ws->score.as<int>(), h, w, ws->cand.as<Cand>(), cand_cap, d_small,
+                           d_small + W_HIST, d_mask, H, W, px);
+        hipLaunchKernelGGL(fast_threshold_kernel, dim3(F), dim3(64), 0, st, d_small, cand_cap, 2u * want);
+        hipLaunchKernelGGL(split_kernel, dim3((cand_cap + 255u) / 256u, F), dim3(256), 0, st, ws->cand.as<Cand>(), d_small, 2u * want,
+                           ws->sel1.as<Cand>(), ws->eq.as<Cand>(), cand_cap, sel1_cap);
+        // ties at the threshold: the first need_eq of them in (y, x) order, placed behind the count(> T) sure ones
+        hipLaunchKernelGGL(rank_tiled_kernel, dim3((cand_cap + 255u) / 256u, F), dim3(256), 0, st, ws->eq.as<Cand>(), d_small + W_NEQ,
+                           d_small + W_NEED_EQ, 0u, 0, ws->sel1.as<Cand>(), d_small + W_NGT, (uint32_t*)nullptr, cand_cap, sel1_cap);
+        hipLaunchKernelGGL(harris_kernel, dim3((2u * want + 255u) / 256u, F), dim3(256), 0, st, img, w, ws->sel1.as<Cand>(),
+                           d_small + W_NSEL1, px, sel1_cap);
+        hipLaunchKernelGGL(rank_tiled_kernel, dim3((2u * want + 255u) / 256u, F), dim3(256), 0, st, ws->sel1.as<Cand>(), d_small + W_NSEL1,
+                           (const uint32_t*)nullptr, want, 1, ws->sel2.as<Cand>(), (const uint32_t*)nullptr, d_small + 8 + lvl,
+                           sel1_cap, sel2_cap);
+        hipLaunchKernelGGL(blur_h_kernel, dim3((h * w + 255u) / 256u, F), dim3(256), 0, st, img, h, w, ws->tmp.as<uint8_t>(), px);
+        hipLaunchKernelGGL(blur_v_kernel, dim3((h * w + 255u) / 256u, F), dim3(256), 0, st, ws->tmp.as<uint8_t>(), h, w,
+                           ws->blur.as<uint8_t>(), px);
+        D.img = img; D.blur = ws->blur.as<uint8_t>(); D.w = w; D.sel = ws->sel2.as<Cand>(); D.n_sel = d_small + 8 + lvl;
+        D.level_counts = d_small + 8; D.level = lvl; D.scale = scale; D.cap = cap; D.pattern = ws->pattern.as<int8_t>();
+        D.kp_xy = d_kp_xy; D.kp_aux = d_kp_aux; D.desc = d_desc; D.fs = px; D.sel_fs = sel2_cap;
+        hipLaunchKernelGGL(describe_kernel, dim3((want + 3u) / 4u, F), dim3(256), 0, st, D);
+      }
     }
     if (use_graph) {
       hipGraph_t g = nullptr;
       const hipError_t ee = hipStreamEndCapture(st, &g);
-      if (ee != hipSuccess || cap_rc != TODHIP_OK || !g) { ctx->last_hip_error = (int)ee; return TODHIP_EHIP; }
+      if (ee != hipSuccess || !g) { ctx->last_hip_error = (int)ee; return TODHIP_EHIP; }
       ws->graph = g;
       TOD_HIP(hipGraphInstantiate(&ws->graph_exec, ws->graph, nullptr, nullptr, 0));
       ws->key = key;
-    } else if (cap_rc != TODHIP_OK) {
-      return cap_rc;
     }
   }
   if (use_graph) TOD_HIP(hipGraphLaunch(ws->graph_exec, st));
-  hipLaunchKernelGGL(copy_out_kernel, dim3((8u * cap + 255u) / 256u), dim3(256), 0, st, d_small + 8, n_levels, cap, d_kp_xy, d_kp_aux,
-                     reinterpret_cast<const uint32_t*>(d_desc), u_kp_xy, u_kp_aux, reinterpret_cast<uint32_t*>(u_desc));
-  uint32_t* h_counts = ws->h_out.as<uint32_t>();
-  TOD_HIP(hipMemcpyAsync(h_counts, d_small + 8, kMaxLevels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(copy_out_kernel, dim3((8u * cap + 255u) / 256u, F), dim3(256), 0, st, d_small + 8, n_levels, cap, d_kp_xy, d_kp_aux,
+                     reinterpret_cast<const uint32_t*>(d_desc), u_kp_xy, u_kp_aux, reinterpret_cast<uint32_t*>(u_desc), d_totals);
+  TOD_HIP(hipGetLastError());
+  uint32_t* h_totals = ws->h_out.as<uint32_t>();
+  TOD_HIP(hipMemcpyAsync(h_totals, d_totals, (size_t)F * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   TOD_HIP(hipStreamSynchronize(st));
-  uint32_t total = 0;
-  for (uint32_t l = 0; l < n_levels; ++l) total += h_counts[l];
-  *n_out = std::min(total, cap);
+  for (uint32_t f = 0; f < F; ++f) n_out[f] = std::min(h_totals[f], cap);
   return TODHIP_OK;
 }
 
@@ -480,7 +525,7 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, ui
 int tod_orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, uint32_t H, uint32_t W, uint32_t stride,
                    uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, float* d_kp_xy,
                    float* d_kp_aux, uint8_t* d_desc, uint32_t cap, uint32_t* n_out) {
-  return orb_device(ctx, d_gray, d_mask, H, W, stride, n_features, n_levels, scale_factor, pattern, d_kp_xy, d_kp_aux, d_desc,
+  return orb_device(ctx, d_gray, 0, d_mask, 1, H, W, stride, n_features, n_levels, scale_factor, pattern, d_kp_xy, d_kp_aux, d_desc,
                     cap, n_out);
 }
 
@@ -507,9 +552,21 @@ int todhip_orb_device(todhip_ctx* ctx, const void* d_gray, uint32_t H, uint32_t 
   TOD_HIP(hipSetDevice(ctx->device));
   const uint32_t cap = *n_out;
   *n_out = 0;
-  return orb_device(ctx, reinterpret_cast<const uint8_t*>(d_gray), nullptr, H, W, stride, n_features, n_levels, scale_factor, pattern,
-                    reinterpret_cast<float*>(d_kp_xy), reinterpret_cast<float*>(d_kp_aux), reinterpret_cast<uint8_t*>(d_desc),
-                    cap, n_out);
+  return orb_device(ctx, reinterpret_cast<const uint8_t*>(d_gray), 0, nullptr, 1, H, W, stride, n_features, n_levels, scale_factor,
+                    pattern, reinterpret_cast<float*>(d_kp_xy), reinterpret_cast<float*>(d_kp_aux),
+                    reinterpret_cast<uint8_t*>(d_desc), cap, n_out);
+}
+
+int todhip_orb_batch_device(todhip_ctx* ctx, const void* d_gray, uint32_t n_frames, uint64_t frame_stride, uint32_t H, uint32_t W,
+                            uint32_t stride, uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern,
+                            void* d_kp_xy, void* d_kp_aux, void* d_desc, uint32_t cap, uint32_t* n_out) {
+  if (!ctx || !d_gray || !d_kp_xy || !d_kp_aux || !d_desc || !n_out || stride < W || n_frames == 0) return TODHIP_EINVAL;
+  if (n_frames > 1 && frame_stride < (uint64_t)H * stride) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  for (uint32_t f = 0; f < n_frames; ++f) n_out[f] = 0;
+  return orb_device(ctx, reinterpret_cast<const uint8_t*>(d_gray), (size_t)frame_stride, nullptr, n_frames, H, W, stride, n_features,
+                    n_levels, scale_factor, pattern, reinterpret_cast<float*>(d_kp_xy), reinterpret_cast<float*>(d_kp_aux),
+                    reinterpret_cast<uint8_t*>(d_desc), cap, n_out);
 }
 
 int todhip_orb(todhip_ctx* ctx, const uint8_t* gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
@@ -525,7 +582,7 @@ int todhip_orb(todhip_ctx* ctx, const uint8_t* gray, uint32_t H, uint32_t W, uin
   TOD_HIP(ws->kp_xy.reserve((size_t)cap * 8)); TOD_HIP(ws->kp_aux.reserve((size_t)cap * 16)); TOD_HIP(ws->desc.reserve((size_t)cap * 32));
   TOD_HIP(hipMemcpyAsync(ws->in_img.p, gray, (size_t)H * stride, hipMemcpyHostToDevice, ctx->stream));
   uint32_t n = 0;
-  const int rc = orb_device(ctx, ws->in_img.as<uint8_t>(), nullptr, H, W, stride, n_features, n_levels, scale_factor, pattern,
+  const int rc = orb_device(ctx, ws->in_img.as<uint8_t>(), 0, nullptr, 1, H, W, stride, n_features, n_levels, scale_factor, pattern,
                             ws->kp_xy.as<float>(), ws->kp_aux.as<float>(), ws->desc.as<uint8_t>(), cap, &n);
   if (rc != TODHIP_OK) return rc;
   if (n) {
