@@ -135,6 +135,24 @@ int todhip_verify_device_depth(todhip_ctx*, const void* d_kp_xy, uint32_t nq, co
                                const todhip_verify_params*, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
                                uint32_t* inlier_kp, uint32_t* n_inlier_kp);
 
+/* A batch of n_frames frames through GuessGenerator::process in the launches and host round trips of one frame.
+ * Inputs are the per-frame arrays of todhip_verify_device[_depth] back to back (frame f at f times the per-frame size:
+ * d_kp_xy[n_frames*nq*2], cloud [n_frames*H*W*3] or depth [n_frames*H*W], d_counts[n_frames*nq], d_matches[n_frames*nq*k],
+ * d_matches_xyz[n_frames*nq*k*3] -- what todhip_match_device yields for n_frames*nq queries); a frame with fewer
+ * than nq keypoints pads with counts 0. rng[n_frames]: one generator per frame (decision D4), each advanced as
+ * the single-frame call would. Poses of frame f: poses[pose_ptr[f] .. pose_ptr[f+1]) (pose_ptr[n_frames+1]);
+ * inlier_begin/end index the shared inlier_kp array. Each frame's result equals the single-frame call's. */
+int todhip_verify_batch_device(todhip_ctx*, uint32_t n_frames, const void* d_kp_xy, uint32_t nq, const void* d_cloud_xyz,
+                               uint32_t H, uint32_t W, const void* d_counts, const void* d_matches, const void* d_matches_xyz,
+                               uint32_t k, const float* spans, uint32_t n_objs, const todhip_verify_params*, todhip_rng* rng,
+                               todhip_pose* poses, uint32_t* n_poses, uint32_t* pose_ptr, uint32_t* inlier_kp,
+                               uint32_t* n_inlier_kp);
+int todhip_verify_batch_device_depth(todhip_ctx*, uint32_t n_frames, const void* d_kp_xy, uint32_t nq, const void* d_depth,
+                                     int depth_is_u16, uint32_t H, uint32_t W, const float* K9, const void* d_counts,
+                                     const void* d_matches, const void* d_matches_xyz, uint32_t k, const float* spans,
+                                     uint32_t n_objs, const todhip_verify_params*, todhip_rng* rng, todhip_pose* poses,
+                                     uint32_t* n_poses, uint32_t* pose_ptr, uint32_t* inlier_kp, uint32_t* n_inlier_kp);
+
 /* ---- stage A: ORB features (ecto_opencv FeatureDescriptor -> cv::ORB; detector.py:10,27) --------- */
 /* gray: H x W u8, row stride `stride`. Outputs up to n_features keypoints: kp_xy (x,y level-0 pixels),
  * kp_aux (size, angle_deg, response, octave) and 32-byte rBRIEF descriptors. *n_out: capacity in, count out.

@@ -346,3 +346,89 @@ def test_depth_image_form_equals_cloud_form(ctx, u16):
                                 d_m.data_ptr(), d_xyz.data_ptr(), k, spans, 8, 1000, 0.01, r2)
     assert len(a) == len(b) == 1 and r1.draws == r2.draws
     assert np.array_equal(a[0]["inliers"], b[0]["inliers"]) and np.array_equal(a[0]["R"], b[0]["R"]) and np.array_equal(a[0]["t"], b[0]["t"])
+
+
+def _pack_scene(sc, k):
+    nq = len(sc["kp_xy"])
+    counts = np.diff(sc["row_ptr"].astype(np.int64)).astype(np.int32)
+    m = np.zeros((nq, k), capi.DMATCH_DTYPE)
+    xyz = np.zeros((nq, k, 3), np.float32)
+    for q in range(nq):
+        lo, hi = int(sc["row_ptr"][q]), int(sc["row_ptr"][q + 1])
+        m[q, :hi - lo] = sc["matches"][lo:hi]
+        xyz[q, :hi - lo] = sc["matches_xyz"][lo:hi]
+    return counts, m.view(np.int32).reshape(nq * k, 4).copy(), xyz.reshape(nq * k, 3)
+
+
+def test_batch_of_frames_equals_frame_by_frame(ctx):
+    """todhip_verify_batch_device: frames at different points of their RANSAC state machines share launches; every
+    frame's poses, inliers, traces and generator state must equal the single-frame call's. Frames: one object, two
+    objects (several rounds each), three objects, and one frame without any match."""
+    import torch
+    k, nq, seed = 5, 400, 500
+    vis = [((1, 0.30),), ((1, 0.30), (4, 0.20)), ((2, 0.2), (5, 0.2), (3, 0.2)), ((0, 0.5),)]
+    scenes = [synth.make_verify_scene(nq, visible=v, seed=seed) for v in vis]
+    assert all(np.array_equal(s["spans"], scenes[0]["spans"]) for s in scenes)
+    packed = [_pack_scene(s, k) for s in scenes]
+    packed.append((np.zeros(nq, np.int32), packed[0][1], packed[0][2]))            # a frame whose queries matched nothing
+    scenes.append(scenes[0])
+    F = len(scenes)
+    d_kp = torch.from_numpy(np.stack([s["kp_xy"] for s in scenes]).astype(np.float32)).cuda()
+    d_cloud = torch.from_numpy(np.stack([s["cloud"] for s in scenes]).astype(np.float32)).cuda()
+    d_counts = torch.from_numpy(np.stack([p[0] for p in packed])).cuda()
+    d_m = torch.from_numpy(np.stack([p[1] for p in packed])).cuda()
+    d_xyz = torch.from_numpy(np.stack([p[2] for p in packed])).cuda()
+    torch.cuda.synchronize()
+    spans = scenes[0]["spans"]
+    want, want_rng, want_tr = [], [], []
+    for f in range(F):
+        r = capi.rng_new(1 + f)
+        want.append(ctx.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), 480, 640, d_counts[f].data_ptr(),
+                                      d_m[f].data_ptr(), d_xyz[f].data_ptr(), k, spans, 8, 400, 0.01, r))
+        want_rng.append((r.draws, list(r.s)))
+        want_tr += [(t.object, t.iterations, t.best_iteration, t.best_count, t.draws_after) for t in ctx.verify_trace()]
+    rngs = (capi.Rng * F)(*[capi.rng_new(1 + f) for f in range(F)])
+    got = ctx.verify_batch_device(F, d_kp.data_ptr(), nq, d_cloud.data_ptr(), 480, 640, d_counts.data_ptr(), d_m.data_ptr(),
+                                  d_xyz.data_ptr(), k, spans, 8, 400, 0.01, rngs)
+    got_tr = [(t.object, t.iterations, t.best_iteration, t.best_count, t.draws_after) for t in ctx.verify_trace()]
+    assert got_tr == want_tr
+    assert [len(p) for p in got] == [len(p) for p in want] and min(len(p) for p in got[:4]) >= 1 and got[4] == []
+    for f in range(F):
+        assert (rngs[f].draws, list(rngs[f].s)) == want_rng[f]
+        for a, b in zip(got[f], want[f]):
+            assert a["object"] == b["object"] and np.array_equal(a["inliers"], b["inliers"])
+            assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])
+
+
+def test_batch_depth_form_after_batched_matching(ctx):
+    """The bench path: one match_device call for F x Q queries, then verify_batch_device_depth on its outputs ==
+    the oracle frame by frame."""
+    import torch
+    desc, pts, off = synth.make_db(6, per_object=2000)
+    F, nq, k, H, W, f = 3, 500, 2, 480, 640, 525.0
+    frames = [synth.make_frame(desc, pts, off, nq, frame=30 + i, visible_object=(1, 4, 2)[i]) for i in range(F)]
+    K = np.array([[f, 0, W / 2.0], [0, f, H / 2.0], [0, 0, 1]], np.float32)
+    depth = np.stack([fr["cloud"][:, :, 2] for fr in frames]).astype(np.float32)
+    u, v = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    spans = ctx.db_load(desc, pts, off)
+    d_q = torch.from_numpy(np.stack([fr["q_desc"] for fr in frames])).cuda()
+    d_counts = torch.empty(F * nq, dtype=torch.int32, device="cuda")
+    d_m = torch.empty((F * nq * k, 4), dtype=torch.int32, device="cuda")
+    d_xyz = torch.empty((F * nq * k, 3), dtype=torch.float32, device="cuda")
+    d_kp = torch.from_numpy(np.stack([fr["kp_xy"] for fr in frames])).cuda()
+    d_depth = torch.from_numpy(depth).cuda()
+    torch.cuda.synchronize()
+    ctx.match_device(d_q.data_ptr(), F * nq, k, 35, d_counts.data_ptr(), d_m.data_ptr(), d_xyz.data_ptr())
+    rngs = (capi.Rng * F)(*[capi.rng_new(1) for _ in range(F)])
+    got = ctx.verify_batch_device(F, d_kp.data_ptr(), nq, 0, H, W, d_counts.data_ptr(), d_m.data_ptr(), d_xyz.data_ptr(), k,
+                                  spans, 8, 2500, 0.01, rngs, depth=(d_depth.data_ptr(), False, K))
+    for i, fr in enumerate(frames):
+        z = depth[i]
+        cloud = np.stack([(u - K[0, 2]) * z / K[0, 0], (v - K[1, 2]) * z / K[1, 1], z], axis=2).astype(np.float32)
+        rc, row_ptr, m, xyz = O.match(desc, off, pts, fr["q_desc"], k, 35)
+        rng_o = O.rng_new(1)
+        rc, o_poses, _ = O.verify(fr["kp_xy"], cloud, row_ptr, m, xyz, O.spans(pts, off), 8, 2500, 0.01, rng_o)
+        assert rngs[i].draws == rng_o.draws and len(got[i]) == len(o_poses) == 1
+        assert got[i][0]["object"] == o_poses[0]["object"] == (1, 4, 2)[i]
+        assert np.array_equal(got[i][0]["inliers"], o_poses[0]["inliers"])
+        assert np.abs(got[i][0]["R"] - o_poses[0]["R"]).max() < POSE_TOL and np.abs(got[i][0]["t"] - o_poses[0]["t"]).max() < POSE_TOL

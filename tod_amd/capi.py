@@ -57,6 +57,7 @@ EXPORTS = [
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
     "todhip_orb_device", "todhip_verify_device_depth", "todhip_orb_batch_device",
+    "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
     "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
 ]
 
@@ -269,6 +270,43 @@ class Context:
         return [dict(object=int(poses[i].object), R=np.array(poses[i].R[:], np.float32).reshape(3, 3),
                      t=np.array(poses[i].t[:], np.float32),
                      inliers=inl[poses[i].inlier_begin:poses[i].inlier_end].copy()) for i in range(n_poses.value)]
+
+    def verify_batch_device(self, n_frames, d_kp_xy, nq, d_cloud, H, W, d_counts, d_matches, d_xyz, k, spans, min_inliers,
+                            n_iter, err, rngs, max_poses=16, depth=None):
+        """rngs: ctypes array (Rng * n_frames). depth = (d_depth, is_u16, K) selects the depth form (d_cloud ignored).
+        Returns a list (per frame) of lists of pose dicts."""
+        sp = np.ascontiguousarray(spans, np.float32)
+        prm = VerifyParams(min_inliers, n_iter, err)
+        cap_p = max_poses * n_frames
+        poses = (Pose * cap_p)()
+        n_poses = C.c_uint32(cap_p)
+        pose_ptr = (C.c_uint32 * (n_frames + 1))()
+        cap = max(nq, 1) * cap_p
+        inl = np.zeros(cap, np.uint32)
+        n_inl = C.c_uint32(cap)
+        if depth is None:
+            rc = lib().todhip_verify_batch_device(self._h, C.c_uint32(n_frames), C.c_void_p(d_kp_xy), C.c_uint32(nq),
+                                                  C.c_void_p(d_cloud), C.c_uint32(H), C.c_uint32(W), C.c_void_p(d_counts),
+                                                  C.c_void_p(d_matches), C.c_void_p(d_xyz), C.c_uint32(k), _np_ptr(sp),
+                                                  C.c_uint32(len(sp)), C.byref(prm), rngs, poses, C.byref(n_poses), pose_ptr,
+                                                  _np_ptr(inl), C.byref(n_inl))
+        else:
+            d_depth, is_u16, K = depth
+            K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+            rc = lib().todhip_verify_batch_device_depth(self._h, C.c_uint32(n_frames), C.c_void_p(d_kp_xy), C.c_uint32(nq),
+                                                        C.c_void_p(d_depth), C.c_int(1 if is_u16 else 0), C.c_uint32(H),
+                                                        C.c_uint32(W), _np_ptr(K9), C.c_void_p(d_counts), C.c_void_p(d_matches),
+                                                        C.c_void_p(d_xyz), C.c_uint32(k), _np_ptr(sp), C.c_uint32(len(sp)),
+                                                        C.byref(prm), rngs, poses, C.byref(n_poses), pose_ptr, _np_ptr(inl),
+                                                        C.byref(n_inl))
+        _check(rc, "todhip_verify_batch_device")
+        out = []
+        for f in range(n_frames):
+            out.append([dict(object=int(poses[i].object), R=np.array(poses[i].R[:], np.float32).reshape(3, 3),
+                             t=np.array(poses[i].t[:], np.float32),
+                             inliers=inl[poses[i].inlier_begin:poses[i].inlier_end].copy())
+                        for i in range(pose_ptr[f], pose_ptr[f + 1])])
+        return out
 
     def verify_trace(self, cap=4096):
         arr = (RoundTrace * cap)()

@@ -31,12 +31,38 @@ using namespace tod;
 
 namespace {
 
+// Every kernel takes up to kMaxSlots argument sets and picks its own with the last grid dimension: the frames of a
+// batch (each at its own point of its own RANSAC state machine) share launches, so a batch costs the launches and
+// host round trips of one frame.
+constexpr uint32_t kMaxSlots = 16;                         // 16 x 200 B of EvalArgs stays under the 4 KB kernarg limit
+template <class A> struct Slots { A a[kMaxSlots]; };
+
+struct AdjArgs { ObjJob job; float span, err; };
+struct JobArgs { ObjJob job; };
+struct PrepArgs { ObjJob job; uint32_t* nvalid; };
+struct DrawArgs { ObjJob job; const uint32_t* rnd; uint32_t window_len, S; DrawEntry* table; };
+struct ChainArgs {
+  const DrawEntry* table; uint32_t S, n_req, attempts0, out_base;
+  uint32_t* iter_samples; uint32_t* iter_pos_after; ChainOut* out;
+};
+struct CopyArgs { const uint32_t* src; uint32_t* dst; uint32_t n; };   // src == nullptr: zero fill
+
+// words from one address space to another (device <-> device-visible pinned host memory) or zero fill: the
+// host's mailbox traffic rides in kernels, so a tick of the batch engine is launches + ONE stream synchronize
+__global__ __launch_bounds__(256) void copy_words_kernel(Slots<CopyArgs> S) {
+  const CopyArgs& a = S.a[blockIdx.y];
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += gridDim.x * 256u) a.dst[i] = a.src ? a.src[i] : 0u;
+}
+
 #define TOD_DBG(...) do { if (getenv("TODHIP_DEBUG")) { fprintf(stderr, "[todhip] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 // ------------------------------------------------------------------------------------------------ K6
-__global__ __launch_bounds__(256) void adjacency_kernel(ObjJob job, float span, float err) {
+__global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs> S) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const ObjJob& job = S.a[blockIdx.z].job;
+  const float span = S.a[blockIdx.z].span, err = S.a[blockIdx.z].err;
   const uint32_t i = blockIdx.x;
+  if (i >= job.n) return;
   const uint32_t word = blockIdx.y * 4u + (threadIdx.x >> 6);
   if (word >= job.W) return;
   const uint32_t j = word * 64u + lane_id();
@@ -67,8 +93,9 @@ __global__ __launch_bounds__(256) void adjacency_kernel(ObjJob job, float span, 
   }
 }
 
-__global__ __launch_bounds__(256) void finite_kernel(ObjJob job) {
+__global__ __launch_bounds__(256) void finite_kernel(Slots<JobArgs> S) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const ObjJob& job = S.a[blockIdx.y].job;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   bool f = false;
   if (v < job.n) {
@@ -85,8 +112,10 @@ __global__ __launch_bounds__(256) void finite_kernel(ObjJob job) {
 }
 
 // per round: sample degree inside the valid set, the ">= 7" filter mask (:211-213), |valid|
-__global__ __launch_bounds__(256) void round_prep_kernel(ObjJob job, uint32_t* nvalid) {
+__global__ __launch_bounds__(256) void round_prep_kernel(Slots<PrepArgs> S) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const ObjJob& job = S.a[blockIdx.y].job;
+  uint32_t* const nvalid = S.a[blockIdx.y].nvalid;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   bool isv = false;
   uint32_t d = 0;
@@ -104,9 +133,12 @@ __global__ __launch_bounds__(256) void round_prep_kernel(ObjJob job, uint32_t* n
 }
 
 // ------------------------------------------------------------------------------------------------ K7a
-__global__ __launch_bounds__(256) void draw_table_kernel(ObjJob job, const uint32_t* __restrict__ rnd,
-                                                         uint32_t window_len, uint32_t S, DrawEntry* table) {
+__global__ __launch_bounds__(256) void draw_table_kernel(Slots<DrawArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const ObjJob& job = SL.a[blockIdx.y].job;
+  const uint32_t* __restrict__ rnd = SL.a[blockIdx.y].rnd;
+  const uint32_t window_len = SL.a[blockIdx.y].window_len, S = SL.a[blockIdx.y].S;
+  DrawEntry* const table = SL.a[blockIdx.y].table;
   const uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (s >= S) return;
   const uint32_t W = job.W;
@@ -152,10 +184,13 @@ __global__ __launch_bounds__(256) void draw_table_kernel(ObjJob job, const uint3
 }
 
 // ------------------------------------------------------------------------------------------------ K7b
-__global__ void chain_kernel(const DrawEntry* __restrict__ table, uint32_t S, uint32_t n_req, uint32_t attempts0,
-                             uint32_t out_base, uint32_t* iter_samples, uint32_t* iter_pos_after, ChainOut* out) {
+__global__ void chain_kernel(Slots<ChainArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (threadIdx.x != 0) return;
+  const ChainArgs& a = SL.a[blockIdx.x];
+  const DrawEntry* __restrict__ table = a.table;
+  const uint32_t S = a.S, n_req = a.n_req, attempts0 = a.attempts0, out_base = a.out_base;
+  uint32_t* const iter_samples = a.iter_samples; uint32_t* const iter_pos_after = a.iter_pos_after; ChainOut* const out = a.out;
   uint32_t p = 0, done = 0, attempts = attempts0, flag = 0;
   while (done < n_req) {
     bool got = false;
@@ -706,8 +741,9 @@ struct EvalArgs {
 
 // launched with 64 threads; the bound is deliberately larger so that hipcc keeps __syncthreads() as a real,
 // convergent s_barrier (with a 64-thread bound it drops the barrier and may split the lanes of the wave)
-__global__ __launch_bounds__(128) void eval_kernel(EvalArgs A) {
+__global__ __launch_bounds__(128) void eval_kernel(Slots<EvalArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const EvalArgs& A = SL.a[blockIdx.y];
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const uint32_t l = lane_id();
   const ObjJob& job = A.job;
@@ -1012,10 +1048,19 @@ struct GrowthOut {
 // One block. inl/rest/extra are W-word bitsets in global scratch. Sums that the reference accumulates
 // sequentially (centroids in float, the correlation matrix in double) are accumulated sequentially here too,
 // each by one lane, so that the admitted sets are reproducible bit for bit against a sequential CPU evaluation.
-__global__ __launch_bounds__(256) void growth_kernel(ObjJob job, uint32_t s0, uint32_t s1, uint32_t s2, float err,
-                                                     u64* inl, u64* rest, u64* extra, uint32_t* kp_list,
-                                                     u64* kp_bits, uint32_t kp_words, GrowthOut* out) {
+struct GrowthArgs {
+  ObjJob job; const uint32_t* triple; float err;          // triple: the winning iteration's samples (device)
+  u64 *inl, *rest, *extra; uint32_t* kp_list; u64* kp_bits; uint32_t kp_words; GrowthOut* out;
+};
+__global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const GrowthArgs& ga = SL.a[blockIdx.x];
+  const ObjJob& job = ga.job;
+  const uint32_t s0 = ga.triple[0], s1 = ga.triple[1], s2 = ga.triple[2];
+  const float err = ga.err;
+  u64* const inl = ga.inl; u64* const rest = ga.rest; u64* const extra = ga.extra;
+  uint32_t* const kp_list = ga.kp_list; u64* const kp_bits = ga.kp_bits; const uint32_t kp_words = ga.kp_words;
+  GrowthOut* const out = ga.out;
   __shared__ float sR[9], sT[3];
   __shared__ double sAcc[16];
   __shared__ float sC[6];
@@ -1194,8 +1239,11 @@ __global__ __launch_bounds__(256) void growth_kernel(ObjJob job, uint32_t s0, ui
 // ------------------------------------------------------------------------------------------------ K11
 // InvalidateQueryIndices (adjacency_ransac.cpp:93-123): drop every valid match whose keypoint is an inlier
 // keypoint, then InvalidateIndices (:63-89): repeatedly drop valid matches whose sample degree is < 3.
-__global__ __launch_bounds__(1024) void invalidate_kernel(ObjJob job, const u64* kp_bits, u64* scratch) {
+struct InvArgs { ObjJob job; const u64* kp_bits; u64* scratch; };
+__global__ __launch_bounds__(1024) void invalidate_kernel(Slots<InvArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const ObjJob& job = SL.a[blockIdx.x].job;
+  const u64* const kp_bits = SL.a[blockIdx.x].kp_bits; u64* const scratch = SL.a[blockIdx.x].scratch;
   __shared__ uint32_t sAny;
   const uint32_t tid = threadIdx.x, W = job.W, n = job.n;
   if (tid == 0) sAny = 0u;
@@ -1237,58 +1285,51 @@ __global__ __launch_bounds__(1024) void invalidate_kernel(ObjJob job, const u64*
 // fixed-stride layout (k slots per query, counts[q] used); the flat order (query asc, rank asc) is what the
 // reference's push_back order produces, and grouping by object is stable, so query_indices_ stays
 // non-decreasing per object (App. A Q4).
-__global__ __launch_bounds__(256) void cluster_lookup_kernel(const float* __restrict__ kp_xy, uint32_t nq,
-                                                             const float* __restrict__ cloud, uint32_t H, uint32_t Wimg,
-                                                             const uint32_t* __restrict__ counts, uint32_t* kept,
-                                                             float* qpt, uint32_t* err) {
+struct LookupArgs {
+  const float* kp_xy; uint32_t nq; const float* cloud; const void* depth; int depth_is_u16; uint32_t H, Wimg;
+  float fx, fy, cx, cy; const uint32_t* counts; uint32_t* kept; float* qpt; uint32_t* err;
+};
+// cloud != nullptr: the query point is read from the H x W x 3 cloud (adjacency_ransac.cpp:184-185).
+// Otherwise N3: the reference back-projects the WHOLE registered depth image to an H x W x 3 cloud
+// (ecto_opencv DepthTo3d, python/object_recognition_tod/detector.py:26,62,66-69) and then reads Q points of it.
+// Here the Q points are computed directly: same pixel truncation, same pinhole back-projection as cv::depthTo3d
+// (x = (u - cx) z / fx, y = (v - cy) z / fy), uint16 depth in millimetres with 0 = no measurement -> NaN as
+// cv::rescaleDepth does (third-party conventions, recalled; parity unpinned).
+__global__ __launch_bounds__(256) void cluster_lookup_kernel(Slots<LookupArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const LookupArgs& a = SL.a[blockIdx.y];
   const uint32_t q = blockIdx.x * 256u + threadIdx.x;
-  if (q >= nq) return;
-  const int row = (int)kp_xy[2 * q + 1], col = (int)kp_xy[2 * q];        // float -> int truncation (:185)
-  if (row < 0 || col < 0 || (uint32_t)row >= H || (uint32_t)col >= Wimg) {
-    atomicExch(err, 1u);
-    kept[q] = 0;
+  if (q >= a.nq) return;
+  const int row = (int)a.kp_xy[2 * q + 1], col = (int)a.kp_xy[2 * q];    // float -> int truncation (:185)
+  if (row < 0 || col < 0 || (uint32_t)row >= a.H || (uint32_t)col >= a.Wimg) {
+    atomicExch(a.err, 1u);
+    a.kept[q] = 0;
     return;
   }
-  const float* p = cloud + 3 * ((size_t)row * Wimg + col);
-  qpt[3 * q] = p[0]; qpt[3 * q + 1] = p[1]; qpt[3 * q + 2] = p[2];
-  kept[q] = isnan(p[0]) ? 0u : counts[q];                                // only .x is tested (:189)
-}
-
-// N3: the reference back-projects the WHOLE registered depth image to an H x W x 3 cloud
-// (ecto_opencv DepthTo3d, python/object_recognition_tod/detector.py:26,62,66-69) and then reads Q points of it
-// (adjacency_ransac.cpp:184-185). Here the Q points are computed directly: same pixel truncation, same pinhole
-// back-projection as cv::depthTo3d (x = (u - cx) z / fx, y = (v - cy) z / fy), uint16 depth in millimetres with 0 = no
-// measurement -> NaN as cv::rescaleDepth does (third-party conventions, recalled; parity unpinned).
-__global__ __launch_bounds__(256) void cluster_lookup_depth_kernel(const float* __restrict__ kp_xy, uint32_t nq,
-                                                                   const void* __restrict__ depth, int depth_is_u16,
-                                                                   uint32_t H, uint32_t Wimg, float fx, float fy, float cx,
-                                                                   float cy, const uint32_t* __restrict__ counts,
-                                                                   uint32_t* kept, float* qpt, uint32_t* err) {
-  __builtin_amdgcn_s_setprio(3);
-  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
-  if (q >= nq) return;
-  const int row = (int)kp_xy[2 * q + 1], col = (int)kp_xy[2 * q];
-  if (row < 0 || col < 0 || (uint32_t)row >= H || (uint32_t)col >= Wimg) {
-    atomicExch(err, 1u);
-    kept[q] = 0;
-    return;
-  }
-  float z;
-  if (depth_is_u16) {
-    const uint16_t d = reinterpret_cast<const uint16_t*>(depth)[(size_t)row * Wimg + col];
-    z = d == 0 ? __builtin_nanf("") : (float)d * 0.001f;
+  float x, y, z;
+  if (a.cloud) {
+    const float* p = a.cloud + 3 * ((size_t)row * a.Wimg + col);
+    x = p[0]; y = p[1]; z = p[2];
   } else {
-    z = reinterpret_cast<const float*>(depth)[(size_t)row * Wimg + col];
+    if (a.depth_is_u16) {
+      const uint16_t d = reinterpret_cast<const uint16_t*>(a.depth)[(size_t)row * a.Wimg + col];
+      z = d == 0 ? __builtin_nanf("") : (float)d * 0.001f;
+    } else {
+      z = reinterpret_cast<const float*>(a.depth)[(size_t)row * a.Wimg + col];
+    }
+    x = ((float)col - a.cx) * z / a.fx; y = ((float)row - a.cy) * z / a.fy;
   }
-  const float x = ((float)col - cx) * z / fx, y = ((float)row - cy) * z / fy;
-  qpt[3 * q] = x; qpt[3 * q + 1] = y; qpt[3 * q + 2] = z;
-  kept[q] = isnan(x) ? 0u : counts[q];
+  a.qpt[3 * q] = x; a.qpt[3 * q + 1] = y; a.qpt[3 * q + 2] = z;
+  a.kept[q] = isnan(x) ? 0u : a.counts[q];                               // only .x is tested (:189)
 }
 
 // exclusive scan of kept[0..nq) into offs[0..nq], one block
-__global__ __launch_bounds__(1024) void cluster_scan_kernel(const uint32_t* __restrict__ kept, uint32_t nq, uint32_t* offs) {
+struct ScanArgs { const uint32_t* kept; uint32_t nq; uint32_t* offs; };
+__global__ __launch_bounds__(1024) void cluster_scan_kernel(Slots<ScanArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const uint32_t* __restrict__ kept = SL.a[blockIdx.x].kept;
+  const uint32_t nq = SL.a[blockIdx.x].nq;
+  uint32_t* const offs = SL.a[blockIdx.x].offs;
   __shared__ uint32_t part[1024];
   const uint32_t tid = threadIdx.x;
   const uint32_t chunk = (nq + 1023u) / 1024u;
@@ -1307,15 +1348,19 @@ __global__ __launch_bounds__(1024) void cluster_scan_kernel(const uint32_t* __re
   for (uint32_t i = lo; i < hi; ++i) { offs[i] = acc; acc += kept[i]; }
 }
 
-__global__ __launch_bounds__(256) void cluster_scatter_kernel(const float* __restrict__ kp_xy, uint32_t nq, uint32_t k,
-                                                              const todhip_dmatch* __restrict__ matches,
-                                                              const float* __restrict__ mxyz,
-                                                              const uint32_t* __restrict__ kept,
-                                                              const uint32_t* __restrict__ offs,
-                                                              const float* __restrict__ qpt, uint32_t n_objs,
-                                                              uint32_t* obj_of, uint32_t* hist, float* ftrain,
-                                                              float* fquery, uint32_t* fqidx, float* fkp, uint32_t* err) {
+struct ScatterArgs {
+  const float* kp_xy; uint32_t nq, k; const todhip_dmatch* matches; const float* mxyz; const uint32_t* kept;
+  const uint32_t* offs; const float* qpt; uint32_t n_objs; uint32_t* obj_of; uint32_t* hist; float* ftrain; float* fquery;
+  uint32_t* fqidx; float* fkp; uint32_t* err;
+};
+__global__ __launch_bounds__(256) void cluster_scatter_kernel(Slots<ScatterArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const ScatterArgs& a = SL.a[blockIdx.y];
+  const float* __restrict__ kp_xy = a.kp_xy; const uint32_t nq = a.nq, k = a.k, n_objs = a.n_objs;
+  const todhip_dmatch* __restrict__ matches = a.matches; const float* __restrict__ mxyz = a.mxyz;
+  const uint32_t* __restrict__ kept = a.kept; const uint32_t* __restrict__ offs = a.offs; const float* __restrict__ qpt = a.qpt;
+  uint32_t* const obj_of = a.obj_of; uint32_t* const hist = a.hist; float* const ftrain = a.ftrain; float* const fquery = a.fquery;
+  uint32_t* const fqidx = a.fqidx; float* const fkp = a.fkp; uint32_t* const err = a.err;
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t q = t / k, j = t % k;
   if (q >= nq || j >= kept[q]) return;
@@ -1331,14 +1376,18 @@ __global__ __launch_bounds__(256) void cluster_scatter_kernel(const float* __res
 }
 
 // stable grouping by object: destination = group offset + number of earlier matches of the same object
-__global__ __launch_bounds__(256) void cluster_group_kernel(uint32_t n_all, const uint32_t* __restrict__ obj_of,
-                                                            const uint32_t* __restrict__ goff,
-                                                            const float* __restrict__ ftrain,
-                                                            const float* __restrict__ fquery,
-                                                            const uint32_t* __restrict__ fqidx,
-                                                            const float* __restrict__ fkp, float* train, float* query,
-                                                            uint32_t* qidx, float* kpxy) {
+struct GroupArgs {
+  uint32_t n_all; const uint32_t* obj_of; const uint32_t* goff; const float* ftrain; const float* fquery;
+  const uint32_t* fqidx; const float* fkp; float* train; float* query; uint32_t* qidx; float* kpxy;
+};
+__global__ __launch_bounds__(256) void cluster_group_kernel(Slots<GroupArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const GroupArgs& a = SL.a[blockIdx.y];
+  const uint32_t n_all = a.n_all;
+  const uint32_t* __restrict__ obj_of = a.obj_of; const uint32_t* __restrict__ goff = a.goff;
+  const float* __restrict__ ftrain = a.ftrain; const float* __restrict__ fquery = a.fquery;
+  const uint32_t* __restrict__ fqidx = a.fqidx; const float* __restrict__ fkp = a.fkp;
+  float* const train = a.train; float* const query = a.query; uint32_t* const qidx = a.qidx; float* const kpxy = a.kpxy;
   const uint32_t f = blockIdx.x * 256u + threadIdx.x;
   if (f >= n_all) return;
   const uint32_t o = obj_of[f];
@@ -1352,21 +1401,39 @@ __global__ __launch_bounds__(256) void cluster_group_kernel(uint32_t n_all, cons
 
 // ------------------------------------------------------------------------------------------------ host side
 struct VerifyWs {
-  DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, rnd, table, iter_samples, iter_pos, counts, gate_m,
-      small, deferred, stacks, kp_list, kp_bits, clique_adj, adjc_scratch, c_kept, c_offs, c_qpt, c_obj, c_hist, c_goff, f_train,
+  DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, rnd, table, iter_samples, counts, gate_m,
+      small, deferred, stacks, kp_bits, clique_adj, adjc_scratch, c_kept, c_offs, c_qpt, c_obj, c_hist, c_goff, f_train,
       f_query, f_qidx, f_kp;
-  HostBuf h_small, h_counts, h_pos, h_kp, h_trip, h_goff;
-  std::vector<uint32_t> rnd_host;
+  // the slot's mailbox: pinned host memory that kernels read and write directly (see copy_words_kernel)
+  HostBuf m_small, m_hist, m_goff, m_rnd, m_pos, m_counts, m_kp;
+  HostBuf h_small;                                          // staging of the test hooks
+  void release() {
+    DevBuf* bufs[] = {&train, &query, &qidx, &kpxy, &phys, &samp, &bits, &sampdeg, &rnd, &table, &iter_samples, &counts, &gate_m,
+                      &small, &deferred, &stacks, &kp_bits, &clique_adj, &adjc_scratch, &c_kept, &c_offs, &c_qpt, &c_obj, &c_hist,
+                      &c_goff, &f_train, &f_query, &f_qidx, &f_kp};
+    for (DevBuf* b : bufs) b->release();
+    HostBuf* hb[] = {&m_small, &m_hist, &m_goff, &m_rnd, &m_pos, &m_counts, &m_kp, &h_small};
+    for (HostBuf* b : hb) b->release();
+  }
 };
+
+// one workspace per frame slot of a batch; slot 0 also serves the single-frame entry points and the test hooks
+struct VerifyPool { std::vector<VerifyWs*> slots; };
 
 constexpr uint32_t kEvalLdsSmall = 48u * 1024u;
 constexpr uint32_t kEvalLdsBig = 160u * 1024u - 512u;
-constexpr uint32_t kStackCap = 256u * 1024u;       // u16 entries per wave (512 KB)
-constexpr uint32_t kMaxEvalWaves = 2048u;
+constexpr uint32_t kStackCap = 128u * 1024u;       // u16 entries per wave beyond the LDS part of the stack (256 KB)
+constexpr uint32_t kMaxEvalWaves = 1024u;          // hypotheses per evaluation batch
+constexpr uint32_t kMailSmallWords = 128u;         // [0, 64) = the slot's device control words, [64] = n_all
 
-VerifyWs* ws_of(todhip_ctx* ctx) {
-  if (!ctx->verify_ws) ctx->verify_ws = new VerifyWs();
-  return reinterpret_cast<VerifyWs*>(ctx->verify_ws);
+VerifyPool* pool_of(todhip_ctx* ctx) {
+  if (!ctx->verify_ws) ctx->verify_ws = new VerifyPool();
+  return reinterpret_cast<VerifyPool*>(ctx->verify_ws);
+}
+VerifyWs* ws_of(todhip_ctx* ctx, size_t slot = 0) {
+  VerifyPool* p = pool_of(ctx);
+  while (p->slots.size() <= slot) p->slots.push_back(new VerifyWs());
+  return p->slots[slot];
 }
 
 // glibc random_r TYPE_3 (see include/todhip.h, decision D4)
@@ -1377,13 +1444,6 @@ inline uint32_t rng_next(todhip_rng& r) {
   ++r.draws;
   return out;
 }
-
-struct RoundResult {
-  bool have_pose;
-  std::vector<uint32_t> inlier_kp;
-  float R[9], T[3];
-  uint32_t iterations, best_iteration; int32_t best_count;
-};
 
 int set_big_lds_once(todhip_ctx* ctx) {
   static bool done = false;
@@ -1397,201 +1457,454 @@ int set_big_lds_once(todhip_ctx* ctx) {
   return TODHIP_OK;
 }
 
-// AdjacencyRansac::Ransac (adjacency_ransac.cpp:234-309) for one object whose job is resident.
-int ransac_round(todhip_ctx* ctx, VerifyWs* ws, const ObjJob& job, uint32_t nq, float err, uint32_t max_iterations,
-                 todhip_rng* rng, RoundResult* res) {
-  res->have_pose = false;
-  res->inlier_kp.clear();
-  res->iterations = 0; res->best_iteration = 0; res->best_count = -INT_MAX;
-  hipStream_t st = ctx->stream;
-  uint32_t* d_small = ws->small.as<uint32_t>();           // [0] nvalid [1..4] ChainOut [8] work [12..14] status
-  TOD_HIP(hipMemsetAsync(d_small, 0, 64 * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(round_prep_kernel, dim3((job.n + 255u) / 256u), dim3(256), 0, st, job, d_small);
-  uint32_t* h_small = ws->h_small.as<uint32_t>();
-  TOD_HIP(hipMemcpyAsync(h_small, d_small, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  TOD_HIP(hipStreamSynchronize(st));
-  const uint32_t nvalid = h_small[0];
-  TOD_DBG("round: n=%u W=%u nvalid=%u", job.n, job.W, nvalid);
-  if (nvalid < 3) return TODHIP_OK;                       // :238-241
+struct ObjSpan { uint32_t obj, offset, n; };
+struct DepthInput { const void* d_depth; int is_u16; float fx, fy, cx, cy; };
 
-  const uint32_t total_iters = max_iterations + 1u;       // iterations_ runs 0 .. max_iterations (ransac.h:132-134)
-  TOD_HIP(ws->iter_samples.reserve((size_t)(total_iters + 1) * 3 * sizeof(uint32_t)));
-  TOD_HIP(ws->iter_pos.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
-  TOD_HIP(ws->counts.reserve((size_t)(total_iters + 1) * sizeof(int32_t)));
-  TOD_HIP(ws->gate_m.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
-  TOD_HIP(ws->deferred.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
-  TOD_HIP(ws->h_counts.reserve((size_t)(total_iters + 1) * sizeof(int32_t)));
-  TOD_HIP(ws->h_pos.reserve((size_t)(total_iters + 1) * sizeof(uint32_t)));
-  TOD_HIP(ws->h_trip.reserve((size_t)(total_iters + 1) * 3 * sizeof(uint32_t)));
-  TOD_HIP(ws->stacks.reserve((size_t)kMaxEvalWaves * kStackCap * sizeof(uint16_t)));
+// ---------------------------------------------------------------------------------------------- the batch engine
+// One Slot = one frame = GuessGenerator::process after matching (GuessGenerator.cpp:127-250): ClusterPerObject, then
+// per object (ascending imgIdx) AdjacencyRansac::Ransac rounds (adjacency_ransac.cpp:234-309) until one fails. The
+// recursion of the reference becomes an explicit phase machine per slot so that the slots of a batch can be
+// advanced together: a TICK lets every live slot issue the kernels of its next phase into per-kernel lists, launches
+// each non-empty list once (all slots in one grid), synchronizes once, and lets every slot consume its results
+// (the ransac.h:95-135 bookkeeping is replayed on the host so that pow/log are libm's).
+enum Phase { PH_CLUSTER, PH_CLUSTER_WAIT, PH_GROUP, PH_OBJECT, PH_ROUND, PH_PREP_WAIT, PH_DRAW, PH_DRAW_WAIT, PH_EVAL,
+             PH_EVAL_WAIT, PH_EVAL2, PH_EVAL2_WAIT, PH_GROWTH, PH_GROWTH_WAIT, PH_DONE };
 
-  // ---- computeModel (ransac.h:80-143): speculative draws in batches, evaluation, host replay
-  todhip_rng gen = *rng;                                  // generator that fills stream windows
-  std::vector<uint32_t>& stream = ws->rnd_host;           // stream[i] = i-th draw after *rng
-  stream.clear();
+struct RoundState {                                       // computeModel (ransac.h:80-143) in flight
+  todhip_rng gen;                                         // generator that fills stream windows
+  std::vector<uint32_t> stream;                           // stream[i] = i-th draw after the caller's generator
   uint64_t consumed = 0;                                  // draws used by completed getSamples calls
   uint32_t it_drawn = 0, attempts_carry = 0;
-  bool selection_empty = false;
+  bool selection_empty = false, loop_done = false;
   int iterations = 0, n_best = -INT_MAX;
   double k = 1.0;
   uint32_t best_it = 0;
-  bool loop_done = false;
   uint64_t pos_after_stop = 0;
   uint32_t batch = 64, lookahead = 4096;
-  while (!loop_done) {
-    const uint32_t it_begin = it_drawn;
-    const uint32_t want = std::min(batch, total_iters - it_begin);
-    // ---- draw `want` iterations, extending the window as often as needed
-    uint32_t got = 0;
-    while (got < want && !selection_empty) {
-      const uint32_t S = std::min<uint32_t>(4u * (want - got) + 256u, 1u << 20);
-      const uint32_t window_len = S + lookahead;
-      while (stream.size() < consumed + window_len) stream.push_back(rng_next(gen));
-      TOD_HIP(ws->rnd.reserve((size_t)window_len * sizeof(uint32_t)));
-      TOD_HIP(ws->table.reserve((size_t)S * sizeof(DrawEntry)));
-      TOD_HIP(hipMemcpyAsync(ws->rnd.p, stream.data() + consumed, (size_t)window_len * sizeof(uint32_t),
-                             hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(draw_table_kernel, dim3((S + 3u) / 4u), dim3(256), 0, st, job, ws->rnd.as<uint32_t>(),
-                         window_len, S, ws->table.as<DrawEntry>());
-      hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(64), 0, st, ws->table.as<DrawEntry>(), S, want - got,
-                         attempts_carry, it_begin + got, ws->iter_samples.as<uint32_t>(), ws->iter_pos.as<uint32_t>(),
-                         reinterpret_cast<ChainOut*>(d_small + 1));
-      const uint32_t req = want - got;
-      TOD_HIP(hipMemcpyAsync(h_small + 1, d_small + 1, sizeof(ChainOut), hipMemcpyDeviceToHost, st));
-      TOD_HIP(hipMemcpyAsync(ws->h_pos.as<uint32_t>() + it_begin + got, ws->iter_pos.as<uint32_t>() + it_begin + got,
-                             (size_t)req * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      TOD_HIP(hipMemcpyAsync(ws->h_trip.as<uint32_t>() + 3 * (size_t)(it_begin + got),
-                             ws->iter_samples.as<uint32_t>() + 3 * (size_t)(it_begin + got),
-                             (size_t)req * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      TOD_HIP(hipStreamSynchronize(st));
-      const ChainOut co = *reinterpret_cast<ChainOut*>(h_small + 1);
-      TOD_DBG("  draw window: S=%u len=%u -> done=%u pos_end=%u attempts=%u flag=%u", S, window_len, co.n_done, co.pos_end,
-              co.attempts, co.flag);
-      // positions of this walk are relative to the window start
-      {
-        uint32_t* hp = ws->h_pos.as<uint32_t>();
-        for (uint32_t i = 0; i < co.n_done; ++i) hp[it_begin + got + i] += (uint32_t)consumed;
-      }
-      got += co.n_done;
-      consumed += co.pos_end;
-      attempts_carry = co.attempts;
-      if (co.flag == 2) selection_empty = true;
-      if (co.flag == 1 && co.n_done == 0 && co.pos_end == 0) {
-        // a single attempt longer than the window: enlarge the look-ahead, give up beyond 64M draws
-        if (lookahead >= (1u << 26)) return TODHIP_ESCRATCH;
-        lookahead *= 4u;
-      }
+  uint32_t nvalid = 0, total_iters = 0;
+  uint32_t it_begin = 0, want = 0, got = 0, S = 0, window_len = 0;   // the evaluation batch being drawn
+  uint32_t n_def = 0;
+};
+
+struct Slot {
+  VerifyWs* ws = nullptr;
+  // inputs (device-resident form)
+  const float* d_kp_xy = nullptr; const float* d_cloud = nullptr; DepthInput dep = {}; bool use_depth = false;
+  const uint32_t* d_counts = nullptr; const todhip_dmatch* d_matches = nullptr; const float* d_mxyz = nullptr;
+  todhip_rng* rng = nullptr;
+  // results
+  std::vector<todhip_pose> poses;
+  std::vector<uint32_t> inliers;
+  std::vector<todhip_round_trace> traces;
+  int rc = TODHIP_OK;
+  // progress
+  Phase ph = PH_DONE;
+  std::vector<ObjSpan> objs;
+  size_t oi = 0;
+  ObjJob job = {};
+  uint32_t n_all = 0;
+  bool pending_invalidate = false;
+  todhip_round_trace tr = {};
+  RoundState r;
+};
+
+struct Launches {
+  std::vector<CopyArgs> copy_in, zero, copy_out;
+  std::vector<LookupArgs> lookup; std::vector<ScanArgs> scan; std::vector<ScatterArgs> scatter; std::vector<GroupArgs> group;
+  std::vector<InvArgs> inval; std::vector<JobArgs> finite; std::vector<AdjArgs> adj; std::vector<PrepArgs> prep;
+  std::vector<DrawArgs> draw; std::vector<ChainArgs> chain; std::vector<EvalArgs> eval_small, eval_big;
+  std::vector<GrowthArgs> growth;
+};
+
+// launch `kern` over the argument sets of v, kMaxSlots at a time; extent(a) = blocks one set needs in x (and y)
+template <class A, class Kern, class Extent>
+void launch_list(hipStream_t st, Kern kern, const std::vector<A>& v, uint32_t block, uint32_t lds, int slot_dim, Extent extent) {
+  for (size_t i0 = 0; i0 < v.size(); i0 += kMaxSlots) {
+    const uint32_t n = (uint32_t)std::min<size_t>(kMaxSlots, v.size() - i0);
+    Slots<A> S;
+    std::memset(&S, 0, sizeof(S));
+    uint32_t gx = 1, gy = 1;
+    for (uint32_t i = 0; i < n; ++i) {
+      S.a[i] = v[i0 + i];
+      const dim3 e = extent(v[i0 + i]);
+      gx = std::max(gx, e.x); gy = std::max(gy, e.y);
     }
-    it_drawn = it_begin + got;
-    // ---- evaluate the drawn iterations
-    if (got > 0) {
+    dim3 grid;
+    if (slot_dim == 0) grid = dim3(n);
+    else if (slot_dim == 1) grid = dim3(gx, n);
+    else grid = dim3(gx, gy, n);
+    hipLaunchKernelGGL(kern, grid, dim3(block), lds, st, S);
+  }
+}
+
+struct Engine {
+  todhip_ctx* ctx;
+  hipStream_t st;
+  uint32_t nq, H, Wimg, k, n_objs;
+  const float* spans;
+  const todhip_verify_params* prm;
+  Launches L;
+
+  static uint32_t* mail(const Slot& s) { return s.ws->m_small.as<uint32_t>(); }
+  void export_small(Slot& s) { L.copy_out.push_back({s.ws->small.as<uint32_t>(), mail(s), 64u}); }
+  void fail(Slot& s, int rc) { s.rc = rc; s.ph = PH_DONE; }
+#define SLOT_HIP(expr) do { if ((expr) != hipSuccess) { fail(s, TODHIP_EHIP); return; } } while (0)
+
+  // ---- issue: queue the kernels of the slot's next phase
+  void issue(Slot& s) {
+    VerifyWs* ws = s.ws;
+    uint32_t* d_small = ws->small.as<uint32_t>();
+    if (s.ph == PH_CLUSTER) {
+      L.zero.push_back({nullptr, d_small + 60, 1u});
+      L.zero.push_back({nullptr, ws->c_hist.as<uint32_t>(), n_objs});
+      LookupArgs la = {s.d_kp_xy, nq, s.use_depth ? nullptr : s.d_cloud, s.dep.d_depth, s.dep.is_u16, H, Wimg, s.dep.fx, s.dep.fy,
+                       s.dep.cx, s.dep.cy, s.d_counts, ws->c_kept.as<uint32_t>(), ws->c_qpt.as<float>(), d_small + 60};
+      L.lookup.push_back(la);
+      L.scan.push_back({ws->c_kept.as<uint32_t>(), nq, ws->c_offs.as<uint32_t>()});
+      ScatterArgs sa = {s.d_kp_xy, nq, k, s.d_matches, s.d_mxyz, ws->c_kept.as<uint32_t>(), ws->c_offs.as<uint32_t>(),
+                        ws->c_qpt.as<float>(), n_objs, ws->c_obj.as<uint32_t>(), ws->c_hist.as<uint32_t>(), ws->f_train.as<float>(),
+                        ws->f_query.as<float>(), ws->f_qidx.as<uint32_t>(), ws->f_kp.as<float>(), d_small + 60};
+      L.scatter.push_back(sa);
+      export_small(s);
+      L.copy_out.push_back({ws->c_offs.as<uint32_t>() + nq, mail(s) + 64, 1u});
+      L.copy_out.push_back({ws->c_hist.as<uint32_t>(), ws->m_hist.as<uint32_t>(), n_objs});
+      s.ph = PH_CLUSTER_WAIT;
+      return;
+    }
+    if (s.ph == PH_GROUP) {
+      L.copy_in.push_back({ws->m_goff.as<uint32_t>(), ws->c_goff.as<uint32_t>(), n_objs});
+      GroupArgs ga = {s.n_all, ws->c_obj.as<uint32_t>(), ws->c_goff.as<uint32_t>(), ws->f_train.as<float>(), ws->f_query.as<float>(),
+                      ws->f_qidx.as<uint32_t>(), ws->f_kp.as<float>(), ws->train.as<float>(), ws->query.as<float>(),
+                      ws->qidx.as<uint32_t>(), ws->kpxy.as<float>()};
+      L.group.push_back(ga);
+      s.ph = PH_OBJECT;
+    }
+    if (s.ph == PH_OBJECT) {
+      // Ransac returns no inliers for < 3 valid matches and draws nothing (:238-241)
+      while (s.oi < s.objs.size() && s.objs[s.oi].n < 3) ++s.oi;
+      if (s.oi >= s.objs.size()) { s.ph = PH_DONE; return; }
+      const ObjSpan& o = s.objs[s.oi];
+      const uint32_t n = o.n, W = (n + 63u) / 64u;
+      ObjJob& job = s.job;
+      job.n = n; job.W = W;
+      job.train = ws->train.as<float>() + 3 * (size_t)o.offset; job.query = ws->query.as<float>() + 3 * (size_t)o.offset;
+      job.qidx = ws->qidx.as<uint32_t>() + o.offset; job.kpxy = ws->kpxy.as<float>() + 2 * (size_t)o.offset;
+      job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
+      u64* bits = ws->bits.as<u64>();                       // finite | valid | deg7 | inl | rest | extra | scratch
+      job.finite = bits; job.valid = bits + W; job.deg7 = bits + 2 * W;
+      job.sampdeg = ws->sampdeg.as<uint32_t>();
+      L.finite.push_back({job});
+      L.adj.push_back({job, spans[o.obj], prm->sensor_error});
+      ctx->counters.last_objects_verified += 1;
+      s.pending_invalidate = false;
+      s.ph = PH_ROUND;
+    }
+    if (s.ph == PH_ROUND) {                                 // one AdjacencyRansac::Ransac call (GuessGenerator.cpp:192-231)
+      if (s.pending_invalidate) {
+        L.inval.push_back({s.job, ws->kp_bits.as<u64>(), ws->bits.as<u64>() + 6 * s.job.W});
+        s.pending_invalidate = false;
+      }
+      L.zero.push_back({nullptr, d_small, 64u});
+      L.prep.push_back({s.job, d_small});
+      export_small(s);
+      s.tr = todhip_round_trace();
+      s.tr.object = s.objs[s.oi].obj; s.tr.draws_before = s.rng->draws; s.tr.best_count = -INT_MAX;
+      s.ph = PH_PREP_WAIT;
+      return;
+    }
+    if (s.ph == PH_DRAW) {
+      RoundState& r = s.r;
+      r.S = std::min<uint32_t>(4u * (r.want - r.got) + 256u, 1u << 20);
+      r.window_len = r.S + r.lookahead;
+      while (r.stream.size() < r.consumed + r.window_len) r.stream.push_back(rng_next(r.gen));
+      SLOT_HIP(ws->rnd.reserve((size_t)r.window_len * sizeof(uint32_t)));
+      SLOT_HIP(ws->m_rnd.reserve((size_t)r.window_len * sizeof(uint32_t)));
+      SLOT_HIP(ws->table.reserve((size_t)r.S * sizeof(DrawEntry)));
+      std::memcpy(ws->m_rnd.p, r.stream.data() + r.consumed, (size_t)r.window_len * sizeof(uint32_t));
+      L.copy_in.push_back({ws->m_rnd.as<uint32_t>(), ws->rnd.as<uint32_t>(), r.window_len});
+      L.draw.push_back({s.job, ws->rnd.as<uint32_t>(), r.window_len, r.S, ws->table.as<DrawEntry>()});
+      ChainArgs ca = {ws->table.as<DrawEntry>(), r.S, r.want - r.got, r.attempts_carry, r.it_begin + r.got,
+                      ws->iter_samples.as<uint32_t>(), ws->m_pos.as<uint32_t>(), reinterpret_cast<ChainOut*>(d_small + 1)};
+      L.chain.push_back(ca);
+      export_small(s);
+      s.ph = PH_DRAW_WAIT;
+      return;
+    }
+    if (s.ph == PH_EVAL || s.ph == PH_EVAL2) {
+      RoundState& r = s.r;
+      const bool second = s.ph == PH_EVAL2;
       EvalArgs A;
-      A.job = job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = it_begin; A.it_end = it_drawn;
-      A.counts = ws->counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
+      A.job = s.job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = r.it_begin; A.it_end = r.it_drawn;
+      A.counts = ws->m_counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
       A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>(); A.stacks = ws->stacks.as<uint16_t>();
-      A.stack_cap = kStackCap; A.lds_bytes = kEvalLdsSmall; A.from_deferred = 0; A.n_deferred = 0;
+      A.stack_cap = kStackCap; A.lds_bytes = second ? kEvalLdsBig : kEvalLdsSmall; A.from_deferred = second ? 1u : 0u;
+      A.n_deferred = second ? r.n_def : 0u;
       A.adjc_scratch = nullptr; A.dbg = nullptr; A.dbg_stride = 0; A.stop_level = 0;
-      TOD_HIP(hipMemsetAsync(d_small + 8, 0, 12 * sizeof(uint32_t), st));
-      const uint32_t waves = got;                         // one block per hypothesis; batches are <= 1024
-      TOD_DBG("  eval: iterations [%u,%u) on %u waves", it_begin, it_drawn, waves);
-      hipLaunchKernelGGL(eval_kernel, dim3(waves), dim3(64), kEvalLdsSmall, st, A);
-      TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-      TOD_HIP(hipMemcpyAsync(ws->h_counts.as<int32_t>() + it_begin, ws->counts.as<int32_t>() + it_begin,
-                             (size_t)got * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      TOD_HIP(hipStreamSynchronize(st));
-      if (h_small[12] != 0) {
-        if (getenv("TODHIP_DEBUG"))
-          fprintf(stderr, "[todhip] eval status %u: g=%u value=%u m=%u it=%u (n=%u W=%u)\n", h_small[12], h_small[16],
-                  h_small[17], h_small[18], h_small[19], job.n, job.W);
-        return TODHIP_ESCRATCH;
-      }
-      const uint32_t n_def = h_small[14];
-      TOD_DBG("  eval done: gate calls=%u deferred=%u", h_small[13], n_def);
-      ctx->counters.last_gate_calls += h_small[13];
-      if (n_def > 0) {                                    // graphs that need the whole LDS of a CU
-        A.lds_bytes = kEvalLdsBig; A.from_deferred = 1; A.n_deferred = n_def;
-        TOD_HIP(ws->adjc_scratch.reserve((size_t)n_def * kAdjcScratchWords * sizeof(u64)));
+      if (second) {                                         // graphs that need the whole LDS of a CU, or global scratch
+        SLOT_HIP(ws->adjc_scratch.reserve((size_t)r.n_def * kAdjcScratchWords * sizeof(u64)));
         A.adjc_scratch = ws->adjc_scratch.as<u64>();
-        TOD_HIP(hipMemsetAsync(d_small + 8, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(eval_kernel, dim3(n_def), dim3(64), kEvalLdsBig, st, A);
-        TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        TOD_HIP(hipStreamSynchronize(st));
-        if (h_small[12] != 0) return TODHIP_ESCRATCH;
-        TOD_HIP(hipMemcpyAsync(ws->h_counts.as<int32_t>() + it_begin, ws->counts.as<int32_t>() + it_begin,
-                               (size_t)got * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        TOD_HIP(hipStreamSynchronize(st));
+        L.zero.push_back({nullptr, d_small + 8, 1u});
+        L.eval_big.push_back(A);
+      } else {
+        L.zero.push_back({nullptr, d_small + 8, 12u});
+        L.eval_small.push_back(A);
       }
-      ctx->counters.last_hypotheses += got;
+      export_small(s);
+      s.ph = second ? PH_EVAL2_WAIT : PH_EVAL_WAIT;
+      return;
     }
-    // ---- replay ransac.h:95-135 over the iterations known so far
-    const int32_t* hc = ws->h_counts.as<int32_t>();
-    const uint32_t* hp = ws->h_pos.as<uint32_t>();
-    while (!loop_done) {
-      if (!(iterations < k)) { loop_done = true; pos_after_stop = iterations > 0 ? hp[iterations - 1] : 0; break; }
-      if ((uint32_t)iterations >= it_drawn) {
-        if (selection_empty) { loop_done = true; pos_after_stop = consumed; }   // selection.empty() -> break (:100-101)
-        break;                                            // need more iterations
+    if (s.ph == PH_GROWTH) {                                // growth (adjacency_ransac.cpp:255-308)
+      const uint32_t kp_words = (nq + 63u) / 64u, W = s.job.W;
+      u64* d_bits = ws->bits.as<u64>();
+      GrowthArgs ga = {s.job, ws->iter_samples.as<uint32_t>() + 3 * (size_t)s.r.best_it, prm->sensor_error, d_bits + 3 * W,
+                       d_bits + 4 * W, d_bits + 5 * W, ws->m_kp.as<uint32_t>(), ws->kp_bits.as<u64>(), kp_words,
+                       reinterpret_cast<GrowthOut*>(d_small + 32)};
+      L.growth.push_back(ga);
+      export_small(s);
+      s.ph = PH_GROWTH_WAIT;
+      return;
+    }
+  }
+
+  // ---- one evaluation batch of computeModel starts: draw `want` iterations (as many windows as it takes)
+  void begin_batch(Slot& s) {
+    RoundState& r = s.r;
+    r.it_begin = r.it_drawn;
+    r.want = std::min(r.batch, r.total_iters - r.it_begin);
+    r.got = 0;
+    if (r.got < r.want && !r.selection_empty) s.ph = PH_DRAW; else after_draw(s);
+  }
+  void after_draw(Slot& s) {
+    RoundState& r = s.r;
+    r.it_drawn = r.it_begin + r.got;
+    if (r.got > 0) s.ph = PH_EVAL; else replay(s);
+  }
+  // ---- ransac.h:95-135 over the iterations known so far
+  void replay(Slot& s) {
+    RoundState& r = s.r;
+    const int32_t* hc = s.ws->m_counts.as<int32_t>();
+    const uint32_t* hp = s.ws->m_pos.as<uint32_t>();
+    while (!r.loop_done) {
+      if (!(r.iterations < r.k)) { r.loop_done = true; r.pos_after_stop = r.iterations > 0 ? hp[r.iterations - 1] : 0; break; }
+      if ((uint32_t)r.iterations >= r.it_drawn) {
+        if (r.selection_empty) { r.loop_done = true; r.pos_after_stop = r.consumed; }   // selection.empty() -> break (:100-101)
+        break;                                              // need more iterations
       }
-      const int n_count = hc[iterations];
-      if (n_count > n_best) {
-        n_best = n_count;
-        best_it = (uint32_t)iterations;
-        const double w = (double)n_best / (double)nvalid;
+      const int n_count = hc[r.iterations];
+      if (n_count > r.n_best) {
+        r.n_best = n_count;
+        r.best_it = (uint32_t)r.iterations;
+        const double w = (double)r.n_best / (double)r.nvalid;
         double p_no_outliers = 1.0 - std::pow(w, 3.0);
         p_no_outliers = std::max(std::numeric_limits<double>::epsilon(), p_no_outliers);
         p_no_outliers = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no_outliers);
-        k = std::log(1.0 - 0.99) / std::log(p_no_outliers);
+        r.k = std::log(1.0 - 0.99) / std::log(p_no_outliers);
       }
-      ++iterations;
-      if (iterations > (int)max_iterations) { loop_done = true; pos_after_stop = hp[iterations - 1]; }
+      ++r.iterations;
+      if (r.iterations > (int)prm->n_ransac_iterations) { r.loop_done = true; r.pos_after_stop = hp[r.iterations - 1]; }
     }
-    batch = std::min<uint32_t>(batch * 4u, 1024u);
+    r.batch = std::min<uint32_t>(r.batch * 4u, kMaxEvalWaves);
+    if (!r.loop_done) { begin_batch(s); return; }
+    // advance the caller's generator by exactly the draws the reference would have consumed
+    for (uint64_t i = 0; i < r.pos_after_stop; ++i) (void)rng_next(*s.rng);
+    s.tr.iterations = (uint32_t)r.iterations; s.tr.best_iteration = r.best_it; s.tr.best_count = r.n_best;
+    if (r.n_best <= 0) { round_done(s, false); return; }   // inliers_.empty(): computeModel() == false (:137-138)
+    s.ph = PH_GROWTH;
   }
-  // advance the caller's generator by exactly the draws the reference would have consumed
-  for (uint64_t i = 0; i < pos_after_stop; ++i) (void)rng_next(*rng);
-  res->iterations = (uint32_t)iterations; res->best_iteration = best_it; res->best_count = n_best;
-  TOD_DBG("  replay: iterations=%d best_it=%u n_best=%d draws=%llu", iterations, best_it, n_best,
-          (unsigned long long)pos_after_stop);
-  if (n_best <= 0) return TODHIP_OK;                      // inliers_.empty(): computeModel() == false (:137-138)
+  void round_done(Slot& s, bool have_pose) {
+    const GrowthOut* go = reinterpret_cast<const GrowthOut*>(mail(s) + 32);
+    const uint32_t n_kp = have_pose ? go->n_kp_inliers : 0u;
+    ctx->counters.last_rounds += 1;
+    s.tr.draws_after = s.rng->draws; s.tr.n_inlier_kp = n_kp; s.tr.accepted = n_kp >= prm->min_inliers;
+    s.traces.push_back(s.tr);
+    if (n_kp < prm->min_inliers) { ++s.oi; s.ph = PH_OBJECT; return; }   // GuessGenerator.cpp:205-206
+    todhip_pose p;
+    std::memset(&p, 0, sizeof(p));
+    p.object = s.objs[s.oi].obj;
+    std::memcpy(p.R, go->R, sizeof(p.R));
+    std::memcpy(p.t, go->T, sizeof(p.t));
+    p.inlier_begin = (uint32_t)s.inliers.size();
+    const uint32_t* list = s.ws->m_kp.as<uint32_t>();
+    s.inliers.insert(s.inliers.end(), list, list + n_kp);
+    p.inlier_end = (uint32_t)s.inliers.size();
+    s.poses.push_back(p);
+    ctx->counters.last_poses += 1;
+    s.pending_invalidate = true;                            // InvalidateQueryIndices, then the next round (:207-230)
+    s.ph = PH_ROUND;
+  }
 
-  // ---- growth (adjacency_ransac.cpp:255-308)
-  const uint32_t kp_words = (nq + 63u) / 64u;
-  TOD_HIP(ws->kp_list.reserve((size_t)std::max(nq, 1u) * sizeof(uint32_t)));
-  TOD_HIP(ws->kp_bits.reserve((size_t)(kp_words + 1) * sizeof(u64)));
-  TOD_HIP(ws->h_kp.reserve((size_t)std::max(nq, 1u) * sizeof(uint32_t) + sizeof(GrowthOut)));
-  u64* d_bits = ws->bits.as<u64>();                       // finite | valid | deg7 | inl | rest | extra | scratch
-  const uint32_t W = job.W;
-  const uint32_t* trip = ws->h_trip.as<uint32_t>() + 3 * (size_t)best_it;
-  GrowthOut* d_go = reinterpret_cast<GrowthOut*>(d_small + 32);
-  hipLaunchKernelGGL(growth_kernel, dim3(1), dim3(256), 0, st, job, trip[0], trip[1], trip[2], err, d_bits + 3 * W,
-                     d_bits + 4 * W, d_bits + 5 * W, ws->kp_list.as<uint32_t>(), ws->kp_bits.as<u64>(), kp_words, d_go);
-  GrowthOut* h_go = reinterpret_cast<GrowthOut*>(ws->h_kp.as<unsigned char>());
-  uint32_t* h_list = reinterpret_cast<uint32_t*>(ws->h_kp.as<unsigned char>() + sizeof(GrowthOut));
-  TOD_HIP(hipMemcpyAsync(h_go, d_go, sizeof(GrowthOut), hipMemcpyDeviceToHost, st));
-  TOD_HIP(hipMemcpyAsync(h_list, ws->kp_list.p, (size_t)std::min(nq, job.n) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  TOD_HIP(hipStreamSynchronize(st));
-  TOD_DBG("  growth: model=%u matches=%u kps=%u passes=%u", h_go->n_model_inliers, h_go->n_match_inliers,
-          h_go->n_kp_inliers, h_go->passes);
-  res->have_pose = true;
-  res->inlier_kp.assign(h_list, h_list + h_go->n_kp_inliers);
-  std::memcpy(res->R, h_go->R, sizeof(res->R));
-  std::memcpy(res->T, h_go->T, sizeof(res->T));
-  return TODHIP_OK;
-}
+  // ---- consume: the tick's results are in the mailbox
+  void consume(Slot& s) {
+    VerifyWs* ws = s.ws;
+    const uint32_t* m = mail(s);
+    RoundState& r = s.r;
+    if (s.ph == PH_CLUSTER_WAIT) {
+      if (m[60] != 0) { fail(s, TODHIP_ERANGE); return; }
+      s.n_all = m[64];
+      if (s.n_all == 0) { s.ph = PH_DONE; return; }
+      const uint32_t* hist = ws->m_hist.as<uint32_t>();
+      uint32_t* goff = ws->m_goff.as<uint32_t>();
+      uint32_t total = 0, max_n = 0;
+      s.objs.clear();
+      for (uint32_t o = 0; o < n_objs; ++o) {
+        goff[o] = total;
+        if (hist[o]) s.objs.push_back({o, total, hist[o]});
+        total += hist[o];
+        max_n = std::max(max_n, hist[o]);
+      }
+      s.oi = 0;
+      if (!reserve_objects(s, max_n)) return;
+      s.ph = PH_GROUP;
+      return;
+    }
+    if (s.ph == PH_PREP_WAIT) {
+      const uint32_t nvalid = m[0];
+      TOD_DBG("round: n=%u W=%u nvalid=%u", s.job.n, s.job.W, nvalid);
+      if (nvalid < 3) { round_done(s, false); return; }    // :238-241
+      r = RoundState();
+      r.nvalid = nvalid;
+      r.total_iters = prm->n_ransac_iterations + 1u;        // iterations_ runs 0 .. max_iterations (ransac.h:132-134)
+      r.gen = *s.rng;
+      SLOT_HIP(ws->iter_samples.reserve((size_t)(r.total_iters + 1) * 3 * sizeof(uint32_t)));
+      SLOT_HIP(ws->gate_m.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
+      SLOT_HIP(ws->deferred.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
+      SLOT_HIP(ws->m_counts.reserve((size_t)(r.total_iters + 1) * sizeof(int32_t)));
+      SLOT_HIP(ws->m_pos.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
+      SLOT_HIP(ws->stacks.reserve((size_t)kMaxEvalWaves * kStackCap * sizeof(uint16_t)));
+      begin_batch(s);
+      return;
+    }
+    if (s.ph == PH_DRAW_WAIT) {
+      const ChainOut co = *reinterpret_cast<const ChainOut*>(m + 1);
+      TOD_DBG("  draw window: S=%u len=%u -> done=%u pos_end=%u attempts=%u flag=%u", r.S, r.window_len, co.n_done, co.pos_end,
+              co.attempts, co.flag);
+      uint32_t* hp = ws->m_pos.as<uint32_t>();             // positions of this walk are relative to the window start
+      for (uint32_t i = 0; i < co.n_done; ++i) hp[r.it_begin + r.got + i] += (uint32_t)r.consumed;
+      r.got += co.n_done;
+      r.consumed += co.pos_end;
+      r.attempts_carry = co.attempts;
+      if (co.flag == 2) r.selection_empty = true;
+      if (co.flag == 1 && co.n_done == 0 && co.pos_end == 0) {
+        // a single attempt longer than the window: enlarge the look-ahead, give up beyond 64M draws
+        if (r.lookahead >= (1u << 26)) { fail(s, TODHIP_ESCRATCH); return; }
+        r.lookahead *= 4u;
+      }
+      if (r.got < r.want && !r.selection_empty) s.ph = PH_DRAW; else after_draw(s);
+      return;
+    }
+    if (s.ph == PH_EVAL_WAIT || s.ph == PH_EVAL2_WAIT) {
+      if (m[12] != 0) {
+        if (getenv("TODHIP_DEBUG"))
+          fprintf(stderr, "[todhip] eval status %u: g=%u value=%u m=%u it=%u (n=%u W=%u)\n", m[12], m[16], m[17], m[18], m[19],
+                  s.job.n, s.job.W);
+        fail(s, TODHIP_ESCRATCH);
+        return;
+      }
+      if (s.ph == PH_EVAL_WAIT) {
+        ctx->counters.last_gate_calls += m[13];
+        r.n_def = m[14];
+        TOD_DBG("  eval done: gate calls=%u deferred=%u", m[13], r.n_def);
+        if (r.n_def > 0) { s.ph = PH_EVAL2; return; }
+      }
+      ctx->counters.last_hypotheses += r.got;
+      replay(s);
+      return;
+    }
+    if (s.ph == PH_GROWTH_WAIT) {
+      const GrowthOut* go = reinterpret_cast<const GrowthOut*>(m + 32);
+      TOD_DBG("  growth: model=%u matches=%u kps=%u passes=%u", go->n_model_inliers, go->n_match_inliers, go->n_kp_inliers,
+              go->passes);
+      round_done(s, true);
+      return;
+    }
+  }
+
+  bool reserve_objects(Slot& s, uint32_t max_n) {
+    VerifyWs* ws = s.ws;
+    if (max_n > (uint32_t)kMaxWords * 64u) { fail(s, TODHIP_ESCRATCH); return false; }
+    if (max_n >= 3) {
+      const uint32_t Wm = (max_n + 63u) / 64u;
+      if (ws->phys.reserve((size_t)max_n * Wm * 8) != hipSuccess || ws->samp.reserve((size_t)max_n * Wm * 8) != hipSuccess ||
+          ws->bits.reserve((size_t)8 * Wm * 8) != hipSuccess || ws->sampdeg.reserve((size_t)max_n * 4) != hipSuccess) {
+        fail(s, TODHIP_EHIP);
+        return false;
+      }
+    }
+    return true;
+  }
+
+  int reserve_common(Slot& s) {
+    VerifyWs* ws = s.ws;
+    const uint32_t kp_words = (nq + 63u) / 64u;
+    TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
+    TOD_HIP(ws->m_small.reserve(kMailSmallWords * sizeof(uint32_t)));
+    TOD_HIP(ws->kp_bits.reserve((size_t)(kp_words + 1) * sizeof(u64)));
+    TOD_HIP(ws->m_kp.reserve((size_t)std::max(nq, 1u) * sizeof(uint32_t)));
+    return TODHIP_OK;
+  }
+  int reserve_cluster(Slot& s) {
+    VerifyWs* ws = s.ws;
+    const size_t cap = (size_t)nq * k;
+    TOD_HIP(ws->c_kept.reserve((size_t)nq * 4)); TOD_HIP(ws->c_offs.reserve(((size_t)nq + 1) * 4));
+    TOD_HIP(ws->c_qpt.reserve((size_t)nq * 12)); TOD_HIP(ws->c_obj.reserve(cap * 4));
+    TOD_HIP(ws->c_hist.reserve((size_t)n_objs * 4)); TOD_HIP(ws->c_goff.reserve((size_t)n_objs * 4));
+    TOD_HIP(ws->m_hist.reserve((size_t)n_objs * 4)); TOD_HIP(ws->m_goff.reserve((size_t)n_objs * 4));
+    TOD_HIP(ws->f_train.reserve(cap * 12)); TOD_HIP(ws->f_query.reserve(cap * 12));
+    TOD_HIP(ws->f_qidx.reserve(cap * 4)); TOD_HIP(ws->f_kp.reserve(cap * 8));
+    TOD_HIP(ws->train.reserve(cap * 12)); TOD_HIP(ws->query.reserve(cap * 12));
+    TOD_HIP(ws->qidx.reserve(cap * 4)); TOD_HIP(ws->kpxy.reserve(cap * 8));
+    return TODHIP_OK;
+  }
+
+  void launch_all() {
+    auto words = [](const CopyArgs& a) { return dim3(std::max(1u, std::min(64u, (a.n + 255u) / 256u))); };
+    launch_list(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
+    launch_list(st, copy_words_kernel, L.zero, 256, 0, 1, words);
+    launch_list(st, cluster_lookup_kernel, L.lookup, 256, 0, 1, [](const LookupArgs& a) { return dim3((a.nq + 255u) / 256u); });
+    launch_list(st, cluster_scan_kernel, L.scan, 1024, 0, 0, [](const ScanArgs&) { return dim3(1); });
+    launch_list(st, cluster_scatter_kernel, L.scatter, 256, 0, 1,
+                [](const ScatterArgs& a) { return dim3((uint32_t)(((size_t)a.nq * a.k + 255u) / 256u)); });
+    launch_list(st, cluster_group_kernel, L.group, 256, 0, 1, [](const GroupArgs& a) { return dim3((a.n_all + 255u) / 256u); });
+    launch_list(st, invalidate_kernel, L.inval, 1024, 0, 0, [](const InvArgs&) { return dim3(1); });
+    launch_list(st, finite_kernel, L.finite, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+    launch_list(st, adjacency_kernel, L.adj, 256, 0, 2, [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
+    launch_list(st, round_prep_kernel, L.prep, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+    launch_list(st, draw_table_kernel, L.draw, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 3u) / 4u); });
+    launch_list(st, chain_kernel, L.chain, 64, 0, 0, [](const ChainArgs&) { return dim3(1); });
+    launch_list(st, eval_kernel, L.eval_small, 64, kEvalLdsSmall, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+    launch_list(st, eval_kernel, L.eval_big, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
+    launch_list(st, growth_kernel, L.growth, 256, 0, 0, [](const GrowthArgs&) { return dim3(1); });
+    launch_list(st, copy_words_kernel, L.copy_out, 256, 0, 1, words);
+    L = Launches();
+  }
+
+  // slots: live frames (phase set by the caller). Returns the first slot error, if any.
+  int run(std::vector<Slot*>& slots) {
+    while (true) {
+      bool any = false;
+      for (Slot* s : slots)
+        if (s->ph != PH_DONE) { issue(*s); any = any || s->ph != PH_DONE; }
+      if (!any) break;
+      launch_all();
+      TOD_HIP(hipGetLastError());
+      TOD_HIP(hipStreamSynchronize(st));
+      for (Slot* s : slots)
+        if (s->ph != PH_DONE) consume(*s);
+    }
+    for (Slot* s : slots)
+      if (s->rc != TODHIP_OK) return s->rc;
+    return TODHIP_OK;
+  }
+#undef SLOT_HIP
+};
 
 }  // namespace
 
 void tod_verify_ws_free(todhip_ctx* ctx) {
   if (!ctx->verify_ws) return;
-  VerifyWs* ws = reinterpret_cast<VerifyWs*>(ctx->verify_ws);
-  DevBuf* bufs[] = {&ws->train, &ws->query, &ws->qidx, &ws->kpxy, &ws->phys, &ws->samp, &ws->bits, &ws->sampdeg,
-                    &ws->rnd, &ws->table, &ws->iter_samples, &ws->iter_pos, &ws->counts, &ws->gate_m, &ws->small,
-                    &ws->deferred, &ws->stacks, &ws->kp_list, &ws->kp_bits, &ws->clique_adj, &ws->adjc_scratch, &ws->c_kept, &ws->c_offs,
-                    &ws->c_qpt, &ws->c_obj, &ws->c_hist, &ws->c_goff, &ws->f_train, &ws->f_query, &ws->f_qidx, &ws->f_kp};
-  for (DevBuf* b : bufs) b->release();
-  ws->h_small.release(); ws->h_counts.release(); ws->h_pos.release(); ws->h_kp.release(); ws->h_trip.release();
-  ws->h_goff.release();
-  delete ws;
+  VerifyPool* p = reinterpret_cast<VerifyPool*>(ctx->verify_ws);
+  for (VerifyWs* ws : p->slots) { ws->release(); delete ws; }
+  delete p;
   ctx->verify_ws = nullptr;
 }
 
@@ -1616,75 +1929,32 @@ void todhip_rng_seed(todhip_rng* r, uint32_t seed) {
   r->draws = 0;
 }
 
-struct ObjSpan { uint32_t obj, offset, n; };
-
-// GuessGenerator::process after clustering (GuessGenerator.cpp:170-235): the grouped match arrays are resident
-// in ws->train/query/qidx/kpxy; objects are visited in ascending imgIdx.
-static int verify_grouped(todhip_ctx* ctx, VerifyWs* ws, const std::vector<ObjSpan>& objs, uint32_t nq,
-                          const float* spans, const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses,
-                          uint32_t pose_cap, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t kp_cap,
-                          uint32_t* n_inlier_kp) {
-  hipStream_t st = ctx->stream;
-  uint32_t max_n = 0;
-  for (const ObjSpan& o : objs) max_n = std::max(max_n, o.n);
-  if (max_n > (uint32_t)kMaxWords * 64u) return TODHIP_ESCRATCH;
-  if (max_n >= 3) {
-    const uint32_t Wm = (max_n + 63u) / 64u;
-    TOD_HIP(ws->phys.reserve((size_t)max_n * Wm * 8)); TOD_HIP(ws->samp.reserve((size_t)max_n * Wm * 8));
-    TOD_HIP(ws->bits.reserve((size_t)8 * Wm * 8)); TOD_HIP(ws->sampdeg.reserve((size_t)max_n * 4));
-  }
-  for (const ObjSpan& o : objs) {
-    const uint32_t n = o.n;
-    if (n < 3) continue;               // Ransac returns no inliers for < 3 valid matches and draws nothing (:238-241)
-    const uint32_t W = (n + 63u) / 64u;
-    ObjJob job;
-    job.n = n; job.W = W;
-    job.train = ws->train.as<float>() + 3 * (size_t)o.offset; job.query = ws->query.as<float>() + 3 * (size_t)o.offset;
-    job.qidx = ws->qidx.as<uint32_t>() + o.offset; job.kpxy = ws->kpxy.as<float>() + 2 * (size_t)o.offset;
-    job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
-    u64* bits = ws->bits.as<u64>();
-    job.finite = bits; job.valid = bits + W; job.deg7 = bits + 2 * W;
-    job.sampdeg = ws->sampdeg.as<uint32_t>();
-    hipLaunchKernelGGL(finite_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, job);
-    hipLaunchKernelGGL(adjacency_kernel, dim3(n, (W + 3u) / 4u), dim3(256), 0, st, job, spans[o.obj], prm->sensor_error);
-    TOD_HIP(hipGetLastError());
-    ctx->counters.last_objects_verified += 1;
-    while (true) {                     // GuessGenerator.cpp:192-231
-      RoundResult rr;
-      todhip_round_trace tr;
-      tr.object = o.obj; tr.draws_before = rng->draws;
-      int rc = ransac_round(ctx, ws, job, nq, prm->sensor_error, prm->n_ransac_iterations, rng, &rr);
-      if (rc != TODHIP_OK) return rc;
-      ctx->counters.last_rounds += 1;
-      tr.draws_after = rng->draws; tr.iterations = rr.iterations; tr.best_iteration = rr.best_iteration;
-      tr.best_count = rr.best_count; tr.n_inlier_kp = (uint32_t)rr.inlier_kp.size();
-      tr.accepted = rr.inlier_kp.size() >= prm->min_inliers;
-      ctx->traces.push_back(tr);
-      if (rr.inlier_kp.size() < prm->min_inliers) break;                 // :205-206
-      hipLaunchKernelGGL(invalidate_kernel, dim3(1), dim3(1024), 0, st, job, ws->kp_bits.as<u64>(), bits + 6 * W);
-      TOD_HIP(hipGetLastError());
-      if (*n_poses >= pose_cap || *n_inlier_kp + rr.inlier_kp.size() > kp_cap) return TODHIP_ECAPACITY;
-      todhip_pose& p = poses[(*n_poses)++];
-      p.object = o.obj;
-      std::memcpy(p.R, rr.R, sizeof(p.R));
-      std::memcpy(p.t, rr.T, sizeof(p.t));
-      p.inlier_begin = *n_inlier_kp;
-      for (uint32_t v : rr.inlier_kp) inlier_kp[(*n_inlier_kp)++] = v;
-      p.inlier_end = *n_inlier_kp;
-      ctx->counters.last_poses += 1;
-    }
-  }
-  TOD_HIP(hipStreamSynchronize(st));
-  return TODHIP_OK;
-}
-
-static int verify_prologue(todhip_ctx* ctx, const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses,
-                           uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
-  if (!ctx || !prm || !rng || !n_poses || !n_inlier_kp || (*n_poses && !poses) || (*n_inlier_kp && !inlier_kp))
-    return TODHIP_EINVAL;
+static int verify_prologue(todhip_ctx* ctx, const todhip_verify_params* prm) {
+  if (!ctx || !prm) return TODHIP_EINVAL;
   ctx->counters.last_objects_verified = ctx->counters.last_rounds = ctx->counters.last_hypotheses = 0;
   ctx->counters.last_gate_calls = ctx->counters.last_poses = 0;
   ctx->traces.clear();
+  TOD_HIP(hipSetDevice(ctx->device));
+  return set_big_lds_once(ctx);
+}
+
+// poses and inlier lists of the slots, concatenated in slot order; pose_ptr (optional) = CSR offsets per slot
+static int collect(todhip_ctx* ctx, std::vector<Slot>& slots, todhip_pose* poses, uint32_t pose_cap, uint32_t* n_poses,
+                   uint32_t* pose_ptr, uint32_t* inlier_kp, uint32_t kp_cap, uint32_t* n_inlier_kp) {
+  uint32_t np = 0, nk = 0;
+  for (size_t f = 0; f < slots.size(); ++f) {
+    Slot& s = slots[f];
+    if (pose_ptr) pose_ptr[f] = np;
+    for (const todhip_round_trace& t : s.traces) ctx->traces.push_back(t);
+    if (np + s.poses.size() > pose_cap || nk + s.inliers.size() > kp_cap) return TODHIP_ECAPACITY;
+    for (todhip_pose p : s.poses) {
+      p.inlier_begin += nk; p.inlier_end += nk;
+      poses[np++] = p;
+    }
+    for (uint32_t v : s.inliers) inlier_kp[nk++] = v;
+  }
+  if (pose_ptr) pose_ptr[slots.size()] = np;
+  *n_poses = np; *n_inlier_kp = nk;
   return TODHIP_OK;
 }
 
@@ -1692,15 +1962,14 @@ int todhip_verify(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float*
                   const uint32_t* row_ptr, const todhip_dmatch* matches, const float* mxyz, const float* spans,
                   uint32_t n_objs, const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses,
                   uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
-  int rc = verify_prologue(ctx, prm, rng, poses, n_poses, inlier_kp, n_inlier_kp);
+  if (!ctx || !prm || !rng || !n_poses || !n_inlier_kp || (*n_poses && !poses) || (*n_inlier_kp && !inlier_kp))
+    return TODHIP_EINVAL;
+  int rc = verify_prologue(ctx, prm);
   if (rc != TODHIP_OK) return rc;
   const uint32_t pose_cap = *n_poses, kp_cap = *n_inlier_kp;
   *n_poses = 0; *n_inlier_kp = 0;
   if (!cloud || H == 0 || Wimg == 0) return TODHIP_OK;   // 2D-only input is an empty TODO (GuessGenerator.cpp:147-152)
   if (nq && (!kp_xy || !row_ptr || !spans)) return TODHIP_EINVAL;
-  TOD_HIP(hipSetDevice(ctx->device));
-  rc = set_big_lds_once(ctx);
-  if (rc != TODHIP_OK) return rc;
   VerifyWs* ws = ws_of(ctx);
 
   // ---- ClusterPerObject (adjacency_ransac.cpp:176-205) on the host buffers the caller handed over: a gather of
@@ -1720,19 +1989,23 @@ int todhip_verify(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float*
       c.qidx.push_back(qi);
     }
   }
-  TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
-  TOD_HIP(ws->h_small.reserve(256 * sizeof(uint32_t)));
   hipStream_t st = ctx->stream;
-  std::vector<ObjSpan> spans_list;
-  uint32_t total = 0;
-  for (auto& kv : objects) { spans_list.push_back({kv.first, total, (uint32_t)kv.second.qidx.size()}); total += (uint32_t)kv.second.qidx.size(); }
+  std::vector<Slot> slots(1);
+  Slot& s = slots[0];
+  s.ws = ws; s.rng = rng;
+  uint32_t total = 0, max_n = 0;
+  for (auto& kv : objects) {
+    s.objs.push_back({kv.first, total, (uint32_t)kv.second.qidx.size()});
+    total += (uint32_t)kv.second.qidx.size();
+    max_n = std::max(max_n, (uint32_t)kv.second.qidx.size());
+  }
   if (total == 0) return TODHIP_OK;
   TOD_HIP(ws->train.reserve((size_t)total * 12)); TOD_HIP(ws->query.reserve((size_t)total * 12));
   TOD_HIP(ws->qidx.reserve((size_t)total * 4)); TOD_HIP(ws->kpxy.reserve((size_t)total * 8));
   size_t i = 0;
   for (auto& kv : objects) {
     HostCluster& c = kv.second;
-    const ObjSpan& o = spans_list[i++];
+    const ObjSpan& o = s.objs[i++];
     if (o.n == 0) continue;
     TOD_HIP(hipMemcpyAsync(ws->train.as<float>() + 3 * (size_t)o.offset, c.train.data(), (size_t)o.n * 12, hipMemcpyHostToDevice, st));
     TOD_HIP(hipMemcpyAsync(ws->query.as<float>() + 3 * (size_t)o.offset, c.query.data(), (size_t)o.n * 12, hipMemcpyHostToDevice, st));
@@ -1740,90 +2013,72 @@ int todhip_verify(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float*
     TOD_HIP(hipMemcpyAsync(ws->kpxy.as<float>() + 2 * (size_t)o.offset, c.kpxy.data(), (size_t)o.n * 8, hipMemcpyHostToDevice, st));
   }
   TOD_HIP(hipStreamSynchronize(st));   // the host vectors die with this scope
-  return verify_grouped(ctx, ws, spans_list, nq, spans, prm, rng, poses, pose_cap, n_poses, inlier_kp, kp_cap, n_inlier_kp);
+  Engine E = {ctx, st, nq, H, Wimg, 0u, n_objs, spans, prm, {}};
+  rc = E.reserve_common(s);
+  if (rc != TODHIP_OK) return rc;
+  if (!E.reserve_objects(s, max_n)) return s.rc;
+  s.ph = PH_OBJECT;
+  std::vector<Slot*> live = {&s};
+  rc = E.run(live);
+  const int rc2 = collect(ctx, slots, poses, pose_cap, n_poses, nullptr, inlier_kp, kp_cap, n_inlier_kp);
+  return rc != TODHIP_OK ? rc : rc2;
 }
 
-// Device-resident form: keypoints, cloud and the matcher's fixed-stride outputs (counts[nq], matches[nq*k],
-// matches_xyz[nq*k*3], see todhip_match_device) are already in HBM; only poses come back to the host.
-struct DepthInput { const void* d_depth; int is_u16; float fx, fy, cx, cy; };
-
-static int verify_device_impl(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const void* d_cloud, const DepthInput* dep,
-                              uint32_t H, uint32_t Wimg, const void* d_counts, const void* d_matches, const void* d_mxyz,
-                              uint32_t k, const float* spans, uint32_t n_objs, const todhip_verify_params* prm,
-                              todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp,
-                              uint32_t* n_inlier_kp) {
-  int rc = verify_prologue(ctx, prm, rng, poses, n_poses, inlier_kp, n_inlier_kp);
+// Device-resident form for a batch of F frames (F = 1 for the single-frame entry points): keypoints, cloud or
+// depth, and the matcher's fixed-stride outputs (counts[nq], matches[nq*k], matches_xyz[nq*k*3], see
+// todhip_match_device) of frame f start at f times their per-frame size; only poses come back to the host.
+static int verify_batch_impl(todhip_ctx* ctx, uint32_t F, const void* d_kp_xy, uint32_t nq, const void* d_cloud,
+                             const DepthInput* dep, uint32_t H, uint32_t Wimg, const void* d_counts, const void* d_matches,
+                             const void* d_mxyz, uint32_t k, const float* spans, uint32_t n_objs,
+                             const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
+                             uint32_t* pose_ptr, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  if (!ctx || !prm || !rng || !n_poses || !n_inlier_kp || (*n_poses && !poses) || (*n_inlier_kp && !inlier_kp) || F == 0)
+    return TODHIP_EINVAL;
+  int rc = verify_prologue(ctx, prm);
   if (rc != TODHIP_OK) return rc;
   const uint32_t pose_cap = *n_poses, kp_cap = *n_inlier_kp;
   *n_poses = 0; *n_inlier_kp = 0;
+  if (pose_ptr) for (uint32_t f = 0; f <= F; ++f) pose_ptr[f] = 0;
   if ((!d_cloud && !dep) || H == 0 || Wimg == 0) return TODHIP_OK;
   if (nq == 0 || n_objs == 0) return TODHIP_OK;
   if (!d_kp_xy || !d_counts || !d_matches || !d_mxyz || !spans || k == 0) return TODHIP_EINVAL;
-  TOD_HIP(hipSetDevice(ctx->device));
-  rc = set_big_lds_once(ctx);
-  if (rc != TODHIP_OK) return rc;
-  VerifyWs* ws = ws_of(ctx);
-  hipStream_t st = ctx->stream;
-  const size_t cap = (size_t)nq * k;
-  TOD_HIP(ws->small.reserve(256 * sizeof(uint32_t)));
-  TOD_HIP(ws->h_small.reserve((256 + (size_t)n_objs + 8) * sizeof(uint32_t)));
-  TOD_HIP(ws->c_kept.reserve((size_t)nq * 4)); TOD_HIP(ws->c_offs.reserve(((size_t)nq + 1) * 4));
-  TOD_HIP(ws->c_qpt.reserve((size_t)nq * 12)); TOD_HIP(ws->c_obj.reserve(cap * 4));
-  TOD_HIP(ws->c_hist.reserve((size_t)n_objs * 4)); TOD_HIP(ws->c_goff.reserve((size_t)n_objs * 4));
-  TOD_HIP(ws->f_train.reserve(cap * 12)); TOD_HIP(ws->f_query.reserve(cap * 12));
-  TOD_HIP(ws->f_qidx.reserve(cap * 4)); TOD_HIP(ws->f_kp.reserve(cap * 8));
-  TOD_HIP(ws->train.reserve(cap * 12)); TOD_HIP(ws->query.reserve(cap * 12));
-  TOD_HIP(ws->qidx.reserve(cap * 4)); TOD_HIP(ws->kpxy.reserve(cap * 8));
-  uint32_t* d_small = ws->small.as<uint32_t>();
-  TOD_HIP(hipMemsetAsync(d_small + 60, 0, sizeof(uint32_t), st));
-  TOD_HIP(hipMemsetAsync(ws->c_hist.p, 0, (size_t)n_objs * 4, st));
-  if (dep)
-    hipLaunchKernelGGL(cluster_lookup_depth_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, st, (const float*)d_kp_xy, nq,
-                       dep->d_depth, dep->is_u16, H, Wimg, dep->fx, dep->fy, dep->cx, dep->cy, (const uint32_t*)d_counts,
-                       ws->c_kept.as<uint32_t>(), ws->c_qpt.as<float>(), d_small + 60);
-  else
-    hipLaunchKernelGGL(cluster_lookup_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, st, (const float*)d_kp_xy, nq,
-                       (const float*)d_cloud, H, Wimg, (const uint32_t*)d_counts, ws->c_kept.as<uint32_t>(),
-                       ws->c_qpt.as<float>(), d_small + 60);
-  hipLaunchKernelGGL(cluster_scan_kernel, dim3(1), dim3(1024), 0, st, ws->c_kept.as<uint32_t>(), nq, ws->c_offs.as<uint32_t>());
-  hipLaunchKernelGGL(cluster_scatter_kernel, dim3((uint32_t)((cap + 255u) / 256u)), dim3(256), 0, st, (const float*)d_kp_xy, nq, k,
-                     (const todhip_dmatch*)d_matches, (const float*)d_mxyz, ws->c_kept.as<uint32_t>(),
-                     ws->c_offs.as<uint32_t>(), ws->c_qpt.as<float>(), n_objs, ws->c_obj.as<uint32_t>(),
-                     ws->c_hist.as<uint32_t>(), ws->f_train.as<float>(), ws->f_query.as<float>(),
-                     ws->f_qidx.as<uint32_t>(), ws->f_kp.as<float>(), d_small + 60);
-  TOD_HIP(hipGetLastError());
-  uint32_t* h = ws->h_small.as<uint32_t>();
-  TOD_HIP(hipMemcpyAsync(h + 200, d_small + 60, 4, hipMemcpyDeviceToHost, st));
-  TOD_HIP(hipMemcpyAsync(h + 201, ws->c_offs.as<uint32_t>() + nq, 4, hipMemcpyDeviceToHost, st));
-  TOD_HIP(hipMemcpyAsync(h + 256, ws->c_hist.p, (size_t)n_objs * 4, hipMemcpyDeviceToHost, st));
-  TOD_HIP(hipStreamSynchronize(st));
-  if (h[200] != 0) return TODHIP_ERANGE;
-  const uint32_t n_all = h[201];
-  if (n_all == 0) return TODHIP_OK;
-  std::vector<ObjSpan> spans_list;
-  TOD_HIP(ws->h_goff.reserve((size_t)n_objs * 4));
-  uint32_t* goff = ws->h_goff.as<uint32_t>();           // pinned and owned by the workspace: no sync needed
-  uint32_t total = 0;
-  for (uint32_t o = 0; o < n_objs; ++o) {
-    goff[o] = total;
-    if (h[256 + o]) spans_list.push_back({o, total, h[256 + o]});
-    total += h[256 + o];
+  Engine E = {ctx, ctx->stream, nq, H, Wimg, k, n_objs, spans, prm, {}};
+  std::vector<Slot> slots(F);
+  std::vector<Slot*> live;
+  const size_t px = (size_t)H * Wimg;
+  for (uint32_t f = 0; f < F; ++f) {
+    Slot& s = slots[f];
+    s.ws = ws_of(ctx, f);
+    s.rng = rng + f;
+    s.d_kp_xy = reinterpret_cast<const float*>(d_kp_xy) + (size_t)f * nq * 2;
+    s.d_counts = reinterpret_cast<const uint32_t*>(d_counts) + (size_t)f * nq;
+    s.d_matches = reinterpret_cast<const todhip_dmatch*>(d_matches) + (size_t)f * nq * k;
+    s.d_mxyz = reinterpret_cast<const float*>(d_mxyz) + (size_t)f * nq * k * 3;
+    if (dep) {
+      s.use_depth = true;
+      s.dep = *dep;
+      s.dep.d_depth = reinterpret_cast<const unsigned char*>(dep->d_depth) + (size_t)f * px * (dep->is_u16 ? 2 : 4);
+    } else {
+      s.d_cloud = reinterpret_cast<const float*>(d_cloud) + (size_t)f * px * 3;
+    }
+    rc = E.reserve_common(s);
+    if (rc != TODHIP_OK) return rc;
+    rc = E.reserve_cluster(s);
+    if (rc != TODHIP_OK) return rc;
+    s.ph = PH_CLUSTER;
+    live.push_back(&s);
   }
-  TOD_HIP(hipMemcpyAsync(ws->c_goff.p, goff, (size_t)n_objs * 4, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(cluster_group_kernel, dim3((n_all + 255u) / 256u), dim3(256), 0, st, n_all, ws->c_obj.as<uint32_t>(),
-                     ws->c_goff.as<uint32_t>(), ws->f_train.as<float>(), ws->f_query.as<float>(),
-                     ws->f_qidx.as<uint32_t>(), ws->f_kp.as<float>(), ws->train.as<float>(), ws->query.as<float>(),
-                     ws->qidx.as<uint32_t>(), ws->kpxy.as<float>());
-  TOD_HIP(hipGetLastError());
-  return verify_grouped(ctx, ws, spans_list, nq, spans, prm, rng, poses, pose_cap, n_poses, inlier_kp, kp_cap, n_inlier_kp);
+  rc = E.run(live);
+  const int rc2 = collect(ctx, slots, poses, pose_cap, n_poses, pose_ptr, inlier_kp, kp_cap, n_inlier_kp);
+  return rc != TODHIP_OK ? rc : rc2;
 }
 
 int todhip_verify_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const void* d_cloud, uint32_t H,
                          uint32_t Wimg, const void* d_counts, const void* d_matches, const void* d_mxyz, uint32_t k,
                          const float* spans, uint32_t n_objs, const todhip_verify_params* prm, todhip_rng* rng,
                          todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
-  return verify_device_impl(ctx, d_kp_xy, nq, d_cloud, nullptr, H, Wimg, d_counts, d_matches, d_mxyz, k, spans, n_objs,
-                            prm, rng, poses, n_poses, inlier_kp, n_inlier_kp);
+  return verify_batch_impl(ctx, 1, d_kp_xy, nq, d_cloud, nullptr, H, Wimg, d_counts, d_matches, d_mxyz, k, spans, n_objs, prm, rng,
+                           poses, n_poses, nullptr, inlier_kp, n_inlier_kp);
 }
 
 int todhip_verify_device_depth(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const void* d_depth, int depth_is_u16,
@@ -1833,8 +2088,29 @@ int todhip_verify_device_depth(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq
                                uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
   if (!d_depth || !K9) return TODHIP_EINVAL;
   DepthInput dep = {d_depth, depth_is_u16, K9[0], K9[4], K9[2], K9[5]};
-  return verify_device_impl(ctx, d_kp_xy, nq, nullptr, &dep, H, Wimg, d_counts, d_matches, d_mxyz, k, spans, n_objs, prm,
-                            rng, poses, n_poses, inlier_kp, n_inlier_kp);
+  return verify_batch_impl(ctx, 1, d_kp_xy, nq, nullptr, &dep, H, Wimg, d_counts, d_matches, d_mxyz, k, spans, n_objs, prm, rng,
+                           poses, n_poses, nullptr, inlier_kp, n_inlier_kp);
+}
+
+int todhip_verify_batch_device(todhip_ctx* ctx, uint32_t n_frames, const void* d_kp_xy, uint32_t nq, const void* d_cloud,
+                               uint32_t H, uint32_t Wimg, const void* d_counts, const void* d_matches, const void* d_mxyz,
+                               uint32_t k, const float* spans, uint32_t n_objs, const todhip_verify_params* prm,
+                               todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses, uint32_t* pose_ptr,
+                               uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  if (!pose_ptr) return TODHIP_EINVAL;
+  return verify_batch_impl(ctx, n_frames, d_kp_xy, nq, d_cloud, nullptr, H, Wimg, d_counts, d_matches, d_mxyz, k, spans, n_objs,
+                           prm, rng, poses, n_poses, pose_ptr, inlier_kp, n_inlier_kp);
+}
+
+int todhip_verify_batch_device_depth(todhip_ctx* ctx, uint32_t n_frames, const void* d_kp_xy, uint32_t nq, const void* d_depth,
+                                     int depth_is_u16, uint32_t H, uint32_t Wimg, const float* K9, const void* d_counts,
+                                     const void* d_matches, const void* d_mxyz, uint32_t k, const float* spans, uint32_t n_objs,
+                                     const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
+                                     uint32_t* pose_ptr, uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  if (!d_depth || !K9 || !pose_ptr) return TODHIP_EINVAL;
+  DepthInput dep = {d_depth, depth_is_u16, K9[0], K9[4], K9[2], K9[5]};
+  return verify_batch_impl(ctx, n_frames, d_kp_xy, nq, nullptr, &dep, H, Wimg, d_counts, d_matches, d_mxyz, k, spans, n_objs, prm,
+                           rng, poses, n_poses, pose_ptr, inlier_kp, n_inlier_kp);
 }
 
 int todhip_verify_trace(const todhip_ctx* ctx, todhip_round_trace* out, uint32_t* n) {
@@ -1864,7 +2140,8 @@ int todhip_test_adjacency(todhip_ctx* ctx, const float* train, const float* quer
   job.n = n; job.W = W;
   job.train = ws->train.as<float>(); job.query = ws->query.as<float>(); job.kpxy = ws->kpxy.as<float>();
   job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
-  hipLaunchKernelGGL(adjacency_kernel, dim3(n, (W + 3u) / 4u), dim3(256), 0, st, job, span, err);
+  launch_list(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
+              [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
   TOD_HIP(hipGetLastError());
   TOD_HIP(hipMemcpyAsync(phys, ws->phys.p, (size_t)n * W * 8, hipMemcpyDeviceToHost, st));
   TOD_HIP(hipMemcpyAsync(samp, ws->samp.p, (size_t)n * W * 8, hipMemcpyDeviceToHost, st));
@@ -1910,9 +2187,11 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   uint32_t* d_small = ws->small.as<uint32_t>();
   uint32_t* h_small = ws->h_small.as<uint32_t>();
   TOD_HIP(hipMemsetAsync(d_small, 0, 64 * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(finite_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, job);
-  hipLaunchKernelGGL(adjacency_kernel, dim3(n, (W + 3u) / 4u), dim3(256), 0, st, job, span, err);
-  hipLaunchKernelGGL(round_prep_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, job, d_small);
+  launch_list(st, finite_kernel, std::vector<JobArgs>{{job}}, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+  launch_list(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
+              [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
+  launch_list(st, round_prep_kernel, std::vector<PrepArgs>{{job, d_small}}, 256, 0, 1,
+              [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
   EvalArgs A;
   A.job = job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = 0; A.it_end = n_triples;
   A.counts = ws->counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
@@ -1921,7 +2200,7 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   A.adjc_scratch = nullptr;
   A.dbg = dbg ? ws->table.as<uint32_t>() : nullptr; A.dbg_stride = dbg_stride; A.stop_level = stop_level;
   if (n_triples > kMaxEvalWaves) return TODHIP_EINVAL;
-  hipLaunchKernelGGL(eval_kernel, dim3(n_triples), dim3(64), kEvalLdsSmall, st, A);
+  launch_list(st, eval_kernel, std::vector<EvalArgs>{A}, 64, kEvalLdsSmall, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
   TOD_HIP(hipGetLastError());
   TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   TOD_HIP(hipStreamSynchronize(st));
@@ -1931,7 +2210,7 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
     TOD_HIP(ws->adjc_scratch.reserve((size_t)n_def * kAdjcScratchWords * sizeof(u64)));
     A.adjc_scratch = ws->adjc_scratch.as<u64>();
     TOD_HIP(hipMemsetAsync(d_small + 8, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(eval_kernel, dim3(n_def), dim3(64), kEvalLdsBig, st, A);
+    launch_list(st, eval_kernel, std::vector<EvalArgs>{A}, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
     TOD_HIP(hipGetLastError());
     TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     TOD_HIP(hipStreamSynchronize(st));
