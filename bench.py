@@ -49,7 +49,6 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
     ap.add_argument("--stages", default="orb,match,verify", help="comma list of: orb,match,verify")
     ap.add_argument("--batch", type=int, default=16, help="frames per rank per step")
-    ap.add_argument("--verify-workers", type=int, default=6, help="ORB + verifier contexts (frames in flight beside the matcher)")
     ap.add_argument("--iterations", type=int, default=2500, help="n_ransac_iterations (conf/detection.ork:38)")
     ap.add_argument("--min-inliers", type=int, default=8, help="min_inliers (conf/detection.ork:39)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
@@ -128,42 +127,47 @@ def main():
     do_orb = "orb" in stages
     B = args.batch                                   # frames per rank per step
     from concurrent.futures import ThreadPoolExecutor
-    from tod_amd import sharded
+    from math import gcd
     # frame f belongs to rank (f % world); every rank keeps its own frames resident in HBM
-    my_frames = [fr for f, fr in enumerate(frames) if f % world == rank] or [frames[rank % len(frames)]]
-    d_q = [torch.from_numpy(fr["q_desc"]).cuda() for fr in my_frames]
-    d_kp = [torch.from_numpy(fr["kp_xy"]).cuda() for fr in my_frames]
-    d_cloud = [torch.from_numpy(fr["cloud"]).cuda() for fr in my_frames] if do_verify else []
+    my_ids = [f for f in range(len(frames)) if f % world == rank] or [rank % len(frames)]
+    n_my = len(my_ids)
+    H, W = frames[0]["cloud"].shape[:2]
+    # A step is a batch of B frames: frame (i * B + b) % n_my of this rank's frames, b = 0..B-1. The batches repeat
+    # with a short period, so each distinct batch is laid out once as contiguous [B, ...] arrays (what a camera
+    # driver handing over B frames would provide).
+    period = n_my // gcd(B, n_my)
+
+    def batch_of(v, key, dtype=None):
+        arrs = [frames[my_ids[(v * B + b) % n_my]][key] for b in range(B)]
+        return torch.from_numpy(np.ascontiguousarray(np.stack(arrs), dtype=dtype)).cuda()
+
+    Q_B = [batch_of(v, "q_desc") for v in range(period)]                            # [B, Q, 32]
+    KP_B = [batch_of(v, "kp_xy", np.float32) for v in range(period)]                # [B, Q, 2]
+    CLOUD_B = [batch_of(v, "cloud", np.float32) for v in range(period)] if do_verify else []   # [B, H, W, 3]
     # stage A runs on the SURVEY 8(d) synthetic grey image of the frame. Its descriptors are not the matcher's input
     # (random-image ORB descriptors cannot match a synthetic DB; the frame's planted descriptors do that), but its
-    # work is part of every frame: it runs on the frame's worker context, overlapped with the next batch's matching.
-    my_ids = [f for f in range(len(frames)) if f % world == rank] or [rank % len(frames)]
-    d_img = [torch.from_numpy(frames[f]["image"]).cuda() for f in my_ids] if do_orb else []
-    H, W = frames[0]["cloud"].shape[:2]
-    # matcher outputs, double buffered: the verifiers of step s read set (s % 2) while step s+1 fills the other
-    outs = [[dict(counts=torch.empty(nq, dtype=torch.int32, device="cuda"),
-                  matches=torch.empty((nq * k, 4), dtype=torch.int32, device="cuda"),
-                  xyz=torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(B)] for _ in range(2)]
+    # work is part of every frame and the matcher of a step starts only when that step's ORB batch is done.
+    IMG_B = [batch_of(v, "image") for v in range(period)] if do_orb else []         # [B, H, W]
+    # matcher outputs, ring of D step buffers: the verifier of step s reads set (s % D) while later steps fill the others
+    D = 3
+    outs = [dict(counts=torch.empty(B * nq, dtype=torch.int32, device="cuda"),
+                 matches=torch.empty((B * nq * k, 4), dtype=torch.int32, device="cuda"),
+                 xyz=torch.empty((B * nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(D)]
     d_keys = torch.empty((world * B * nq, k), dtype=torch.int64, device="cuda")
-    # verification is latency bound (host round trips + a single-wave clique search), so several frames are
-    # verified concurrently, each on its own context/stream; matching of the next step overlaps with it
-    n_workers = max(1, min(args.verify_workers, B)) if (do_verify or do_orb) else 0
-    # high-priority streams: the verifier's short kernels must not queue behind the matcher's full-chip launches
-    vstreams = [torch.cuda.Stream(priority=-1) for _ in range(n_workers)]
-    vctx = [capi.Context(local_rank, vs.cuda_stream) for vs in vstreams]
-    for c, vs in zip(vctx, vstreams):
-        c.tstream = vs
-    pool = ThreadPoolExecutor(n_workers) if n_workers else None
-    import queue
-    free_ctx = queue.Queue()                          # one call in flight per context
-    for c in vctx:
-        c.orb_out = (torch.empty((args.nq, 2), device="cuda"), torch.empty((args.nq, 4), device="cuda"),
-                     torch.empty((args.nq, 32), dtype=torch.uint8, device="cuda"))
-        free_ctx.put(c)
+    # Three stages, three streams, three host threads: ORB batch (step s+1..s+2) | matcher (step s, this thread: it owns
+    # torch's current stream and the collectives) | verifier batch (step s-1). Every stage call covers the B frames of
+    # a step in the launches of one frame (todhip_orb_batch_device, todhip_verify_batch_device).
+    ostream, vstream = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)
+    octx = capi.Context(local_rank, ostream.cuda_stream) if do_orb else None
+    vctx = capi.Context(local_rank, vstream.cuda_stream) if do_verify else None
+    orb_out = (torch.empty((B, nq, 2), device="cuda"), torch.empty((B, nq, 4), device="cuda"),
+               torch.empty((B, nq, 32), dtype=torch.uint8, device="cuda")) if do_orb else None
+    opool = ThreadPoolExecutor(1) if do_orb else None
+    vpool = ThreadPoolExecutor(1) if do_verify else None
+    stage_s = {"orb": 0.0, "match_issue": 0.0, "verify": 0.0}
     n_kp_total = [0]
     n_pose_total = [0]
-    from collections import deque
-    pending = deque()                                  # one list of futures per step in flight
+    n_steps_done = [0]
 
     def alloc(shape, dtype_name):
         return torch.empty(shape, dtype=getattr(torch, dtype_name), device="cuda")
@@ -176,80 +180,81 @@ def main():
             dist.all_gather(parts, inp.contiguous().view(-1).cpu())
             out.view(-1).copy_(torch.cat(parts).to(out.device))
 
-    def verify_task(f, o, ev):
-        c = free_ctx.get()
-        try:
-            c.tstream.wait_event(ev)                   # this step's matcher outputs (recorded on the main stream)
-            n_kp = 0
-            t_a = time.perf_counter()
-            if do_orb:
-                n_kp = c.orb_device(d_img[f].data_ptr(), H, W, W, args.nq, 3, 1.2, c.orb_out[0].data_ptr(),
-                                              c.orb_out[1].data_ptr(), c.orb_out[2].data_ptr(), args.nq)
-            poses = []
-            t_b = time.perf_counter()
-            if do_verify:
-                rng = capi.rng_new(1)                 # rand() restarts per frame (decision D4)
-                poses = c.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), H, W, o["counts"].data_ptr(),
-                                        o["matches"].data_ptr(), o["xyz"].data_ptr(), k, db_spans, args.min_inliers,
-                                        args.iterations, 0.01, rng)
-            t_c = time.perf_counter()
-            c.t_orb = getattr(c, "t_orb", 0.0) + (t_b - t_a)
-            c.t_verify = getattr(c, "t_verify", 0.0) + (t_c - t_b)
-            c.n_frames = getattr(c, "n_frames", 0) + 1
-        finally:
-            free_ctx.put(c)
-        return len(poses), n_kp
+    def orb_task(i):
+        t = time.perf_counter()
+        n = octx.orb_batch_device(IMG_B[i % period].data_ptr(), B, H * W, H, W, W, nq, 3, 1.2, orb_out[0].data_ptr(),
+                                  orb_out[1].data_ptr(), orb_out[2].data_ptr(), nq)
+        stage_s["orb"] += time.perf_counter() - t
+        return sum(n)
 
-    def drain(keep=0):
-        while len(pending) > keep:
-            for fut in pending.popleft():
-                n_p, n_k = fut.result()
-                n_pose_total[0] += n_p
-                n_kp_total[0] += n_k
+    def verify_task(i, ev):
+        vstream.wait_event(ev)                          # this step's matcher outputs (recorded on the matcher's stream)
+        t = time.perf_counter()
+        o = outs[i % D]
+        rngs = (capi.Rng * B)(*[capi.rng_new(1) for _ in range(B)])   # rand() restarts per frame (decision D4)
+        poses = vctx.verify_batch_device(B, KP_B[i % period].data_ptr(), nq, CLOUD_B[i % period].data_ptr(), H, W,
+                                         o["counts"].data_ptr(), o["matches"].data_ptr(), o["xyz"].data_ptr(), k, db_spans,
+                                         args.min_inliers, args.iterations, 0.01, rngs)
+        stage_s["verify"] += time.perf_counter() - t
+        return sum(len(p) for p in poses)
 
-    def step(i):
-        if n_workers:
-            drain(keep=1)                              # buffers of step i-2 are free again; step i-1 keeps running
-        buf = outs[i % 2]
-        fidx = [(i * B + b) % len(d_q) for b in range(B)]
+    def match_step(i):
+        o = outs[i % D]
+        q = Q_B[i % period]
         if world == 1:
-            for b in range(B):                         # single device: no key exchange
-                ctx.match_device(d_q[fidx[b]].data_ptr(), nq, k, args.radius, buf[b]["counts"].data_ptr(),
-                                 buf[b]["matches"].data_ptr(), buf[b]["xyz"].data_ptr())
+            for b in range(B):                         # single device: no key exchange; one DB pass per frame
+                ctx.match_device(q[b].data_ptr(), nq, k, args.radius, o["counts"][b * nq:].data_ptr(),
+                                 o["matches"][b * nq * k:].data_ptr(), o["xyz"][b * nq * k:].data_ptr())
         else:
             # tod_amd/sharded.py with B frames per rank: gather descriptors, match all world*B frames against this
             # rank's shard, all-gather the candidates, merge this rank's B frames
-            mine = torch.stack([d_q[f] for f in fidx])                              # [B, Q, 32]
             q_all = alloc((world, B, nq, 32), "uint8")
-            all_gather(q_all, mine)
+            all_gather(q_all, q)
             ctx.match_shard_device(q_all.data_ptr(), world * B * nq, k, args.radius, d_keys.data_ptr())
             keys_all = alloc((world, world, B, nq, k), "int64")                     # [shard][rank][b][Q][k]
             all_gather(keys_all, d_keys)
-            for b in range(B):
-                km = keys_all[:, rank, b].contiguous()                              # [shard][Q][k]
-                ctx.merge_shards_device(km.data_ptr(), world, nq, k, args.radius, buf[b]["counts"].data_ptr(),
-                                        buf[b]["matches"].data_ptr(), buf[b]["xyz"].data_ptr())
-        if n_workers:
-            ev = torch.cuda.Event()
-            ev.record(stream)                          # the matcher outputs of this step are complete after this
-            pending.append([pool.submit(verify_task, fidx[b], buf[b], ev) for b in range(B)])
+            km = keys_all[:, rank].contiguous()                                     # [shard][B*Q][k]
+            ctx.merge_shards_device(km.data_ptr(), world, B * nq, k, args.radius, o["counts"].data_ptr(),
+                                    o["matches"].data_ptr(), o["xyz"].data_ptr())
+
+    def run_steps(n_steps):
+        """ORB(i) -> match(i) -> verify(i); ORB runs up to D steps ahead, the matcher up to D - 1 steps ahead of the verifier."""
+        ofut, vfut = {}, {}
+        for j in range(min(D, n_steps)):
+            if do_orb:
+                ofut[j] = opool.submit(orb_task, j)
+        for i in range(n_steps):
+            if do_verify and i - D in vfut:
+                n_pose_total[0] += vfut.pop(i - D).result()          # buffer set i % D is free again
+            if do_orb:
+                n_kp_total[0] += ofut.pop(i).result()
+                if i + D < n_steps:
+                    ofut[i + D] = opool.submit(orb_task, i + D)
+            t = time.perf_counter()
+            match_step(i)
+            stage_s["match_issue"] += time.perf_counter() - t
+            if do_verify:
+                ev = torch.cuda.Event()
+                ev.record(stream)                      # the matcher outputs of this step are complete after this
+                vfut[i] = vpool.submit(verify_task, i, ev)
+        for i in sorted(vfut):
+            n_pose_total[0] += vfut[i].result()
+        n_steps_done[0] += n_steps
 
     def fence():
-        if n_workers:
-            drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    run_steps(args.warmup)
     fence()
+    for key in stage_s:
+        stage_s[key] = 0.0
     ctx.set_kernel_timing(True)
     c0 = ctx.counters()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     c1 = ctx.counters()
@@ -296,14 +301,12 @@ def main():
                                    "Hamming BF k=%d, radius %d" % (nq, desc.shape[0], args.objects, k, args.radius),
                        "stages": stages, "db_rows_per_gpu": info["shard_rows"],
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
-                       "poses_per_frame_rank0": n_pose_total[0] / max((args.steps + args.warmup) * B, 1),
-                       "frames_per_rank_per_step": B, "verify_workers": n_workers,
-                       "worker_ms_per_frame": {"orb": 1e3 * sum(getattr(c, "t_orb", 0.0) for c in vctx) /
-                                               max(sum(getattr(c, "n_frames", 0) for c in vctx), 1),
-                                               "verify": 1e3 * sum(getattr(c, "t_verify", 0.0) for c in vctx) /
-                                               max(sum(getattr(c, "n_frames", 0) for c in vctx), 1)} if n_workers else None,
+                       "poses_per_frame_rank0": n_pose_total[0] / max(n_steps_done[0] * B, 1),
+                       "frames_per_rank_per_step": B,
+                       "pipeline": "3 stages on 3 streams, each one batched call per step: ORB | matcher | verifier",
+                       "stage_ms_per_step": {key: 1e3 * v / max(args.steps, 1) for key, v in stage_s.items()},
                        "orb": "ORB-%d, 3 levels, scale 1.2 on the 8(d) synthetic image; %.0f keypoints/frame" %
-                              (args.nq, n_kp_total[0] / max((args.steps + args.warmup) * B, 1)) if do_orb else None,
+                              (args.nq, n_kp_total[0] / max(n_steps_done[0] * B, 1)) if do_orb else None,
                        "frames_per_step": world * B,
                        "parallelism": ("DB rows sharded x%d (object aligned), %d frames per rank per step, RCCL all-gather of "
                                        "descriptors and of per-shard candidates" % (world, B)) if world > 1 else "1 GPU"},
@@ -321,8 +324,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
                                                args.iterations, args.min_inliers)
         print(json.dumps(out))
-    for c in vctx:
-        c.close()
+    for c in (octx, vctx):
+        if c is not None:
+            c.close()
     ctx.close()
     if world > 1:
         dist.barrier()
