@@ -202,9 +202,9 @@ def main():
         o = outs[i % D]
         q = Q_B[i % period]
         if world == 1:
-            for b in range(B):                         # single device: no key exchange; one DB pass per frame
-                ctx.match_device(q[b].data_ptr(), nq, k, args.radius, o["counts"][b * nq:].data_ptr(),
-                                 o["matches"][b * nq * k:].data_ptr(), o["xyz"][b * nq * k:].data_ptr())
+            # single device: no key exchange; the B frames' descriptors share one pass over the DB
+            ctx.match_device(q.data_ptr(), B * nq, k, args.radius, o["counts"].data_ptr(), o["matches"].data_ptr(),
+                             o["xyz"].data_ptr())
         else:
             # tod_amd/sharded.py with B frames per rank: gather descriptors, match all world*B frames against this
             # rank's shard, all-gather the candidates, merge this rank's B frames
@@ -267,10 +267,9 @@ def main():
 
     n_launch = c1.n_match_kernel_launches - c0.n_match_kernel_launches
     k4_ms = (c1.sum_match_kernel_ms - c0.sum_match_kernel_ms) / max(n_launch, 1)
-    frames_per_launch = B if world > 1 else 1
+    frames_per_launch = B                                          # one launch matches the world*B frames of a step
     alg_bytes = info["shard_rows"] * 32 + world * frames_per_launch * nq * (32 + k * 8)   # N*32 + F*Q*(32 + k*8)
     achieved = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
-    frames_per_launch = B if world > 1 else 1                      # sharded: one launch matches world*B frames
     distances = float(nq) * world * frames_per_launch * info["shard_rows"]
 
     # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, collected in their own
@@ -282,8 +281,9 @@ def main():
     # workload is the profiled one, else the dense count is used and the figure is an upper bound.
     laneops, laneops_src = float(LANEOPS_DENSE), "dense instruction count (upper bound)"
     pmc_path = os.path.join(ROOT, "profiles", "r01_k4_pmc.json")
-    if world == 1 and nq == 1000 and k == 2 and info["shard_rows"] == 1000000 and args.radius == 35 and os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))
+    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+    if (world == 1 and k == 2 and info["shard_rows"] == 1000000 and args.radius == 35 and
+            pmc.get("queries_per_launch") == B * nq):
         traffic = pmc["hbm_traffic_bytes_per_launch"]
         traffic_src = "profiles/r01_k4_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         if "valu_insts_per_row_and_wave" in pmc:
@@ -313,8 +313,9 @@ def main():
             "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,
-                         "note": "at Q=%d queries per DB pass this kernel is bound by integer VALU issue, not HBM "
-                                 "(SURVEY F11): see valu_roofline" % nq},
+                         "queries_per_launch": world * B * nq,
+                         "note": "at %d queries per DB pass this kernel is bound by integer VALU issue, not HBM "
+                                 "(SURVEY F11): see valu_roofline" % (world * B * nq)},
             "valu_roofline": {"bound": "valu", "achieved": laneops * distances / (k4_ms * 1e-3) / 1e12
                               if k4_ms > 0 else 0.0, "peak": VALU_PEAK_LANEOPS / 1e12, "unit": "T lane-op/s",
                               "frac": valu_frac, "distances_per_launch": distances, "valu_ops_per_distance": laneops,

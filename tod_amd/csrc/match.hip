@@ -92,10 +92,13 @@ __device__ __forceinline__ uint32_t hamming256_mem(const uint32_t (&q)[kWords], 
 template <int K>
 __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], const RowGroup& g, uint32_t r,
                                               uint32_t (&best)[K], uint32_t& worst_d, uint32_t& limit, uint32_t foreign) {
-  uint32_t d0 = hamming128<0, 0>(qd, g.lo, 0u);
-  uint32_t d1 = hamming128<1, 0>(qd, g.lo, 0u);
-  uint32_t d2 = hamming128<0, 0>(qd, g.hi, 0u);
-  uint32_t d3 = hamming128<1, 0>(qd, g.hi, 0u);
+  // the four rows' accumulate chains are interleaved word by word: no instruction depends on its predecessor
+  uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t x0 = qd[w] ^ g.lo[w], x1 = qd[w] ^ g.lo[kWords + w], x2 = qd[w] ^ g.hi[w], x3 = qd[w] ^ g.hi[kWords + w];
+    d0 = bcnt_acc(x0, d0); d1 = bcnt_acc(x1, d1); d2 = bcnt_acc(x2, d2); d3 = bcnt_acc(x3, d3);
+  }
   uint32_t dmin = min(min(d0, d1), min(d2, d3));
   if (__builtin_amdgcn_ballot_w64(dmin < limit) == 0ull) return;      // lower bounds already out: skip the second half
   d0 = hamming128<0, 4>(qd, g.lo, d0);

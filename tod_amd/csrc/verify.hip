@@ -1637,7 +1637,7 @@ struct Engine {
       A.job = s.job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = r.it_begin; A.it_end = r.it_drawn;
       A.counts = ws->m_counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
       A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>(); A.stacks = ws->stacks.as<uint16_t>();
-      A.stack_cap = kStackCap; A.lds_bytes = second ? kEvalLdsBig : kEvalLdsSmall; A.from_deferred = second ? 1u : 0u;
+      A.stack_cap = kStackCap; A.lds_bytes = second ? kEvalLdsBig : eval_lds_small(s.job.n); A.from_deferred = second ? 1u : 0u;
       A.n_deferred = second ? r.n_def : 0u;
       A.adjc_scratch = nullptr; A.dbg = nullptr; A.dbg_stride = 0; A.stop_level = 0;
       if (second) {                                         // graphs that need the whole LDS of a CU, or global scratch
@@ -1856,6 +1856,14 @@ struct Engine {
     return TODHIP_OK;
   }
 
+  // first-pass LDS per hypothesis: the induced graph has at most n vertices, so a small object does not need the
+  // whole 48 KB carve (adjacency + colouring scratch + 4 KB of level stack) and more hypotheses fit a CU at once
+  static uint32_t eval_lds_small(uint32_t n) {
+    const uint32_t W = (n + 63u) / 64u;
+    const uint32_t want = gate_lds_bytes(n) + 8u * n * W + 4096u;
+    return std::min(kEvalLdsSmall, std::max(8192u, (want + 1023u) & ~1023u));
+  }
+
   void launch_all() {
     auto words = [](const CopyArgs& a) { return dim3(std::max(1u, std::min(64u, (a.n + 255u) / 256u))); };
     launch_list(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
@@ -1871,7 +1879,13 @@ struct Engine {
     launch_list(st, round_prep_kernel, L.prep, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
     launch_list(st, draw_table_kernel, L.draw, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 3u) / 4u); });
     launch_list(st, chain_kernel, L.chain, 64, 0, 0, [](const ChainArgs&) { return dim3(1); });
-    launch_list(st, eval_kernel, L.eval_small, 64, kEvalLdsSmall, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+    {
+      // one dynamic LDS size per launch: the largest any slot of the launch wants; every slot carves that much
+      uint32_t lds = 8192u;
+      for (const EvalArgs& a : L.eval_small) lds = std::max(lds, a.lds_bytes);
+      for (EvalArgs& a : L.eval_small) a.lds_bytes = lds;
+      launch_list(st, eval_kernel, L.eval_small, 64, lds, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+    }
     launch_list(st, eval_kernel, L.eval_big, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
     launch_list(st, growth_kernel, L.growth, 256, 0, 0, [](const GrowthArgs&) { return dim3(1); });
     launch_list(st, copy_words_kernel, L.copy_out, 256, 0, 1, words);

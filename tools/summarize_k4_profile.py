@@ -26,12 +26,19 @@ for d in sorted(glob.glob(os.path.join(out, "prof_k4_pmc*"))):
         for c in acc:
             pmc[c] = acc[c] / len(n[c])
 traffic = (pmc.get("FETCH_SIZE", 0.0) + pmc.get("WRITE_SIZE", 0.0)) * 1024.0
-nq_waves, rows = 16, 1_000_000
+# the profiled command prints bench.py's JSON line: take the launch shape from it
+import re
+log = open(os.path.join(out, "prof_k4_trace.log")).read()
+bench = json.loads(re.findall(r"^\{.*\}$", log, re.M)[-1])
+queries = int(bench["roofline"]["queries_per_launch"])
+rows = int(bench["config"]["db_rows_per_gpu"])
+nq_waves = (queries + 63) // 64
 doc = {
     "kernel": "hamming_topk_tiles<2>",
     "command": "rocprofv3 --pmc <counters> -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --stages match "
                "(tools/profile_k4.sh; each counter set in its own pass; digested by tools/summarize_k4_profile.py)",
-    "workload": "C3: Q=1000, N=1,000,000 rows, k=2, radius 35 on one MI355X",
+    "workload": "C3: %d queries (a step's batch of frames) x %d DB rows per launch, k=2, radius 35 on one MI355X" % (queries, rows),
+    "queries_per_launch": queries,
     "avg_duration_ns_kernel_trace": avg_ns, "calls": calls, "pmc_per_launch": pmc,
     "hbm_traffic_bytes_per_launch": traffic,
     "valu_insts_per_row_and_wave": pmc.get("SQ_INSTS_VALU", 0.0) / (rows * nq_waves),
@@ -39,7 +46,7 @@ doc = {
     "note": "FETCH_SIZE/WRITE_SIZE are in KB. The DB rows are read with 64-byte scalar loads (s_load_dwordx16), not with "
             "wide coalesced vector loads, so the guide's x2 correction for 16 B/lane streams does not apply: FETCH_SIZE "
             "matches the 32.0 MB of DB rows + 32 KB of queries read once per launch; WRITE_SIZE is the per-tile partial "
-            "lists. SQ_INSTS_VALU / (1M rows x 16 query waves) = VALU instructions per row and wave: 8 xor + 8 popcount "
+            "lists. SQ_INSTS_VALU / (DB rows x 64-query waves) = VALU instructions per row and wave: 8 xor + 8 popcount "
             "for a full 256-bit distance, 4 + 4 when the 128-bit lower bound already rules the row out. "
             "GRBM_GUI_ACTIVE / 8 XCDs / duration = clock.",
 }
