@@ -96,6 +96,18 @@ int todhip_match(todhip_ctx*, const uint8_t* q_desc, uint32_t nq, uint32_t k, ui
 int todhip_match_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t k, uint32_t radius,
                         void* d_counts, void* d_matches, void* d_matches_xyz);
 
+/* Float descriptors (BASELINE.json configs[3]; not a reference feature -- the reference's matcher throws for anything
+ * but FLANN-LSH on binary descriptors, DescriptorMatcher.cpp:154-188): a DB loaded with desc_bytes == 512 (128 x f32 per
+ * row, one device) is searched by exact L2 k-NN, k <= 8. Result shape as todhip_match[_device] (DescriptorMatcher.cpp:
+ * 195-252): order (distance asc, global row asc), truncated at the first distance > radius; DMatch.distance =
+ * sqrtf(d2), d2 = sum over i = 0..127 in index order of (q[i] - r[i])^2 in IEEE binary32 without fused multiply-add
+ * (the CPU checker of this definition is oracle/l2_oracle.c). The candidates come from a
+ * bf16 MFMA GEMM with a proven error bound, the final order from the exact distances. */
+int todhip_match_l2(todhip_ctx*, const float* q_desc, uint32_t nq, uint32_t k, float radius, uint32_t* row_ptr,
+                    todhip_dmatch* matches, float* matches_xyz);
+int todhip_match_l2_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t k, float radius, void* d_counts,
+                           void* d_matches, void* d_matches_xyz);
+
 /* Sharded form, step 1: this shard's top-k per query as keys (distance << 32 | global_row), ascending,
  * UINT64_MAX padded; d_keys[nq*k]. The ranks exchange these with one RCCL all-gather. `radius` is the radius of
  * step 2: rows farther away never survive the truncation of DescriptorMatcher.cpp:212-220, so the search is

@@ -291,3 +291,29 @@ def train_erode4(mask):
     out = np.zeros_like(mk)
     lib().train_erode4(_p(mk, C.c_uint8), C.c_uint32(mk.shape[0]), C.c_uint32(mk.shape[1]), _p(out, C.c_uint8))
     return out
+
+
+# ------------------------------------------------------------------------------------------ float descriptors (C4)
+def l2_knn_keys(db, q, k):
+    db = np.ascontiguousarray(db, np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    keys = np.zeros((q.shape[0], k), np.uint64)
+    lib().l2_knn_keys(_p(db, C.c_float), C.c_uint64(db.shape[0]), C.c_uint32(db.shape[1]), _p(q, C.c_float),
+                      C.c_uint32(q.shape[0]), C.c_uint32(k), _p(keys, C.c_uint64))
+    return keys
+
+
+def l2_match(db, obj_off, db_pts, q, k, radius):
+    db = np.ascontiguousarray(db, np.float32)
+    q = np.ascontiguousarray(q, np.float32)
+    obj_off = np.ascontiguousarray(obj_off, np.uint32)
+    db_pts = np.ascontiguousarray(db_pts, np.float32)
+    nq = q.shape[0]
+    row_ptr = np.zeros(nq + 1, np.uint32)
+    m = np.zeros(nq * k, DMATCH_DTYPE)
+    xyz = np.zeros((nq * k, 3), np.float32)
+    rc = lib().l2_match(_p(db, C.c_float), _p(obj_off, C.c_uint32), C.c_uint32(len(obj_off) - 1), _p(db_pts, C.c_float),
+                        C.c_uint32(db.shape[1]), _p(q, C.c_float), C.c_uint32(nq), C.c_uint32(k), C.c_float(radius),
+                        _p(row_ptr, C.c_uint32), m.ctypes.data_as(C.c_void_p), _p(xyz, C.c_float))
+    n = int(row_ptr[nq])
+    return rc, row_ptr, m[:n].copy(), xyz[:n].copy()

@@ -1,0 +1,84 @@
+"""GPU parity of the float-descriptor matcher (BASELINE configs[3]: SIFT-128, L2 brute force as a bf16 MFMA GEMM with
+exact refinement) against oracle/l2_oracle.c. PARITY UNPINNED with respect to the reference: its matcher throws for
+anything but FLANN-LSH on binary descriptors (DescriptorMatcher.cpp:154-188); the oracle only DEFINES the result."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from tod_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _assert_same(ctx, desc, pts, off, q, k, radius):
+    row_ptr, m, xyz = ctx.match_l2(q, k, radius)
+    rc, o_row_ptr, o_m, o_xyz = O.l2_match(desc, off, pts, q, k, radius)
+    assert rc == 0
+    assert np.array_equal(row_ptr, o_row_ptr)
+    for f in ("queryIdx", "trainIdx", "imgIdx"):
+        assert np.array_equal(m[f], o_m[f]), f
+    assert np.array_equal(m["distance"], o_m["distance"])            # sqrtf of the same sequential f32 sum: bit-exact
+    assert np.array_equal(xyz, o_xyz)
+    return row_ptr, m
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 8])
+def test_sift_like_db_exact_indices_and_distances(ctx, k):
+    desc, pts, off = synth.make_sift_db(6, per_object=5000)                  # 30k rows
+    q, truth = synth.make_sift_queries(desc, 300, frame=k)
+    ctx.db_load(desc, pts, off)
+    row_ptr, m = _assert_same(ctx, desc, pts, off, q, k, 1.0e9)             # no radius cut: plain top-k
+    first = m[row_ptr[:-1][np.diff(row_ptr.astype(np.int64)) > 0]]
+    planted = truth >= 0
+    glob = off[first["imgIdx"]].astype(np.int64) + first["trainIdx"]
+    assert (glob[planted] == truth[planted]).mean() > 0.99                   # the planted rows are the nearest ones
+
+
+def test_radius_cut_ragged_and_tiny_dbs(ctx):
+    desc, pts, off = synth.make_sift_db(3, per_object=700)                   # 2100 rows: not a multiple of the 32-row tile
+    off = np.array([0, 700, 700, 2100], np.uint32)                           # an empty object in the middle
+    q, truth = synth.make_sift_queries(desc, 77, frame=9)
+    ctx.db_load(desc, pts, off)
+    for radius in (50.0, 136.0, 200.0, 400.0, 1.0e9):                        # planted matches sit at ~12 * sqrt(128) = 136
+        _assert_same(ctx, desc, pts, off, q, 3, radius)
+    # fewer rows than k
+    ctx.db_load(desc[:2], pts[:2], np.array([0, 2], np.uint32))
+    row_ptr, m = _assert_same(ctx, desc[:2], pts[:2], np.array([0, 2], np.uint32), q[:10], 5, 1.0e9)
+    assert (np.diff(row_ptr.astype(np.int64)) == 2).all()
+    with pytest.raises(capi.TodError):
+        ctx.match_l2(q, 9, 10.0)                                             # k > 8
+    with pytest.raises(capi.TodError):
+        ctx.match(np.zeros((4, 32), np.uint8), 2, 35)                        # the Hamming matcher refuses a float DB
+
+
+def test_adversarial_near_ties_use_the_exact_fallback(ctx):
+    """Many rows almost equidistant from the query: the bf16 filter cannot separate them, the candidate list of some
+    queries overflows and those queries are redone by the exact scan; the result must not change."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    base = rng.random(128, dtype=np.float32) * 100
+    desc = (base[None, :] + rng.normal(0, 0.05, (4000, 128))).astype(np.float32)    # a tight cluster: 4000 near ties
+    pts = rng.random((4000, 3)).astype(np.float32)
+    off = np.array([0, 4000], np.uint32)
+    q = (base[None, :] + rng.normal(0, 0.05, (40, 128))).astype(np.float32)
+    ctx.db_load(desc, pts, off)
+    _assert_same(ctx, desc, pts, off, q, 4, 1.0e9)
+
+
+def test_integer_valued_descriptors_and_duplicates(ctx):
+    """OpenCV's SIFT stores integer-valued floats 0..255; duplicates of a row must come out in row order."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    desc = rng.integers(0, 256, (5000, 128)).astype(np.float32)
+    desc[100] = desc[4000]; desc[2500] = desc[4000]                                     # three identical rows
+    pts = rng.random((5000, 3)).astype(np.float32)
+    off = np.array([0, 2000, 5000], np.uint32)
+    q = desc[[4000, 7, 4999]] + 0.0
+    ctx.db_load(desc, pts, off)
+    row_ptr, m = _assert_same(ctx, desc, pts, off, q, 3, 1.0e9)
+    assert list(off[m["imgIdx"][:3]] + m["trainIdx"][:3]) == [100, 2500, 4000] and (m["distance"][:3] == 0).all()

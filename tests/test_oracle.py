@@ -175,3 +175,26 @@ def test_train_observation_against_numpy():
         cam = R @ row + T
         u, v = cam[0] / cam[2] * 100 + 31.5, cam[1] / cam[2] * 100 + 23.5
         assert abs(cam[2] - 0.8) < 1e-5 and abs(u - kp[s, 0]) <= 2.5 and abs(v - kp[s, 1]) <= 2.5
+
+
+def test_l2_oracle_against_numpy():
+    """oracle/l2_oracle.c (the DEFINITION of the float-descriptor result, BASELINE configs[3]) against float64 numpy:
+    same neighbours wherever float64 separates them by more than the f32 summation error."""
+    from tod_amd import synth
+    desc, pts, off = synth.make_sift_db(2, per_object=1500)
+    q, truth = synth.make_sift_queries(desc, 40, frame=1)
+    k = 4
+    rc, row_ptr, m, xyz = O.l2_match(desc, off, pts, q, k, 1.0e9)
+    assert rc == 0 and (np.diff(row_ptr.astype(np.int64)) == k).all()
+    d2 = ((q[:, None, :].astype(np.float64) - desc[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    order = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    got = (off[m["imgIdx"]].astype(np.int64) + m["trainIdx"]).reshape(-1, k)
+    gap = np.diff(np.sort(d2, axis=1)[:, :k + 1], axis=1).min(axis=1)
+    clear = gap > 1.0                                               # f32 error of a 128-term sum at d2 ~ 1e5 is ~ 0.1
+    assert clear.sum() > 30 and np.array_equal(got[clear], order[clear])
+    assert np.allclose(m["distance"].reshape(-1, k), np.sqrt(np.take_along_axis(d2, got, axis=1)), rtol=1e-5)
+    assert np.array_equal(xyz, pts[got.reshape(-1)])
+    # radius truncation is strict: a cut exactly at a distance keeps it
+    r0 = float(m["distance"][1])
+    rc, row_ptr2, m2, _ = O.l2_match(desc, off, pts, q[:1], k, r0)
+    assert row_ptr2[1] == 2 and np.array_equal(m2["trainIdx"], m["trainIdx"][:2])

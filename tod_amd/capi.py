@@ -58,6 +58,7 @@ EXPORTS = [
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
     "todhip_orb_device", "todhip_verify_device_depth", "todhip_orb_batch_device",
     "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
+    "todhip_match_l2", "todhip_match_l2_device",
     "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
 ]
 
@@ -142,13 +143,14 @@ class Context:
 
     # ---------------------------------------------------------------- stage B
     def db_load(self, desc, pts, obj_off, shard_rank=0, shard_count=1):
-        """desc u8[N,B], pts f32[N,3], obj_off u32[n_obj+1] (rows of object o are obj_off[o]:obj_off[o+1])."""
-        desc = np.ascontiguousarray(desc, np.uint8)
+        """desc u8[N,32] (binary, Hamming) or f32[N,128] (float, L2), pts f32[N,3], obj_off u32[n_obj+1] (rows of object o
+        are obj_off[o]:obj_off[o+1])."""
+        desc = np.ascontiguousarray(desc, np.float32 if np.asarray(desc).dtype == np.float32 else np.uint8)
         pts = np.ascontiguousarray(pts, np.float32)
         obj_off = np.asarray(obj_off, np.int64)
         n_obj = len(obj_off) - 1
         objs = (TodObject * max(n_obj, 1))()
-        B = desc.shape[1] if desc.ndim == 2 else 32
+        B = (desc.shape[1] if desc.ndim == 2 else 32) * desc.itemsize
         for o in range(n_obj):
             lo, hi = int(obj_off[o]), int(obj_off[o + 1])
             objs[o].desc = desc.ctypes.data + lo * B
@@ -178,6 +180,24 @@ class Context:
         _check(rc, "todhip_match")
         n = int(row_ptr[nq])
         return row_ptr, m[:n].copy(), xyz[:n].copy()
+
+    def match_l2(self, q_desc, k, radius):
+        """Float descriptors, host-buffer form. Returns (row_ptr u32[nq+1], matches DMATCH[n], xyz f32[n,3])."""
+        q = np.ascontiguousarray(q_desc, np.float32)
+        nq = q.shape[0]
+        row_ptr = np.zeros(nq + 1, np.uint32)
+        m = np.zeros(max(nq * k, 1), DMATCH_DTYPE)
+        xyz = np.zeros((max(nq * k, 1), 3), np.float32)
+        rc = lib().todhip_match_l2(self._h, _np_ptr(q), C.c_uint32(nq), C.c_uint32(k), C.c_float(radius), _np_ptr(row_ptr),
+                                   _np_ptr(m), _np_ptr(xyz))
+        _check(rc, "todhip_match_l2")
+        n = int(row_ptr[nq])
+        return row_ptr, m[:n].copy(), xyz[:n].copy()
+
+    def match_l2_device(self, d_q, nq, k, radius, d_counts, d_matches, d_xyz):
+        rc = lib().todhip_match_l2_device(self._h, C.c_void_p(d_q), C.c_uint32(nq), C.c_uint32(k), C.c_float(radius),
+                                          C.c_void_p(d_counts), C.c_void_p(d_matches), C.c_void_p(d_xyz))
+        _check(rc, "todhip_match_l2_device")
 
     def match_device(self, d_q, nq, k, radius, d_counts, d_matches, d_xyz):
         """Device-pointer form (ints from tensor.data_ptr())."""

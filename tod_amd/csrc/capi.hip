@@ -50,6 +50,7 @@ void todhip_destroy(todhip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   tod_verify_ws_free(ctx);
   tod_orb_ws_free(ctx);
+  tod_l2_ws_free(ctx);
   ctx->db_desc.release(); ctx->db_pts.release(); ctx->db_obj_off.release();
   ctx->m_q.release(); ctx->m_part.release(); ctx->m_keys.release(); ctx->m_counts.release();
   ctx->m_matches.release(); ctx->m_xyz.release(); ctx->m_bound.release(); ctx->h_stage.release();
@@ -103,7 +104,8 @@ static void shard_bounds(const std::vector<uint32_t>& off, uint32_t n_objs, uint
 int todhip_db_load(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, uint32_t desc_bytes,
                    uint32_t shard_rank, uint32_t shard_count, float* spans_out) {
   if (!ctx || (!objs && n_objs) || shard_count == 0 || shard_rank >= shard_count) return TODHIP_EINVAL;
-  if (desc_bytes != 32) return TODHIP_EINVAL;   // 256-bit binary descriptors (ORB) in this round
+  // 32: 256-bit binary descriptors (ORB), Hamming; 512: 128 x f32 (SIFT-like), L2 -- one device only
+  if (desc_bytes != 32 && !(desc_bytes == 512 && shard_count == 1)) return TODHIP_EINVAL;
   TOD_HIP(hipSetDevice(ctx->device));
   ctx->h_obj_off.assign(n_objs + 1, 0u);
   uint64_t total = 0;
@@ -156,6 +158,10 @@ int todhip_db_load(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, 
                              (size_t)objs[o].n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   TOD_HIP(hipMemcpyAsync(ctx->db_obj_off.p, ctx->h_obj_off.data(), (size_t)(n_objs + 1) * sizeof(uint32_t),
                          hipMemcpyHostToDevice, ctx->stream));
+  if (desc_bytes == 512) {
+    int rc = tod_l2_db_prepare(ctx);
+    if (rc != TODHIP_OK) return rc;
+  }
   TOD_HIP(hipStreamSynchronize(ctx->stream));
   return TODHIP_OK;
 }

@@ -95,6 +95,7 @@ struct todhip_ctx {
   // ---- verifier / ORB workspaces live in their own translation units
   void* verify_ws = nullptr;
   void* orb_ws = nullptr;
+  void* l2_ws = nullptr;
 };
 
 // match.hip
@@ -109,6 +110,8 @@ int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_s
                        uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz);
 // verify.hip / orb.hip
 void tod_verify_ws_free(todhip_ctx* ctx);
+void tod_l2_ws_free(todhip_ctx* ctx);
+int tod_l2_db_prepare(todhip_ctx* ctx);      // l2.hip: bf16 image + norms of a 128 x f32 DB resident in db_desc
 void tod_orb_ws_free(todhip_ctx* ctx);
 int tod_orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, uint32_t H, uint32_t W, uint32_t stride,
                    uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, float* d_kp_xy,

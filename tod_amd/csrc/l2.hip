@@ -1,0 +1,518 @@
+// Float-descriptor matcher on gfx950 (BASELINE.json configs[3]: "SIFT-128 float descriptors, L2 brute force as an
+// MFMA bf16 GEMM"). Not a reference feature: DescriptorMatcher serves binary descriptors through FLANN-LSH only and
+// throws for other index types (src/detection/DescriptorMatcher.cpp:154-188). What is kept from the reference is the
+// result shape of DescriptorMatcher::process (:195-252): k nearest rows per query over the concatenated DB, truncated
+// at the first distance > radius (:212-220), (imgIdx, trainIdx) by object prefix sums, the 3D point of each match.
+//
+// Exact result from an approximate GEMM -- filter and refine:
+//   score(q, r) = |r|^2 - 2 <q^, r^>          q^, r^ = bf16 roundings, product on the matrix cores (f32 accumulate)
+//   |score + |q|^2 - d2(q, r)| <= eps(q)      eps(q) = 2^-7 (1 + 2^-6) |q| Rmax + 2^-14 (|q| + Rmax)^2, Rmax = max |r|
+//   (bf16 rounding moves each vector by <= 2^-9 of its norm, Cauchy-Schwarz on the two error terms, the f32
+//   accumulation of 128 products and of the norms is below 2^-16 of |q||r|; the second term covers the rounding
+//   of the sequential f32 sum that DEFINES d2, see include/todhip.h).
+//   pass 0  seed(q) = k-th smallest score over the first rows only   (an upper bound of A_k: a subset's k-th smallest)
+//   pass 1  A_k(q) = k-th smallest score over the DB                (GEMM + per-lane top-8 in registers; only scores
+//                                                                    below the seed are ever inserted)
+//   pass 2  candidates = { r : score <= A_k + 2 eps }                (same GEMM, atomic append, <= kCandCap per query)
+//           every row of the true top-k is a candidate: its d2 <= T_k <= A_k + |q|^2 + eps
+//   pass 3  exact d2 of the candidates in the defining order (sequential f32, no fma), k smallest by (d2, row);
+//           a query whose candidate list overflowed is redone by an exact scan of the whole DB
+// L2G  l2_gemm_kernel<PASS>    block = 4 waves x 4 query tiles of 32 = 512 queries; DB tiles of 32 rows x 128 bf16
+//                              (8 KB) stream through a double-buffered LDS image; per 32 DB rows and query tile 8
+//                              v_mfma_f32_32x32x16_bf16 with the row norms as the C operand and the queries
+//                              pre-scaled by -2 (exact in bf16), so the accumulator IS the score
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ctx.h"
+
+namespace {
+
+constexpr uint32_t kDim = 128;
+constexpr uint32_t kSubRows = 32;                         // rows of one MFMA A tile
+constexpr uint32_t kSub = 1;                              // A tiles per staged DB tile (one barrier per kSub x 16 MFMAs per wave)
+constexpr uint32_t kTileRows = kSubRows * kSub;           // DB rows per LDS buffer (x 128 bf16 = 8 KB each 32 rows)
+constexpr uint32_t kLdsRowBytes = 272;                    // 256 B of bf16 + 16 B pad: ds_read_b128 of a column is 2-way
+constexpr uint32_t kQTilesPerWave = 4;
+constexpr uint32_t kWaves = 4;
+constexpr uint32_t kBlockQueries = kWaves * kQTilesPerWave * 32u;   // 256
+constexpr uint32_t kTop = 8;                              // per-lane list length of pass 1 (k <= 8)
+constexpr uint32_t kCandCap = 256;                        // candidates per query before the exact-scan fallback
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 = 4 VGPRs: one MFMA A/B fragment
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct L2Ws {
+  DevBuf db_bf16, db_norm, q_bf16, q_eps, part, thr, cand, cand_cnt, keys, scal;
+  uint32_t n_pad = 0;
+};
+
+L2Ws* l2ws_of(todhip_ctx* ctx) {
+  if (!ctx->l2_ws) ctx->l2_ws = new L2Ws();
+  return reinterpret_cast<L2Ws*>(ctx->l2_ws);
+}
+
+__device__ __forceinline__ uint16_t bf16_rne(float x) {
+  const uint32_t b = __float_as_uint(x);
+  return (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);
+}
+
+// one wave per row: bf16 image (scaled by `scale`, a power of two) and |row|^2; rows >= n are padding
+__global__ __launch_bounds__(256) void l2_prepare_kernel(const float* __restrict__ src, uint32_t n, uint32_t n_pad, float scale,
+                                                         uint16_t* __restrict__ dst, float* __restrict__ norm2,
+                                                         uint32_t* __restrict__ max_norm2_bits) {
+  const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+  if (row >= n_pad) return;
+  float a = 0.f, b = 0.f;
+  if (row < n) { a = src[(size_t)row * kDim + 2u * l]; b = src[(size_t)row * kDim + 2u * l + 1u]; }
+  reinterpret_cast<uint32_t*>(dst)[(size_t)row * (kDim / 2u) + l] =
+      (uint32_t)bf16_rne(a * scale) | ((uint32_t)bf16_rne(b * scale) << 16);
+  float s = a * a + b * b;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (l == 0) {
+    norm2[row] = row < n ? s : 3.0e38f;                     // a padding row can never be a candidate
+    if (row < n && max_norm2_bits) atomicMax(max_norm2_bits, __float_as_uint(s));
+  }
+}
+
+// eps(q) from |q|^2 (norm2 of the query image) and Rmax^2
+__global__ __launch_bounds__(256) void l2_eps_kernel(const float* __restrict__ qnorm2, uint32_t nq_pad,
+                                                     const uint32_t* __restrict__ max_norm2_bits, float* __restrict__ eps) {
+  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+  if (q >= nq_pad) return;
+  const float nq = sqrtf(qnorm2[q]), rmax = sqrtf(__uint_as_float(*max_norm2_bits));
+  eps[q] = 0.0079345703125f * nq * rmax + 6.103515625e-05f * (nq + rmax) * (nq + rmax);   // 2^-7 (1 + 2^-6), 2^-14
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restrict__ db, const float* __restrict__ dbn,
+                                                         uint32_t n_tiles, uint32_t tiles_per_chunk,
+                                                         const uint16_t* __restrict__ qh, uint32_t nq_pad,
+                                                         float* __restrict__ part, const float* __restrict__ thr,
+                                                         uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
+  // thr: PASS 1 -- optional per-query seed (only scores below it can matter), PASS 2 -- the candidate threshold
+  __shared__ __align__(16) unsigned char s_tile[2][kTileRows * kLdsRowBytes];
+  __shared__ __align__(16) float s_norm[2][kTileRows];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, l = tid & 63u, r = l & 31u, h = l >> 5;
+  const uint32_t chunk = blockIdx.x;
+  const uint32_t q_base = blockIdx.y * kBlockQueries + wave * (kQTilesPerWave * 32u);
+  const uint32_t t_begin = chunk * tiles_per_chunk, t_end = min(n_tiles, t_begin + tiles_per_chunk);
+  if (t_begin >= t_end) return;
+
+  // this wave's query fragments: B[k = 16 s + 8 h + j][col r] = q^[q_base + 32 t + r][16 s + 8 h + j]
+  bf16x8 bq[kQTilesPerWave][8];
+#pragma unroll
+  for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
+    const uint16_t* qp = qh + (size_t)(q_base + 32u * t + r) * kDim + 8u * h;
+#pragma unroll
+    for (uint32_t s = 0; s < 8; ++s) bq[t][s] = *reinterpret_cast<const bf16x8*>(qp + 16u * s);
+  }
+  float best[kQTilesPerWave][kTop];
+  float limit[kQTilesPerWave];
+#pragma unroll
+  for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
+#pragma unroll
+    for (uint32_t j = 0; j < kTop; ++j) best[t][j] = FLT_MAX;
+    limit[t] = (PASS == 1 && !thr) ? FLT_MAX : thr[q_base + 32u * t + r];
+  }
+
+  // global -> LDS staging: thread moves 16-byte chunks tid + 256 i of the 1024 of a tile (coalesced)
+  static_assert(kSub == 1 || kSub == 2, "two or four 16-byte chunks per thread");
+  uint4 g0, g1, g2, g3;
+  float gn = 0.f;
+#define L2_FETCH(tile_)                                                                                   \
+  {                                                                                                       \
+    const uint4* src_ = reinterpret_cast<const uint4*>(db + (size_t)(tile_) * kTileRows * kDim);          \
+    g0 = src_[tid]; g1 = src_[tid + 256u];                                                                \
+    if (kSub == 2) { g2 = src_[tid + 512u]; g3 = src_[tid + 768u]; }                                      \
+    if (tid < kTileRows) gn = dbn[(size_t)(tile_) * kTileRows + tid];                                     \
+  }
+#define L2_LDS_AT(buf_, c_) (&s_tile[buf_][((c_) >> 4) * kLdsRowBytes + ((c_) & 15u) * 16u])
+#define L2_STASH(buf_)                                                                                    \
+  {                                                                                                       \
+    *reinterpret_cast<uint4*>(L2_LDS_AT(buf_, tid)) = g0;                                                 \
+    *reinterpret_cast<uint4*>(L2_LDS_AT(buf_, tid + 256u)) = g1;                                          \
+    if (kSub == 2) {                                                                                      \
+      *reinterpret_cast<uint4*>(L2_LDS_AT(buf_, tid + 512u)) = g2;                                        \
+      *reinterpret_cast<uint4*>(L2_LDS_AT(buf_, tid + 768u)) = g3;                                        \
+    }                                                                                                     \
+    if (tid < kTileRows) s_norm[buf_][tid] = gn;                                                          \
+  }
+  L2_FETCH(t_begin);
+  L2_STASH(0u);
+  __syncthreads();
+  for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+    const uint32_t buf = (tile - t_begin) & 1u;
+    if (tile + 1 < t_end) L2_FETCH(tile + 1);
+#pragma unroll
+    for (uint32_t sub = 0; sub < kSub; ++sub) {
+    // A[row r][k = 16 s + 8 h + j]: 16 bytes at byte 32 s + 16 h of LDS row r
+    bf16x8 a[8];
+#pragma unroll
+    for (uint32_t s = 0; s < 8; ++s)
+      a[s] = *reinterpret_cast<const bf16x8*>(&s_tile[buf][(sub * kSubRows + r) * kLdsRowBytes + 32u * s + 16u * h]);
+    // C operand = |row|^2 of the rows this lane's accumulators belong to: reg 4 g + i <-> row 8 g + 4 h + i
+    f32x16 cn;
+#pragma unroll
+    for (uint32_t gg = 0; gg < 4; ++gg) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&s_norm[buf][sub * kSubRows + 8u * gg + 4u * h]);
+      cn[4 * gg + 0] = v[0]; cn[4 * gg + 1] = v[1]; cn[4 * gg + 2] = v[2]; cn[4 * gg + 3] = v[3];
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
+      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[t][0], cn, 0, 0, 0);
+#pragma unroll
+      for (uint32_t s = 1; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[t][s], acc, 0, 0, 0);
+      float m = acc[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) m = fminf(m, acc[i]);
+      if (PASS == 1) {
+        if (__builtin_amdgcn_ballot_w64(m < limit[t]) != 0ull) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (__builtin_amdgcn_ballot_w64(acc[i] < limit[t]) != 0ull) {   // wave-uniform: usually one value of the 16
+              float v = acc[i] < limit[t] ? acc[i] : FLT_MAX;               // FLT_MAX falls through the list unchanged
+#pragma unroll
+              for (uint32_t j = 0; j < kTop; ++j) { const float lo = fminf(best[t][j], v); v = fmaxf(best[t][j], v); best[t][j] = lo; }
+            }
+          }
+          limit[t] = fminf(limit[t], best[t][kTop - 1]);
+        }
+      } else {
+        if (__builtin_amdgcn_ballot_w64(m <= limit[t]) != 0ull) {
+          const uint32_t q = q_base + 32u * t + r;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if (acc[i] <= limit[t]) {
+              const uint32_t row = tile * kTileRows + sub * kSubRows + (uint32_t)(i & 3) + 8u * (uint32_t)(i >> 2) + 4u * h;
+              const uint32_t at = atomicAdd(&cand_cnt[q], 1u);
+              if (at < kCandCap) cand[(size_t)q * kCandCap + at] = row;
+            }
+          }
+        }
+      }
+    }
+    }
+    if (tile + 1 < t_end) L2_STASH(buf ^ 1u);
+    __syncthreads();
+  }
+#undef L2_FETCH
+#undef L2_STASH
+#undef L2_LDS_AT
+  if (PASS == 1) {
+    // partition (chunk, lane half): kTop ascending scores per query
+#pragma unroll
+    for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
+      float* dst = part + ((size_t)(chunk * 2u + h) * nq_pad + (q_base + 32u * t + r)) * kTop;
+#pragma unroll
+      for (uint32_t j = 0; j < kTop; ++j) dst[j] = best[t][j];
+    }
+  }
+}
+
+// per query (one wave): k-th smallest score over the partitions' lists; scores at or above the seed were never
+// recorded, so fewer than k entries mean A_k == seed. out = A_k + margin * eps
+__global__ __launch_bounds__(256) void l2_threshold_kernel(const float* __restrict__ part, uint32_t n_parts, uint32_t nq,
+                                                           uint32_t nq_pad, uint32_t k, const float* __restrict__ seed,
+                                                           const float* __restrict__ eps, float margin, float* __restrict__ out) {
+  const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+  if (q >= nq_pad) return;
+  if (q >= nq) { if (l == 0) out[q] = -FLT_MAX; return; }   // padding queries collect nothing
+  float best[kTop];
+#pragma unroll
+  for (uint32_t j = 0; j < kTop; ++j) best[j] = FLT_MAX;
+  for (uint32_t p = l; p < n_parts; p += 64u) {
+    const float* src = part + ((size_t)p * nq_pad + q) * kTop;
+    for (uint32_t i = 0; i < kTop; ++i) {
+      float v = src[i];
+      if (v >= best[kTop - 1]) break;                       // lists are ascending
+#pragma unroll
+      for (uint32_t j = 0; j < kTop; ++j) { const float lo = fminf(best[j], v); v = fmaxf(best[j], v); best[j] = lo; }
+    }
+  }
+  // k rounds of wave-min over the lanes' heads (values may repeat: pop one lane per round)
+  float ak = FLT_MAX;
+  for (uint32_t j = 0; j < k; ++j) {
+    float v = best[0];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    ak = v;
+    const unsigned long long owners = __builtin_amdgcn_ballot_w64(best[0] == v);
+    if (v != FLT_MAX && l == (uint32_t)__ffsll((long long)owners) - 1u) {
+#pragma unroll
+      for (uint32_t i = 0; i + 1 < kTop; ++i) best[i] = best[i + 1];
+      best[kTop - 1] = FLT_MAX;
+    }
+  }
+  if (seed) ak = fminf(ak, seed[q]);
+  if (l == 0) out[q] = ak + margin * eps[q];
+}
+
+// the defining distance (include/todhip.h): sequential f32, no fused multiply-add (-ffp-contract=off)
+__device__ __forceinline__ float d2_exact(const float* __restrict__ q, const float* __restrict__ r) {
+  float acc = 0.f;
+  for (uint32_t i = 0; i < kDim; i += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(q + i), b = *reinterpret_cast<const float4*>(r + i);
+    float t = a.x - b.x; acc = acc + t * t;
+    t = a.y - b.y; acc = acc + t * t;
+    t = a.z - b.z; acc = acc + t * t;
+    t = a.w - b.w; acc = acc + t * t;
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void keys_insert(uint64_t (&best)[kTop], uint64_t key) {
+#pragma unroll
+  for (uint32_t j = 0; j < kTop; ++j) { const uint64_t lo = key < best[j] ? key : best[j]; key = key < best[j] ? best[j] : key; best[j] = lo; }
+}
+
+// the k smallest keys of the wave's lanes' ascending lists -> out[0..k) (lane 0 writes)
+__device__ __forceinline__ void wave_select(uint64_t (&best)[kTop], uint32_t k, uint64_t* out) {
+  const uint32_t l = threadIdx.x & 63u;
+  for (uint32_t j = 0; j < k; ++j) {
+    uint64_t v = best[0];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(v >> 32), off) << 32) | __shfl_xor((uint32_t)v, off);
+      v = o < v ? o : v;
+    }
+    if (l == 0) out[j] = v;
+    if (best[0] == v && v != ~0ull) {                        // keys are unique: exactly one lane pops
+#pragma unroll
+      for (uint32_t i = 0; i + 1 < kTop; ++i) best[i] = best[i + 1];
+      best[kTop - 1] = ~0ull;
+    }
+  }
+}
+
+// pass 3: one wave per query. keys[q][k] = (f32 bits of d2) << 32 | row, ascending, ~0 padded
+__global__ __launch_bounds__(256) void l2_rerank_kernel(const float* __restrict__ q, uint32_t nq, const float* __restrict__ db,
+                                                        const uint32_t* __restrict__ cand, const uint32_t* __restrict__ cand_cnt,
+                                                        uint32_t k, uint64_t* __restrict__ keys, uint32_t* __restrict__ overflow) {
+  const uint32_t qi = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
+  if (qi >= nq) return;
+  const uint32_t cnt = cand_cnt[qi];
+  if (cnt > kCandCap) { if (l == 0) overflow[qi] = 1u; return; }   // redone by l2_exact_scan_kernel
+  if (l == 0) overflow[qi] = 0u;
+  uint64_t best[kTop];
+#pragma unroll
+  for (uint32_t j = 0; j < kTop; ++j) best[j] = ~0ull;
+  for (uint32_t c = l; c < cnt; c += 64u) {
+    const uint32_t row = cand[(size_t)qi * kCandCap + c];
+    const float d2 = d2_exact(q + (size_t)qi * kDim, db + (size_t)row * kDim);
+    keys_insert(best, ((uint64_t)__float_as_uint(d2) << 32) | row);
+  }
+  wave_select(best, k, keys + (size_t)qi * k);
+}
+
+// fallback for queries whose candidate list overflowed (and the test hook's exact GPU reference): one block per
+// query scans every DB row with the defining distance
+__global__ __launch_bounds__(256) void l2_exact_scan_kernel(const float* __restrict__ q, uint32_t nq, const float* __restrict__ db,
+                                                            uint32_t n, uint32_t k, const uint32_t* __restrict__ only_flagged,
+                                                            uint64_t* __restrict__ keys) {
+  __shared__ uint64_t s_keys[4][kTop];
+  const uint32_t qi = blockIdx.x, tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
+  if (qi >= nq || (only_flagged && only_flagged[qi] == 0u)) return;
+  uint64_t best[kTop];
+#pragma unroll
+  for (uint32_t j = 0; j < kTop; ++j) best[j] = ~0ull;
+  for (uint32_t row = tid; row < n; row += 256u) {
+    const float d2 = d2_exact(q + (size_t)qi * kDim, db + (size_t)row * kDim);
+    keys_insert(best, ((uint64_t)__float_as_uint(d2) << 32) | row);
+  }
+  wave_select(best, kTop, s_keys[w]);
+  __syncthreads();
+  if (w == 0) {
+#pragma unroll
+    for (uint32_t j = 0; j < kTop; ++j) best[j] = ~0ull;
+    if (l < 4u * kTop) keys_insert(best, s_keys[l / kTop][l % kTop]);
+    wave_select(best, k, keys + (size_t)qi * k);
+  }
+}
+
+// radius cut (DescriptorMatcher.cpp:212-220 shape), object lookup (:60-129 load order), 3D gather (:231-244)
+__global__ __launch_bounds__(256) void l2_finalize_kernel(const uint64_t* __restrict__ keys, uint32_t nq, uint32_t k, float radius,
+                                                          const uint32_t* __restrict__ obj_off, uint32_t n_objs,
+                                                          const float* __restrict__ pts, uint32_t* __restrict__ counts,
+                                                          todhip_dmatch* __restrict__ matches, float* __restrict__ xyz) {
+  const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
+  if (qi >= nq) return;
+  uint32_t kept = 0;
+  for (uint32_t j = 0; j < k; ++j) {
+    const uint64_t key = keys[(size_t)qi * k + j];
+    if (key == ~0ull) break;
+    const float dist = sqrtf(__uint_as_float((uint32_t)(key >> 32)));
+    if (dist > radius) break;
+    const uint32_t row = (uint32_t)key;
+    uint32_t lo = 0, hi = n_objs;                           // last object whose first row is <= row
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (obj_off[mid] <= row) lo = mid; else hi = mid; }
+    todhip_dmatch m;
+    m.queryIdx = (int)qi; m.trainIdx = (int)(row - obj_off[lo]); m.imgIdx = (int)lo; m.distance = dist;
+    matches[(size_t)qi * k + kept] = m;
+    float* o = xyz + ((size_t)qi * k + kept) * 3;
+    o[0] = pts[(size_t)row * 3 + 0]; o[1] = pts[(size_t)row * 3 + 1]; o[2] = pts[(size_t)row * 3 + 2];
+    ++kept;
+  }
+  counts[qi] = kept;
+}
+
+}  // namespace
+
+void tod_l2_ws_free(todhip_ctx* ctx) {
+  if (!ctx->l2_ws) return;
+  L2Ws* ws = reinterpret_cast<L2Ws*>(ctx->l2_ws);
+  DevBuf* bufs[] = {&ws->db_bf16, &ws->db_norm, &ws->q_bf16, &ws->q_eps, &ws->part, &ws->thr, &ws->cand, &ws->cand_cnt, &ws->keys,
+                    &ws->scal};
+  for (DevBuf* b : bufs) b->release();
+  delete ws;
+  ctx->l2_ws = nullptr;
+}
+
+// called by todhip_db_load for 128 x f32 rows (already resident in ctx->db_desc): bf16 image, norms, Rmax
+int tod_l2_db_prepare(todhip_ctx* ctx) {
+  L2Ws* ws = l2ws_of(ctx);
+  const uint32_t n = (uint32_t)ctx->shard_rows;
+  ws->n_pad = ((n + kTileRows - 1u) / kTileRows) * kTileRows;
+  TOD_HIP(ws->db_bf16.reserve((size_t)std::max(ws->n_pad, kTileRows) * kDim * 2));
+  TOD_HIP(ws->db_norm.reserve((size_t)std::max(ws->n_pad, kTileRows) * 4));
+  TOD_HIP(ws->scal.reserve(64));
+  TOD_HIP(hipMemsetAsync(ws->scal.p, 0, 64, ctx->stream));
+  if (ws->n_pad)
+    hipLaunchKernelGGL(l2_prepare_kernel, dim3((ws->n_pad + 3u) / 4u), dim3(256), 0, ctx->stream, ctx->db_desc.as<float>(), n,
+                       ws->n_pad, 1.0f, ws->db_bf16.as<uint16_t>(), ws->db_norm.as<float>(), ws->scal.as<uint32_t>());
+  TOD_HIP(hipGetLastError());
+  return TODHIP_OK;
+}
+
+static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, int exact_only) {
+  L2Ws* ws = l2ws_of(ctx);
+  hipStream_t st = ctx->stream;
+  const uint32_t n = (uint32_t)ctx->shard_rows;
+  TOD_HIP(ws->keys.reserve((size_t)nq * k * 8));
+  TOD_HIP(ws->cand_cnt.reserve(((size_t)nq + kBlockQueries) * 4 * 2));
+  uint32_t* overflow = ws->cand_cnt.as<uint32_t>() + nq + kBlockQueries;
+  if (exact_only) {
+    hipLaunchKernelGGL(l2_exact_scan_kernel, dim3(nq), dim3(256), 0, st, d_q, nq, ctx->db_desc.as<float>(), n, k,
+                       (const uint32_t*)nullptr, ws->keys.as<uint64_t>());
+    TOD_HIP(hipGetLastError());
+    return TODHIP_OK;
+  }
+  const uint32_t nq_pad = ((nq + kBlockQueries - 1u) / kBlockQueries) * kBlockQueries;
+  const uint32_t q_blocks = nq_pad / kBlockQueries;
+  const uint32_t n_tiles = ws->n_pad / kTileRows;
+  // 2 blocks per CU in flight; the DB is cut into as many chunks as that allows for this many query blocks
+  uint32_t n_chunks = std::max(1u, (2u * (uint32_t)ctx->n_cu) / q_blocks);
+  n_chunks = std::min(n_chunks, std::max(1u, n_tiles));
+  const uint32_t tiles_per_chunk = (n_tiles + n_chunks - 1u) / n_chunks;
+  n_chunks = (n_tiles + tiles_per_chunk - 1u) / tiles_per_chunk;
+  const uint32_t n_parts = 2u * n_chunks;
+  TOD_HIP(ws->q_bf16.reserve((size_t)nq_pad * kDim * 2));
+  TOD_HIP(ws->q_eps.reserve((size_t)nq_pad * 4 * 2));
+  TOD_HIP(ws->part.reserve((size_t)n_parts * nq_pad * kTop * 4));
+  TOD_HIP(ws->thr.reserve((size_t)nq_pad * 4 * 2));
+  TOD_HIP(ws->cand.reserve((size_t)nq_pad * kCandCap * 4));
+  float* qnorm = ws->q_eps.as<float>() + nq_pad;
+  // queries: bf16 image pre-scaled by -2 (a power of two: no extra rounding), |q|^2, eps
+  hipLaunchKernelGGL(l2_prepare_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, d_q, nq, nq_pad, -2.0f,
+                     ws->q_bf16.as<uint16_t>(), qnorm, (uint32_t*)nullptr);
+  hipLaunchKernelGGL(l2_eps_kernel, dim3((nq_pad + 255u) / 256u), dim3(256), 0, st, qnorm, nq_pad, ws->scal.as<uint32_t>(),
+                     ws->q_eps.as<float>());
+  TOD_HIP(hipMemsetAsync(ws->cand_cnt.p, 0, (size_t)nq_pad * 4, st));
+  const uint32_t k_eff = std::min(k, std::max(1u, n));
+  // pass 0: the k-th smallest score over a sample (the first rows) bounds A_k from above; with it as the initial
+  // limit of pass 1 only ~k N / n_sample scores per query ever reach the insertion path
+  const float* seed = nullptr;
+  const uint32_t sample_tiles = std::min(n_tiles, 256u);
+  if (n_tiles >= 8u * sample_tiles && sample_tiles * kTileRows >= k_eff) {
+    const uint32_t s_chunks = std::min(sample_tiles, 32u), s_tpc = (sample_tiles + s_chunks - 1u) / s_chunks;
+    float* d_seed = ws->thr.as<float>() + nq_pad;
+    hipLaunchKernelGGL(l2_gemm_kernel<1>, dim3(s_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
+                       ws->db_norm.as<float>(), sample_tiles, s_tpc, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
+                       (const float*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), 2u * s_chunks, nq_pad,
+                       nq_pad, k_eff, (const float*)nullptr, ws->q_eps.as<float>(), 0.f, d_seed);
+    seed = d_seed;
+  }
+  int slot = -1;
+  if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
+  hipLaunchKernelGGL(l2_gemm_kernel<1>, dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
+                     ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
+                     seed, (uint32_t*)nullptr, (uint32_t*)nullptr);
+  if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
+  hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), n_parts, nq, nq_pad,
+                     k_eff, seed, ws->q_eps.as<float>(), 2.f, ws->thr.as<float>());
+  hipLaunchKernelGGL(l2_gemm_kernel<2>, dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
+                     ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, ws->q_bf16.as<uint16_t>(), nq_pad, (float*)nullptr,
+                     ws->thr.as<float>(), ws->cand.as<uint32_t>(), ws->cand_cnt.as<uint32_t>());
+  hipLaunchKernelGGL(l2_rerank_kernel, dim3((nq + 3u) / 4u), dim3(256), 0, st, d_q, nq, ctx->db_desc.as<float>(),
+                     ws->cand.as<uint32_t>(), ws->cand_cnt.as<uint32_t>(), k, ws->keys.as<uint64_t>(), overflow);
+  hipLaunchKernelGGL(l2_exact_scan_kernel, dim3(nq), dim3(256), 0, st, d_q, nq, ctx->db_desc.as<float>(), n, k,
+                     (const uint32_t*)overflow, ws->keys.as<uint64_t>());
+  TOD_HIP(hipGetLastError());
+  return TODHIP_OK;
+}
+
+extern "C" {
+
+int todhip_match_l2_device(todhip_ctx* ctx, const void* d_q_desc, uint32_t nq, uint32_t k, float radius, void* d_counts,
+                           void* d_matches, void* d_matches_xyz) {
+  if (!ctx || !d_q_desc || !d_counts || !d_matches || !d_matches_xyz) return TODHIP_EINVAL;
+  if (k == 0 || k > kTop || !(radius > 0.f)) return TODHIP_EINVAL;
+  if (ctx->total_rows == 0) return TODHIP_ENODB;
+  if (ctx->desc_bytes != kDim * 4u || ctx->shard_rows != ctx->total_rows) return TODHIP_EINVAL;   // needs a 128 x f32 DB
+  if (nq == 0) return TODHIP_OK;
+  TOD_HIP(hipSetDevice(ctx->device));
+  static const bool exact_only = getenv("TODHIP_L2_EXACT_SCAN") != nullptr;      // diagnostics: skip the GEMM filter
+  int rc = l2_keys(ctx, reinterpret_cast<const float*>(d_q_desc), nq, k, exact_only ? 1 : 0);
+  if (rc != TODHIP_OK) return rc;
+  L2Ws* ws = l2ws_of(ctx);
+  hipLaunchKernelGGL(l2_finalize_kernel, dim3((nq + 255u) / 256u), dim3(256), 0, ctx->stream, ws->keys.as<uint64_t>(), nq, k, radius,
+                     ctx->db_obj_off.as<uint32_t>(), ctx->n_objs, ctx->db_pts.as<float>(), reinterpret_cast<uint32_t*>(d_counts),
+                     reinterpret_cast<todhip_dmatch*>(d_matches), reinterpret_cast<float*>(d_matches_xyz));
+  TOD_HIP(hipGetLastError());
+  ctx->counters.last_nq = nq; ctx->counters.last_k = k;
+  return TODHIP_OK;
+}
+
+int todhip_match_l2(todhip_ctx* ctx, const float* q_desc, uint32_t nq, uint32_t k, float radius, uint32_t* row_ptr,
+                    todhip_dmatch* matches, float* matches_xyz) {
+  if (!ctx || (!q_desc && nq) || !row_ptr || (nq && (!matches || !matches_xyz))) return TODHIP_EINVAL;
+  if (k == 0 || k > kTop || !(radius > 0.f)) return TODHIP_EINVAL;
+  if (ctx->total_rows == 0) return TODHIP_ENODB;
+  row_ptr[0] = 0;
+  if (nq == 0) return TODHIP_OK;
+  TOD_HIP(hipSetDevice(ctx->device));
+  const size_t cap = (size_t)nq * k;
+  TOD_HIP(ctx->m_q.reserve((size_t)nq * kDim * 4));
+  TOD_HIP(ctx->m_counts.reserve((size_t)nq * 4));
+  TOD_HIP(ctx->m_matches.reserve(cap * sizeof(todhip_dmatch)));
+  TOD_HIP(ctx->m_xyz.reserve(cap * 12));
+  TOD_HIP(hipMemcpyAsync(ctx->m_q.p, q_desc, (size_t)nq * kDim * 4, hipMemcpyHostToDevice, ctx->stream));
+  int rc = todhip_match_l2_device(ctx, ctx->m_q.p, nq, k, radius, ctx->m_counts.p, ctx->m_matches.p, ctx->m_xyz.p);
+  if (rc != TODHIP_OK) return rc;
+  std::vector<uint32_t> counts(nq);
+  std::vector<todhip_dmatch> m(cap);
+  std::vector<float> x(cap * 3);
+  TOD_HIP(hipMemcpyAsync(counts.data(), ctx->m_counts.p, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TOD_HIP(hipMemcpyAsync(m.data(), ctx->m_matches.p, cap * sizeof(todhip_dmatch), hipMemcpyDeviceToHost, ctx->stream));
+  TOD_HIP(hipMemcpyAsync(x.data(), ctx->m_xyz.p, cap * 12, hipMemcpyDeviceToHost, ctx->stream));
+  TOD_HIP(hipStreamSynchronize(ctx->stream));
+  uint32_t out = 0;
+  for (uint32_t qi = 0; qi < nq; ++qi) {                    // fixed-stride slots -> CSR
+    for (uint32_t j = 0; j < counts[qi]; ++j) {
+      matches[out] = m[(size_t)qi * k + j];
+      std::memcpy(matches_xyz + 3 * (size_t)out, &x[((size_t)qi * k + j) * 3], 12);
+      ++out;
+    }
+    row_ptr[qi + 1] = out;
+  }
+  return TODHIP_OK;
+}
+
+}  // extern "C"

@@ -142,3 +142,35 @@ def make_verify_scene(n_kp, n_objects=6, per_object=400, visible=((1, 0.30),), m
             matches[m] = (i, rows[j], objs[j], float(rng.integers(0, 60)))
             mxyz[m] = model[objs[j]][rows[j]]
     return dict(kp_xy=kp_xy, cloud=cloud, row_ptr=row_ptr, matches=matches, matches_xyz=mxyz, spans=spans, poses=poses)
+
+
+# ------------------------------------------------------------------------------------------ float descriptors (C4)
+SIFT_DB_SEED = 1004
+
+
+def make_sift_db(n_objects, per_object=5000, dim=128):
+    """SIFT-like float DB of BASELINE configs[3]: f32 in [0, 255], rows L2-normalised to 512.
+    Returns (desc f32[N, dim], pts f32[N, 3], obj_off u32[n_objects + 1])."""
+    rng = np.random.Generator(np.random.PCG64(SIFT_DB_SEED))
+    n = n_objects * per_object
+    desc = rng.random((n, dim), dtype=np.float32) * np.float32(255.0)
+    desc *= (np.float32(512.0) / np.linalg.norm(desc, axis=1, keepdims=True)).astype(np.float32)
+    pts = ((rng.random((n, 3)) - 0.5) * np.array([0.20, 0.15, 0.10])).astype(np.float32)
+    off = (np.arange(n_objects + 1) * per_object).astype(np.uint32)
+    return np.ascontiguousarray(desc, np.float32), pts, off
+
+
+def make_sift_queries(desc, n_q, frame=0, on_object=0.30, noise=12.0):
+    """Queries: a fraction are DB rows plus Gaussian noise (true matches at distance ~ noise * sqrt(dim)), the rest
+    random SIFT-like vectors. Returns (q f32[n_q, dim], truth_rows i64[n_q] with -1 for clutter)."""
+    rng = np.random.Generator(np.random.PCG64(FRAME_SEED + 5000 + frame))
+    dim = desc.shape[1]
+    n_on = int(round(n_q * on_object))
+    rows = rng.choice(desc.shape[0], size=n_on, replace=False)
+    q = rng.random((n_q, dim), dtype=np.float32) * np.float32(255.0)
+    q *= (np.float32(512.0) / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    q[:n_on] = desc[rows] + rng.normal(0, noise, (n_on, dim)).astype(np.float32)
+    truth = np.full(n_q, -1, np.int64)
+    truth[:n_on] = rows
+    perm = rng.permutation(n_q)
+    return np.ascontiguousarray(q[perm], np.float32), truth[perm]
