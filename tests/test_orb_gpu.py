@@ -87,3 +87,20 @@ def test_batch_of_frames_equals_frame_by_frame(ctx):
     n2 = ctx.orb_batch_device(d[1:3].contiguous().data_ptr(), 2, 480 * 640, 480, 640, 640, 1000, 3, 1.2, kp.data_ptr(),
                               aux.data_ptr(), desc.data_ptr(), cap)
     assert n2 == [1000, 1000] and np.array_equal(desc[1].cpu().numpy(), O.orb(imgs[2], 1000, 3, 1.2)[2])
+
+
+def test_c5_shape_batch_of_1080p_frames_orb2000(ctx):
+    """BASELINE configs[4] front end on one GPU: a batch of 1920x1080 frames, ORB-2000 (3 levels, scale 1.2)."""
+    import torch
+    imgs = [synth.make_image(50 + i, H=1080, W=1920, n_rect=6000) for i in range(3)]
+    F, cap = len(imgs), 2000
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    kp = torch.zeros((F, cap, 2), device="cuda"); aux = torch.zeros((F, cap, 4), device="cuda")
+    desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device="cuda")
+    n = ctx.orb_batch_device(d.data_ptr(), F, 1080 * 1920, 1080, 1920, 1920, 2000, 3, 1.2, kp.data_ptr(), aux.data_ptr(),
+                             desc.data_ptr(), cap)
+    assert n == [2000] * F
+    for f in range(F):
+        o_kp, o_aux, o_desc, _ = O.orb(imgs[f], 2000, 3, 1.2)
+        assert np.array_equal(kp[f].cpu().numpy(), o_kp) and np.array_equal(desc[f].cpu().numpy(), o_desc)
+        assert np.array_equal(aux[f].cpu().numpy()[:, [0, 2, 3]], o_aux[:, [0, 2, 3]])

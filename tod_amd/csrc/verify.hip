@@ -607,7 +607,7 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
   uint32_t level = 1, qsz = 0, qmax = 0, top = m;
   int all_steps = 1;
   // optional phase profile (diagnostics): cycles in intersection / degree re-sort / colouring, and their counts
-  uint32_t pf_isect = 0, pf_sort = 0, pf_col = 0, pf_nsort = 0, pf_nfull = 0, pf_vfull = 0, pf_big = 0, pf_vbig = 0;
+  uint32_t pf_isect = 0, pf_sort = 0, pf_col = 0, pf_vfull = 0, pf_big = 0, pf_vbig = 0;
   uint16_t* cur = L.cur;
   uint16_t* nxt = L.nxt;
   bool reload = false;
@@ -651,7 +651,6 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
           if ((uint64_t)uni(L.S[level]) * 40ull < (uint64_t)all_steps) {
             degrees_in_list(L, nxt, rp, MW);
             rank_sort_desc(nxt, L.tmp, L.deg, rp, L.keys);
-            ++pf_nsort;
           }
           const long long pt2 = prof ? clock64() : 0;
           pf_sort += (uint32_t)(pt2 - pt1);
@@ -659,7 +658,7 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
           if (prof) {
             const uint32_t dt = (uint32_t)(clock64() - pt2);
             pf_col += dt;
-            if ((int)qmax - (int)qsz + 1 < 2) { ++pf_nfull; pf_vfull += rp; if (rp > 64u) { pf_big += dt; pf_vbig += rp; } }
+            if ((int)qmax - (int)qsz + 1 < 2) { pf_vfull += rp; if (rp > 64u) { pf_big += dt; pf_vbig += rp; } }
           }
           if (l == 0) L.S[level] += 1u;
           ++all_steps;

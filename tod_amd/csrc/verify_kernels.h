@@ -108,7 +108,6 @@ __device__ __forceinline__ void wb_set(WaveBits& b, uint32_t v) {
 // index of the idx-th set bit (ascending); idx < count and idx wave-uniform
 __device__ __forceinline__ uint32_t wb_select(const WaveBits& b, uint32_t idx) {
   idx = uni(idx);
-  const uint32_t l = lane_id();
   uint32_t result = 0xFFFFFFFFu;
 #pragma unroll
   for (int j = 0; j < kWPL; ++j) {
