@@ -18,7 +18,7 @@
 //   pass 3  exact d2 of the candidates in the defining order (sequential f32, no fma), k smallest by (d2, row);
 //           a query whose candidate list overflowed is redone by an exact scan of the whole DB
 // L2G  l2_gemm_kernel<PASS>    block = 4 waves x 4 query tiles of 32 = 512 queries; DB tiles of 32 rows x 128 bf16
-//                              (8 KB) stream through a double-buffered LDS image; per 32 DB rows and query tile 8
+//                              (8 KB) stream through a 4-slot LDS ring filled by global_load_lds 2-3 tiles ahead; per 32 DB rows and query tile 8
 //                              v_mfma_f32_32x32x16_bf16 with the row norms as the C operand and the queries
 //                              pre-scaled by -2 (exact in bf16), so the accumulator IS the score
 #include <algorithm>
@@ -33,10 +33,8 @@
 namespace {
 
 constexpr uint32_t kDim = 128;
-constexpr uint32_t kSubRows = 32;                         // rows of one MFMA A tile
-constexpr uint32_t kSub = 1;                              // A tiles per staged DB tile (one barrier per kSub x 16 MFMAs per wave)
-constexpr uint32_t kTileRows = kSubRows * kSub;           // DB rows per LDS buffer (x 128 bf16 = 8 KB each 32 rows)
-constexpr uint32_t kLdsRowBytes = 272;                    // 256 B of bf16 + 16 B pad: ds_read_b128 of a column is 2-way
+constexpr uint32_t kTileRows = 32;                        // DB rows of one MFMA A tile = one LDS ring slot (8 KB)
+constexpr uint32_t kRing = 4;                             // LDS ring slots: loads run 2-3 tiles ahead of the MFMAs
 constexpr uint32_t kQTilesPerWave = 4;
 constexpr uint32_t kWaves = 4;
 constexpr uint32_t kBlockQueries = kWaves * kQTilesPerWave * 32u;   // 256
@@ -90,15 +88,20 @@ __global__ __launch_bounds__(256) void l2_eps_kernel(const float* __restrict__ q
   eps[q] = 0.0079345703125f * nq * rmax + 6.103515625e-05f * (nq + rmax) * (nq + rmax);   // 2^-7 (1 + 2^-6), 2^-14
 }
 
-template <int PASS>
+// KT: per-lane list length of pass 1 (4 when k <= 4: 16 VGPRs less), unused in pass 2
+template <int PASS, uint32_t KT>
 __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restrict__ db, const float* __restrict__ dbn,
                                                          uint32_t n_tiles, uint32_t tiles_per_chunk,
                                                          const uint16_t* __restrict__ qh, uint32_t nq_pad,
                                                          float* __restrict__ part, const float* __restrict__ thr,
                                                          uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
   // thr: PASS 1 -- optional per-query seed (only scores below it can matter), PASS 2 -- the candidate threshold
-  __shared__ __align__(16) unsigned char s_tile[2][kTileRows * kLdsRowBytes];
-  __shared__ __align__(16) float s_norm[2][kTileRows];
+  // LDS ring of DB tiles, written by global_load_lds (no VGPR staging): a wave-load drops 64 x 16 B = 4 rows
+  // contiguously, so rows are unpadded and the 16-byte chunk c of row r is stored at chunk c ^ (r & 15) instead
+  // (the swizzle is applied to the GLOBAL address each lane fetches from): the column-wise ds_read_b128 of the
+  // A fragment then spreads over all banks (2-way, as a padded image would be)
+  __shared__ __align__(16) unsigned char s_tile[kRing][kTileRows * 256u];
+  __shared__ __align__(16) float s_norm[kRing][64];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, l = tid & 63u, r = l & 31u, h = l >> 5;
   const uint32_t chunk = blockIdx.x;
   const uint32_t q_base = blockIdx.y * kBlockQueries + wave * (kQTilesPerWave * 32u);
@@ -113,84 +116,96 @@ __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restr
 #pragma unroll
     for (uint32_t s = 0; s < 8; ++s) bq[t][s] = *reinterpret_cast<const bf16x8*>(qp + 16u * s);
   }
-  float best[kQTilesPerWave][kTop];
+  float best[kQTilesPerWave][KT];
   float limit[kQTilesPerWave];
 #pragma unroll
   for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
 #pragma unroll
-    for (uint32_t j = 0; j < kTop; ++j) best[t][j] = FLT_MAX;
+    for (uint32_t j = 0; j < KT; ++j) best[t][j] = FLT_MAX;
     limit[t] = (PASS == 1 && !thr) ? FLT_MAX : thr[q_base + 32u * t + r];
   }
 
-  // global -> LDS staging: thread moves 16-byte chunks tid + 256 i of the 1024 of a tile (coalesced)
-  static_assert(kSub == 1 || kSub == 2, "two or four 16-byte chunks per thread");
-  uint4 g0, g1, g2, g3;
-  float gn = 0.f;
-#define L2_FETCH(tile_)                                                                                   \
-  {                                                                                                       \
-    const uint4* src_ = reinterpret_cast<const uint4*>(db + (size_t)(tile_) * kTileRows * kDim);          \
-    g0 = src_[tid]; g1 = src_[tid + 256u];                                                                \
-    if (kSub == 2) { g2 = src_[tid + 512u]; g3 = src_[tid + 768u]; }                                      \
-    if (tid < kTileRows) gn = dbn[(size_t)(tile_) * kTileRows + tid];                                     \
-  }
-#define L2_LDS_AT(buf_, c_) (&s_tile[buf_][((c_) >> 4) * kLdsRowBytes + ((c_) & 15u) * 16u])
-#define L2_STASH(buf_)                                                                                    \
-  {                                                                                                       \
-    *reinterpret_cast<uint4*>(L2_LDS_AT(buf_, tid)) = g0;                                                 \
-    *reinterpret_cast<uint4*>(L2_LDS_AT(buf_, tid + 256u)) = g1;                                          \
-    if (kSub == 2) {                                                                                      \
-      *reinterpret_cast<uint4*>(L2_LDS_AT(buf_, tid + 512u)) = g2;                                        \
-      *reinterpret_cast<uint4*>(L2_LDS_AT(buf_, tid + 768u)) = g3;                                        \
-    }                                                                                                     \
-    if (tid < kTileRows) s_norm[buf_][tid] = gn;                                                          \
-  }
-  L2_FETCH(t_begin);
-  L2_STASH(0u);
-  __syncthreads();
-  for (uint32_t tile = t_begin; tile < t_end; ++tile) {
-    const uint32_t buf = (tile - t_begin) & 1u;
-    if (tile + 1 < t_end) L2_FETCH(tile + 1);
+  // wave w moves wave-loads 2w and 2w+1 of the tile's 8 (each 1 KB = rows 4j .. 4j+3) and, redundantly with the
+  // other waves (same bytes, same place), the 32 row norms: 3 loads per wave and tile, so the waits below count in 3s
+  // issued as asm: the compiler would otherwise drain vmcnt to 0 before every LDS read (it cannot know which
+  // slot a read touches), which is exactly the prefetch depth this ring exists for
+  typedef __attribute__((address_space(3))) void* lptr_t;
+#define L2_LOAD_LDS(width_, gaddr_, lds_)                                                                      \
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_" width_ " %0, off"                             \
+               :: "v"(gaddr_), "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(lptr_t)(lds_))) : "memory", "m0")
+  uint32_t src_chunk[2];                                   // this lane's 16-byte chunk inside a tile, per wave-load
 #pragma unroll
-    for (uint32_t sub = 0; sub < kSub; ++sub) {
-    // A[row r][k = 16 s + 8 h + j]: 16 bytes at byte 32 s + 16 h of LDS row r
+  for (uint32_t i = 0; i < 2; ++i) {
+    const uint32_t p = (2u * wave + i) * 64u + l, row = p >> 4, c = p & 15u;
+    src_chunk[i] = row * 16u + (c ^ (row & 15u));
+  }
+#define L2_ISSUE(tile_)                                                                                        \
+  {                                                                                                            \
+    const uint32_t slot_ = ((tile_) - t_begin) % kRing;                                                        \
+    const uint4* src_ = reinterpret_cast<const uint4*>(db + (size_t)(tile_) * kTileRows * kDim);               \
+    L2_LOAD_LDS("dwordx4", src_ + src_chunk[0], &s_tile[slot_][(2u * wave) * 1024u]);                          \
+    L2_LOAD_LDS("dwordx4", src_ + src_chunk[1], &s_tile[slot_][(2u * wave + 1u) * 1024u]);                     \
+    L2_LOAD_LDS("dword", dbn + (size_t)(tile_) * kTileRows + r, &s_norm[slot_][0]);                            \
+  }
+  // s_waitcnt vmcnt(N), nothing else: N = loads that may stay in flight (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8)
+#define L2_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
+  for (uint32_t i = 0; i < kRing - 1u; ++i)
+    if (t_begin + i < t_end) L2_ISSUE(t_begin + i);
+  for (uint32_t tile = t_begin; tile < t_end; ++tile) {
+    const uint32_t buf = (tile - t_begin) % kRing;
+    // this wave's loads of `tile` have landed once at most the loads of the later tiles in flight remain
+    if (tile + 2u < t_end) L2_WAIT_VM(6); else if (tile + 1u < t_end) L2_WAIT_VM(3); else L2_WAIT_VM(0);
+    __syncthreads();                                       // ... and everybody else's; slot (tile - 1) % kRing is free again
+    if (tile + kRing - 1u < t_end) L2_ISSUE(tile + kRing - 1u);
+    {
+    // A[row r][k = 16 s + 8 h + j] = chunk 2 s + h of row r, stored at chunk (2 s + h) ^ (r & 15)
     bf16x8 a[8];
 #pragma unroll
     for (uint32_t s = 0; s < 8; ++s)
-      a[s] = *reinterpret_cast<const bf16x8*>(&s_tile[buf][(sub * kSubRows + r) * kLdsRowBytes + 32u * s + 16u * h]);
-    // C operand = |row|^2 of the rows this lane's accumulators belong to: reg 4 g + i <-> row 8 g + 4 h + i
-    f32x16 cn;
+      a[s] = *reinterpret_cast<const bf16x8*>(&s_tile[buf][r * 256u + (((2u * s + h) ^ (r & 15u)) << 4)]);
+    // software pipeline over the wave's query tiles: the MFMAs of tile t + 1 are issued (into the other
+    // accumulator) before the epilogue of tile t, so the matrix pipe never waits for the 16-way min and the ballot
+    f32x16 acc[2];
+    auto mfma_tile = [&](uint32_t t) {
+      // C operand = |row|^2 of the rows this lane's accumulators belong to (reg 4 g + i <-> row 8 g + 4 h + i), read
+      // from LDS straight into the accumulator (no second register set for it)
+      f32x16 c;
 #pragma unroll
-    for (uint32_t gg = 0; gg < 4; ++gg) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(&s_norm[buf][sub * kSubRows + 8u * gg + 4u * h]);
-      cn[4 * gg + 0] = v[0]; cn[4 * gg + 1] = v[1]; cn[4 * gg + 2] = v[2]; cn[4 * gg + 3] = v[3];
-    }
+      for (uint32_t gg = 0; gg < 4; ++gg) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&s_norm[buf][8u * gg + 4u * h]);
+        c[4 * gg + 0] = v[0]; c[4 * gg + 1] = v[1]; c[4 * gg + 2] = v[2]; c[4 * gg + 3] = v[3];
+      }
+#pragma unroll
+      for (uint32_t s = 0; s < 8; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[t][s], c, 0, 0, 0);
+      return c;
+    };
+    acc[0] = mfma_tile(0);
 #pragma unroll
     for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
-      f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[t][0], cn, 0, 0, 0);
-#pragma unroll
-      for (uint32_t s = 1; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[t][s], acc, 0, 0, 0);
-      float m = acc[0];
-#pragma unroll
-      for (int i = 1; i < 16; ++i) m = fminf(m, acc[i]);
+      if (t + 1 < kQTilesPerWave) acc[(t + 1) & 1u] = mfma_tile(t + 1);
+      const f32x16& sc = acc[t & 1u];
+      const float m0 = fminf(fminf(sc[0], sc[1]), fminf(sc[2], sc[3])), m1 = fminf(fminf(sc[4], sc[5]), fminf(sc[6], sc[7]));
+      const float m2 = fminf(fminf(sc[8], sc[9]), fminf(sc[10], sc[11])), m3 = fminf(fminf(sc[12], sc[13]), fminf(sc[14], sc[15]));
+      const float m = fminf(fminf(m0, m1), fminf(m2, m3));
       if (PASS == 1) {
         if (__builtin_amdgcn_ballot_w64(m < limit[t]) != 0ull) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            if (__builtin_amdgcn_ballot_w64(acc[i] < limit[t]) != 0ull) {   // wave-uniform: usually one value of the 16
-              float v = acc[i] < limit[t] ? acc[i] : FLT_MAX;               // FLT_MAX falls through the list unchanged
+            if (__builtin_amdgcn_ballot_w64(sc[i] < limit[t]) != 0ull) {    // wave-uniform: usually one value of the 16
+              float v = sc[i] < limit[t] ? sc[i] : FLT_MAX;                  // FLT_MAX falls through the list unchanged
 #pragma unroll
-              for (uint32_t j = 0; j < kTop; ++j) { const float lo = fminf(best[t][j], v); v = fmaxf(best[t][j], v); best[t][j] = lo; }
+              for (uint32_t j = 0; j < KT; ++j) { const float lo = fminf(best[t][j], v); v = fmaxf(best[t][j], v); best[t][j] = lo; }
             }
           }
-          limit[t] = fminf(limit[t], best[t][kTop - 1]);
+          limit[t] = fminf(limit[t], best[t][KT - 1]);
         }
       } else {
         if (__builtin_amdgcn_ballot_w64(m <= limit[t]) != 0ull) {
           const uint32_t q = q_base + 32u * t + r;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            if (acc[i] <= limit[t]) {
-              const uint32_t row = tile * kTileRows + sub * kSubRows + (uint32_t)(i & 3) + 8u * (uint32_t)(i >> 2) + 4u * h;
+            if (sc[i] <= limit[t]) {
+              const uint32_t row = tile * kTileRows + (uint32_t)(i & 3) + 8u * (uint32_t)(i >> 2) + 4u * h;
               const uint32_t at = atomicAdd(&cand_cnt[q], 1u);
               if (at < kCandCap) cand[(size_t)q * kCandCap + at] = row;
             }
@@ -199,19 +214,17 @@ __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restr
       }
     }
     }
-    if (tile + 1 < t_end) L2_STASH(buf ^ 1u);
-    __syncthreads();
   }
-#undef L2_FETCH
-#undef L2_STASH
-#undef L2_LDS_AT
+#undef L2_ISSUE
+#undef L2_WAIT_VM
+#undef L2_LOAD_LDS
   if (PASS == 1) {
     // partition (chunk, lane half): kTop ascending scores per query
 #pragma unroll
     for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
       float* dst = part + ((size_t)(chunk * 2u + h) * nq_pad + (q_base + 32u * t + r)) * kTop;
 #pragma unroll
-      for (uint32_t j = 0; j < kTop; ++j) dst[j] = best[t][j];
+      for (uint32_t j = 0; j < kTop; ++j) dst[j] = j < KT ? best[t][j] : FLT_MAX;
     }
   }
 }
@@ -432,7 +445,7 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
   if (n_tiles >= 8u * sample_tiles && sample_tiles * kTileRows >= k_eff) {
     const uint32_t s_chunks = std::min(sample_tiles, 32u), s_tpc = (sample_tiles + s_chunks - 1u) / s_chunks;
     float* d_seed = ws->thr.as<float>() + nq_pad;
-    hipLaunchKernelGGL(l2_gemm_kernel<1>, dim3(s_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
+    hipLaunchKernelGGL((k_eff <= 4u ? l2_gemm_kernel<1, 4> : l2_gemm_kernel<1, 8>), dim3(s_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
                        ws->db_norm.as<float>(), sample_tiles, s_tpc, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
                        (const float*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), 2u * s_chunks, nq_pad,
@@ -441,13 +454,13 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
   }
   int slot = -1;
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
-  hipLaunchKernelGGL(l2_gemm_kernel<1>, dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
+  hipLaunchKernelGGL((k_eff <= 4u ? l2_gemm_kernel<1, 4> : l2_gemm_kernel<1, 8>), dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
                      ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
                      seed, (uint32_t*)nullptr, (uint32_t*)nullptr);
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), n_parts, nq, nq_pad,
                      k_eff, seed, ws->q_eps.as<float>(), 2.f, ws->thr.as<float>());
-  hipLaunchKernelGGL(l2_gemm_kernel<2>, dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
+  hipLaunchKernelGGL((l2_gemm_kernel<2, 4>), dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
                      ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, ws->q_bf16.as<uint16_t>(), nq_pad, (float*)nullptr,
                      ws->thr.as<float>(), ws->cand.as<uint32_t>(), ws->cand_cnt.as<uint32_t>());
   hipLaunchKernelGGL(l2_rerank_kernel, dim3((nq + 3u) / 4u), dim3(256), 0, st, d_q, nq, ctx->db_desc.as<float>(),
