@@ -126,12 +126,20 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
                                                              const uint32_t* __restrict__ q, uint32_t n_rows,
                                                              uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
                                                              uint32_t n_tiles, uint32_t n_qw,
-                                                             uint32_t blocks_per_xcd, uint32_t cut,
+                                                             uint32_t blocks_per_xcd, uint32_t tiles_per_xcd, uint32_t cut,
                                                              uint32_t* __restrict__ part, uint32_t* bound) {
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t vblock = xcd * blocks_per_xcd + slot;                 // XCD-contiguous virtual block id
-  const uint32_t item = __builtin_amdgcn_readfirstlane(vblock * kWavesPerBlock + (threadIdx.x >> 6));
-  const uint32_t tile = item / n_qw, qw = item % n_qw;
+  uint32_t tile, qw;
+  if (tiles_per_xcd) {
+    // every XCD owns whole DB tiles (its L2 then holds one contiguous slice of the DB, read by all its query waves)
+    const uint32_t local = __builtin_amdgcn_readfirstlane(slot * kWavesPerBlock + (threadIdx.x >> 6));
+    if (local >= tiles_per_xcd * n_qw) return;
+    tile = xcd * tiles_per_xcd + local / n_qw; qw = local % n_qw;
+  } else {
+    const uint32_t vblock = xcd * blocks_per_xcd + slot;               // XCD-contiguous virtual block id
+    const uint32_t item = __builtin_amdgcn_readfirstlane(vblock * kWavesPerBlock + (threadIdx.x >> 6));
+    tile = item / n_qw; qw = item % n_qw;
+  }
   if (tile >= n_tiles) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t qi = qw * 64u + lane;
@@ -333,6 +341,7 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radi
   const uint32_t target_waves = (uint32_t)ctx->n_cu * (uint32_t)(env_wpc > 0 ? env_wpc : kWavesPerCU);
   uint32_t n_tiles = target_waves / n_qw;
   if (n_tiles < 1) n_tiles = 1;
+  if (n_tiles >= 8) n_tiles &= ~7u;                      // whole tiles per XCD (8 XCDs)
   uint32_t rows_per_tile = (n_rows + n_tiles - 1) / n_tiles;
   rows_per_tile = ((rows_per_tile + 2 * kGroupRows - 1) / (2 * kGroupRows)) * (2 * kGroupRows);
   if (rows_per_tile < 64) rows_per_tile = 64;
@@ -340,7 +349,12 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radi
   n_tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
   const uint32_t items = n_tiles * n_qw;
   const uint32_t blocks = (items + kWavesPerBlock - 1) / kWavesPerBlock;
-  const uint32_t blocks_per_xcd = (blocks + 7u) / 8u;
+  uint32_t blocks_per_xcd = (blocks + 7u) / 8u;
+  uint32_t tiles_per_xcd = 0;
+  if (n_tiles >= 8 && n_tiles % 8u == 0) {
+    tiles_per_xcd = n_tiles / 8u;
+    blocks_per_xcd = (tiles_per_xcd * n_qw + kWavesPerBlock - 1) / kWavesPerBlock;
+  }
   const uint32_t groups = n_tiles < (uint32_t)kMergeGroups ? n_tiles : (uint32_t)kMergeGroups;
   TOD_HIP(ctx->m_part.reserve((size_t)n_tiles * K * nq_pad * sizeof(uint32_t)));
   TOD_HIP(ctx->m_bound.reserve((size_t)nq_pad * sizeof(uint32_t)));
@@ -349,7 +363,7 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radi
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(hamming_topk_tiles<K>, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw,
-                     blocks_per_xcd, cut, ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>());
+                     blocks_per_xcd, tiles_per_xcd, cut, ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>());
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
                      ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
