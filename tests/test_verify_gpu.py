@@ -432,3 +432,35 @@ def test_batch_depth_form_after_batched_matching(ctx):
         assert got[i][0]["object"] == o_poses[0]["object"] == (1, 4, 2)[i]
         assert np.array_equal(got[i][0]["inliers"], o_poses[0]["inliers"])
         assert np.abs(got[i][0]["R"] - o_poses[0]["R"]).max() < POSE_TOL and np.abs(got[i][0]["t"] - o_poses[0]["t"]).max() < POSE_TOL
+
+
+def test_batch_larger_than_one_launch_group(ctx):
+    """More frames than argument sets fit one launch (16): the engine splits every kernel list into several launches.
+    18 frames (the same 3 scenes, different generators) == frame by frame."""
+    import torch
+    k, nq, seed = 3, 200, 41
+    vis = [((2, 0.3),), ((5, 0.3), (3, 0.25)), ((1, 0.4),)]
+    base = [synth.make_verify_scene(nq, visible=v, seed=seed, matches_per_kp=3) for v in vis]
+    packed = [_pack_scene(s, k) for s in base]
+    F = 18
+    idx = [f % 3 for f in range(F)]
+    d_kp = torch.from_numpy(np.stack([base[i]["kp_xy"] for i in idx]).astype(np.float32)).cuda()
+    d_cloud = torch.from_numpy(np.stack([base[i]["cloud"] for i in idx]).astype(np.float32)).cuda()
+    d_counts = torch.from_numpy(np.stack([packed[i][0] for i in idx])).cuda()
+    d_m = torch.from_numpy(np.stack([packed[i][1] for i in idx])).cuda()
+    d_xyz = torch.from_numpy(np.stack([packed[i][2] for i in idx])).cuda()
+    torch.cuda.synchronize()
+    spans = base[0]["spans"]
+    want = []
+    for f in range(F):
+        r = capi.rng_new(1 + f // 3)
+        want.append((ctx.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), 480, 640, d_counts[f].data_ptr(),
+                                       d_m[f].data_ptr(), d_xyz[f].data_ptr(), k, spans, 8, 300, 0.01, r), r.draws))
+    rngs = (capi.Rng * F)(*[capi.rng_new(1 + f // 3) for f in range(F)])
+    got = ctx.verify_batch_device(F, d_kp.data_ptr(), nq, d_cloud.data_ptr(), 480, 640, d_counts.data_ptr(), d_m.data_ptr(),
+                                  d_xyz.data_ptr(), k, spans, 8, 300, 0.01, rngs)
+    assert sum(len(p) for p in got) >= F
+    for f in range(F):
+        assert rngs[f].draws == want[f][1] and len(got[f]) == len(want[f][0])
+        for a, b in zip(got[f], want[f][0]):
+            assert a["object"] == b["object"] and np.array_equal(a["inliers"], b["inliers"]) and np.array_equal(a["R"], b["R"])

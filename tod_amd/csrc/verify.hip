@@ -1479,7 +1479,7 @@ struct RoundState {                                       // computeModel (ransa
   double k = 1.0;
   uint32_t best_it = 0;
   uint64_t pos_after_stop = 0;
-  uint32_t batch = 64, lookahead = 4096;
+  uint32_t batch = 16, lookahead = 4096;   // evaluation batches: 16, 64, 256, 1024 (easy scenes stop within the first)
   uint32_t nvalid = 0, total_iters = 0;
   uint32_t it_begin = 0, want = 0, got = 0, S = 0, window_len = 0;   // the evaluation batch being drawn
   uint32_t n_def = 0;
