@@ -313,6 +313,7 @@ def main():
             "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,
+                         "binding_roof": "integer VALU (see valu_roofline)", "valu_frac": valu_frac,
                          "queries_per_launch": world * B * nq,
                          "note": "at %d queries per DB pass this kernel is bound by integer VALU issue, not HBM "
                                  "(SURVEY F11): see valu_roofline" % (world * B * nq)},

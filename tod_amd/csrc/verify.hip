@@ -1239,7 +1239,9 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
 // InvalidateQueryIndices (adjacency_ransac.cpp:93-123): drop every valid match whose keypoint is an inlier
 // keypoint, then InvalidateIndices (:63-89): repeatedly drop valid matches whose sample degree is < 3.
 struct InvArgs { ObjJob job; const u64* kp_bits; u64* scratch; };
-__global__ __launch_bounds__(1024) void invalidate_kernel(Slots<InvArgs> SL) {
+// 256 threads (one wave per SIMD): a block this size still finds wave slots on a CU whose other slots are held by the
+// matcher's resident grid; a 1024-thread block had to wait for a whole matcher launch to end (1.4 ms on average)
+__global__ __launch_bounds__(256) void invalidate_kernel(Slots<InvArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = SL.a[blockIdx.x].job;
   const u64* const kp_bits = SL.a[blockIdx.x].kp_bits; u64* const scratch = SL.a[blockIdx.x].scratch;
@@ -1247,7 +1249,7 @@ __global__ __launch_bounds__(1024) void invalidate_kernel(Slots<InvArgs> SL) {
   const uint32_t tid = threadIdx.x, W = job.W, n = job.n;
   if (tid == 0) sAny = 0u;
   __syncthreads();
-  for (uint32_t w = tid; w < W; w += 1024u) {
+  for (uint32_t w = tid; w < W; w += 256u) {
     u64 gone = 0ull, val = job.valid[w];
     u64 bits = val;
     while (bits) {
@@ -1264,9 +1266,9 @@ __global__ __launch_bounds__(1024) void invalidate_kernel(Slots<InvArgs> SL) {
     __syncthreads();
     if (tid == 0) sAny = 0u;
     __syncthreads();
-    for (uint32_t w = tid; w < W; w += 1024u) scratch[w] = 0ull;
+    for (uint32_t w = tid; w < W; w += 256u) scratch[w] = 0ull;
     __syncthreads();
-    for (uint32_t v = tid; v < n; v += 1024u) {
+    for (uint32_t v = tid; v < n; v += 256u) {
       if ((job.valid[v >> 6] >> (v & 63u)) & 1ull) {
         uint32_t d = 0;
         for (uint32_t w = 0; w < W; ++w) d += (uint32_t)__popcll(job.samp[(size_t)v * W + w] & job.valid[w]);
@@ -1275,7 +1277,7 @@ __global__ __launch_bounds__(1024) void invalidate_kernel(Slots<InvArgs> SL) {
     }
     __syncthreads();
     if (sAny == 0u) break;
-    for (uint32_t w = tid; w < W; w += 1024u) job.valid[w] &= ~scratch[w];
+    for (uint32_t w = tid; w < W; w += 256u) job.valid[w] &= ~scratch[w];
   }
 }
 
@@ -1324,14 +1326,14 @@ __global__ __launch_bounds__(256) void cluster_lookup_kernel(Slots<LookupArgs> S
 
 // exclusive scan of kept[0..nq) into offs[0..nq], one block
 struct ScanArgs { const uint32_t* kept; uint32_t nq; uint32_t* offs; };
-__global__ __launch_bounds__(1024) void cluster_scan_kernel(Slots<ScanArgs> SL) {
+__global__ __launch_bounds__(256) void cluster_scan_kernel(Slots<ScanArgs> SL) {
   __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t* __restrict__ kept = SL.a[blockIdx.x].kept;
   const uint32_t nq = SL.a[blockIdx.x].nq;
   uint32_t* const offs = SL.a[blockIdx.x].offs;
-  __shared__ uint32_t part[1024];
+  __shared__ uint32_t part[256];
   const uint32_t tid = threadIdx.x;
-  const uint32_t chunk = (nq + 1023u) / 1024u;
+  const uint32_t chunk = (nq + 255u) / 256u;
   const uint32_t lo = min(nq, tid * chunk), hi = min(nq, lo + chunk);
   uint32_t s = 0;
   for (uint32_t i = lo; i < hi; ++i) s += kept[i];
@@ -1339,7 +1341,7 @@ __global__ __launch_bounds__(1024) void cluster_scan_kernel(Slots<ScanArgs> SL) 
   __syncthreads();
   if (tid == 0) {
     uint32_t acc = 0;
-    for (uint32_t i = 0; i < 1024u; ++i) { const uint32_t c = part[i]; part[i] = acc; acc += c; }
+    for (uint32_t i = 0; i < 256u; ++i) { const uint32_t c = part[i]; part[i] = acc; acc += c; }
     offs[nq] = acc;
   }
   __syncthreads();
@@ -1868,11 +1870,11 @@ struct Engine {
     launch_list(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
     launch_list(st, copy_words_kernel, L.zero, 256, 0, 1, words);
     launch_list(st, cluster_lookup_kernel, L.lookup, 256, 0, 1, [](const LookupArgs& a) { return dim3((a.nq + 255u) / 256u); });
-    launch_list(st, cluster_scan_kernel, L.scan, 1024, 0, 0, [](const ScanArgs&) { return dim3(1); });
+    launch_list(st, cluster_scan_kernel, L.scan, 256, 0, 0, [](const ScanArgs&) { return dim3(1); });
     launch_list(st, cluster_scatter_kernel, L.scatter, 256, 0, 1,
                 [](const ScatterArgs& a) { return dim3((uint32_t)(((size_t)a.nq * a.k + 255u) / 256u)); });
     launch_list(st, cluster_group_kernel, L.group, 256, 0, 1, [](const GroupArgs& a) { return dim3((a.n_all + 255u) / 256u); });
-    launch_list(st, invalidate_kernel, L.inval, 1024, 0, 0, [](const InvArgs&) { return dim3(1); });
+    launch_list(st, invalidate_kernel, L.inval, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
     launch_list(st, finite_kernel, L.finite, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
     launch_list(st, adjacency_kernel, L.adj, 256, 0, 2, [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
     launch_list(st, round_prep_kernel, L.prep, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
