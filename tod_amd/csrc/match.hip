@@ -20,6 +20,7 @@
 //                          descriptors with independent bits and radius 35).
 // K4m merge_tiles_kernel   per query: merge the per-tile lists into k global keys.
 // K4f finalize_kernel      per query: merge shard lists, radius cut, object lookup, 3D gather.
+#include <algorithm>
 #include <cstdlib>
 
 #include "ctx.h"
@@ -32,7 +33,7 @@ constexpr int kLocalBits = 22;     // tile-local row index bits in a partial key
 constexpr uint32_t kLocalMask = (1u << kLocalBits) - 1u;
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr int kWavesPerCU = 24;    // grid is sized to be fully resident: 6 blocks of 4 waves per CU (<= 112 SGPRs)
+constexpr int kWavesPerCU = 24;    // waves a CU holds at once: 6 blocks of 4 waves (<= 112 SGPRs); the grid is ~3x that
 constexpr uint32_t kSharePeriod = 128;   // groups between two exchanges of the per-query distance bound
 constexpr int kMergeGroups = 16;   // stage-1 merge fan-in
 
@@ -336,12 +337,20 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radi
   const uint32_t n_rows = (uint32_t)ctx->shard_rows;
   const uint32_t n_qw = (nq + 63u) / 64u;
   const uint32_t nq_pad = n_qw * 64u;
-  // a fully resident grid (no second round of blocks): n_cu x kWavesPerCU waves, equal work per wave
+  // Tiling (measured, tools/time_k4.py): about three times more waves than fit the chip at once and tiles of at most
+  // ~4096 rows. An exactly-resident grid of long-running waves (the first design) lost 15-20 %: the hardware does not
+  // spread blocks evenly over the CUs, and the query waves of a large tile drift apart in it (scalar-cache and L2
+  // misses); short blocks rebalance by themselves and keep a tile's readers together.
   static const int env_wpc = getenv("TODHIP_K4_WAVES_PER_CU") ? atoi(getenv("TODHIP_K4_WAVES_PER_CU")) : 0;   // tuning knob
-  const uint32_t target_waves = (uint32_t)ctx->n_cu * (uint32_t)(env_wpc > 0 ? env_wpc : kWavesPerCU);
-  uint32_t n_tiles = target_waves / n_qw;
+  uint32_t n_tiles;
+  if (env_wpc > 0) {
+    n_tiles = (uint32_t)ctx->n_cu * (uint32_t)env_wpc / n_qw;
+  } else {
+    n_tiles = std::max(3u * (uint32_t)ctx->n_cu * (uint32_t)kWavesPerCU / n_qw, (n_rows + 4095u) / 4096u);
+    n_tiles = std::min(n_tiles, 4096u);
+  }
   if (n_tiles < 1) n_tiles = 1;
-  if (n_tiles >= 8) n_tiles &= ~7u;                      // whole tiles per XCD (8 XCDs)
+  if (n_tiles >= 8) n_tiles = (n_tiles + 7u) & ~7u;      // whole tiles per XCD (8 XCDs)
   uint32_t rows_per_tile = (n_rows + n_tiles - 1) / n_tiles;
   rows_per_tile = ((rows_per_tile + 2 * kGroupRows - 1) / (2 * kGroupRows)) * (2 * kGroupRows);
   if (rows_per_tile < 64) rows_per_tile = 64;
