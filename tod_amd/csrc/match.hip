@@ -93,30 +93,38 @@ __device__ __forceinline__ uint32_t hamming256_mem(const uint32_t (&q)[kWords], 
 template <int K>
 __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], const RowGroup& g, uint32_t r,
                                               uint32_t (&best)[K], uint32_t& worst_d, uint32_t& limit, uint32_t foreign) {
-  // the four rows' accumulate chains are interleaved word by word: no instruction depends on its predecessor
+  // Three-stage partial-distance elimination. Stage A: 96 bits of each of the four rows (chains interleaved word by
+  // word: no instruction depends on its predecessor) and one ballot per row; a row whose lower bound reaches the limit
+  // in all 64 queries is finished. Stage B, per surviving row (~29 % of the rows on independent bits at radius 35):
+  // the 4th word, test again; stage C (rare): the other 128 bits, test, insert.
   uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < 3; ++w) {
     const uint32_t x0 = qd[w] ^ g.lo[w], x1 = qd[w] ^ g.lo[kWords + w], x2 = qd[w] ^ g.hi[w], x3 = qd[w] ^ g.hi[kWords + w];
     d0 = bcnt_acc(x0, d0); d1 = bcnt_acc(x1, d1); d2 = bcnt_acc(x2, d2); d3 = bcnt_acc(x3, d3);
   }
-  uint32_t dmin = min(min(d0, d1), min(d2, d3));
-  if (__builtin_amdgcn_ballot_w64(dmin < limit) == 0ull) return;      // lower bounds already out: skip the second half
-  d0 = hamming128<0, 4>(qd, g.lo, d0);
-  d1 = hamming128<1, 4>(qd, g.lo, d1);
-  d2 = hamming128<0, 4>(qd, g.hi, d2);
-  d3 = hamming128<1, 4>(qd, g.hi, d3);
-  dmin = min(min(d0, d1), min(d2, d3));
-  if (__builtin_amdgcn_ballot_w64(dmin < limit) != 0ull) {
-    // rows are visited in ascending order, so a later row never displaces an equal distance:
-    // "key < best[K-1]" is exactly "d < worst_d" and insertion order inside the group is free.
-    topk_insert<K>(best, (d0 << kLocalBits) | r);
-    topk_insert<K>(best, (d1 << kLocalBits) | (r + 1));
-    topk_insert<K>(best, (d2 << kLocalBits) | (r + 2));
-    topk_insert<K>(best, (d3 << kLocalBits) | (r + 3));
-    worst_d = best[K - 1] >> kLocalBits;
-    limit = min(worst_d, foreign);
+  const unsigned long long b0 = __builtin_amdgcn_ballot_w64(d0 < limit), b1 = __builtin_amdgcn_ballot_w64(d1 < limit),
+                           b2 = __builtin_amdgcn_ballot_w64(d2 < limit), b3 = __builtin_amdgcn_ballot_w64(d3 < limit);
+  if ((b0 | b1 | b2 | b3) == 0ull) return;
+  // rows are visited in ascending order, so a later row never displaces an equal distance:
+  // "key < best[K-1]" is exactly "d < worst_d"
+#define TOD_ROW_STAGES(bal_, d_, rows_, half_, idx_)                                                               \
+  if ((bal_) != 0ull) {                                                                                            \
+    d_ = bcnt_acc(qd[3] ^ rows_[half_ * kWords + 3], d_);                                                         \
+    if (__builtin_amdgcn_ballot_w64(d_ < limit) != 0ull) {                                                         \
+      d_ = hamming128<half_, 4>(qd, rows_, d_);                                                                   \
+      if (__builtin_amdgcn_ballot_w64(d_ < limit) != 0ull) {                                                       \
+        topk_insert<K>(best, (d_ << kLocalBits) | (r + idx_));                                                    \
+        worst_d = best[K - 1] >> kLocalBits;                                                                      \
+        limit = min(worst_d, foreign);                                                                            \
+      }                                                                                                           \
+    }                                                                                                             \
   }
+  TOD_ROW_STAGES(b0, d0, g.lo, 0, 0u)
+  TOD_ROW_STAGES(b1, d1, g.lo, 1, 1u)
+  TOD_ROW_STAGES(b2, d2, g.hi, 0, 2u)
+  TOD_ROW_STAGES(b3, d3, g.hi, 1, 3u)
+#undef TOD_ROW_STAGES
 }
 
 // One WAVE = one work item (DB tile, group of 64 queries). Work items are numbered tile-major so the waves
