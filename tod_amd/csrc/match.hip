@@ -90,9 +90,43 @@ __device__ __forceinline__ uint32_t hamming256_mem(const uint32_t (&q)[kWords], 
 // `limit` = min(own k-th best distance, 1 + the smallest k-th best distance any tile has published for this
 // query): a row at or above it cannot be among the k nearest of the whole DB (ties with a foreign bound are kept
 // because a smaller row index could still win them), so skipping it keeps the merged result exact.
-template <int K>
+// MODE picks the elimination schedule by how tight the initial bound (radius + 1) is; every schedule is exact.
+//   2: test after 96 bits per row, then the 4th word, then the rest   (pays for cut <= 38: a row passes the first test
+//      in some lane with probability ~0.3 on independent bits at cut 36, ~0.9 at cut 40)
+//   1: test after 128 bits per 4 rows, then the rest                  (38 < cut <= 46)
+//   0: full distances, one test per 4 rows                            (larger radii: no lower bound prunes anything)
+template <int K, int MODE>
 __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], const RowGroup& g, uint32_t r,
                                               uint32_t (&best)[K], uint32_t& worst_d, uint32_t& limit, uint32_t foreign) {
+  if (MODE < 2) {
+    // the four rows' accumulate chains are interleaved word by word: no instruction depends on its predecessor
+    uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
+#pragma unroll
+    for (int w = 0; w < (MODE == 1 ? 4 : kWords); ++w) {
+      const uint32_t x0 = qd[w] ^ g.lo[w], x1 = qd[w] ^ g.lo[kWords + w], x2 = qd[w] ^ g.hi[w], x3 = qd[w] ^ g.hi[kWords + w];
+      d0 = bcnt_acc(x0, d0); d1 = bcnt_acc(x1, d1); d2 = bcnt_acc(x2, d2); d3 = bcnt_acc(x3, d3);
+    }
+    uint32_t dmin = min(min(d0, d1), min(d2, d3));
+    if (MODE == 1) {
+      if (__builtin_amdgcn_ballot_w64(dmin < limit) == 0ull) return;    // lower bounds already out: skip the second half
+      d0 = hamming128<0, 4>(qd, g.lo, d0);
+      d1 = hamming128<1, 4>(qd, g.lo, d1);
+      d2 = hamming128<0, 4>(qd, g.hi, d2);
+      d3 = hamming128<1, 4>(qd, g.hi, d3);
+      dmin = min(min(d0, d1), min(d2, d3));
+    }
+    if (__builtin_amdgcn_ballot_w64(dmin < limit) != 0ull) {
+      // rows are visited in ascending order, so a later row never displaces an equal distance:
+      // "key < best[K-1]" is exactly "d < worst_d" and insertion order inside the group is free.
+      topk_insert<K>(best, (d0 << kLocalBits) | r);
+      topk_insert<K>(best, (d1 << kLocalBits) | (r + 1));
+      topk_insert<K>(best, (d2 << kLocalBits) | (r + 2));
+      topk_insert<K>(best, (d3 << kLocalBits) | (r + 3));
+      worst_d = best[K - 1] >> kLocalBits;
+      limit = min(worst_d, foreign);
+    }
+    return;
+  }
   // Three-stage partial-distance elimination. Stage A: 96 bits of each of the four rows (chains interleaved word by
   // word: no instruction depends on its predecessor) and one ballot per row; a row whose lower bound reaches the limit
   // in all 64 queries is finished. Stage B, per surviving row (~29 % of the rows on independent bits at radius 35):
@@ -130,7 +164,7 @@ __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], cons
 // One WAVE = one work item (DB tile, group of 64 queries). Work items are numbered tile-major so the waves
 // of a block share a tile (scalar-cache / L2 locality); blocks b and b+8 share an XCD, and the decode below
 // gives each XCD a contiguous run of tiles.
-template <int K>
+template <int K, int MODE>
 __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __restrict__ db,
                                                              const uint32_t* __restrict__ q, uint32_t n_rows,
                                                              uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
@@ -186,11 +220,11 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
     uint32_t g = 0, next_share = 16;                        // first exchange early: the tile's own list is full by then
     for (; g + 2 <= n_groups; g += 2) {
       issue_rows(gb, base + (size_t)(g + 1) * kStride);
-      consume_group<K>(qd, ga, r, best, worst_d, limit, foreign);
+      consume_group<K, MODE>(qd, ga, r, best, worst_d, limit, foreign);
       wait_rows(gb);
       const uint32_t gn = (g + 2 < n_groups) ? g + 2 : g;      // the last pair re-reads an in-bounds group
       issue_rows(ga, base + (size_t)gn * kStride);
-      consume_group<K>(qd, gb, r + kGroupRows, best, worst_d, limit, foreign);
+      consume_group<K, MODE>(qd, gb, r + kGroupRows, best, worst_d, limit, foreign);
       wait_rows(ga);
       r += 2 * kGroupRows;
       if (g >= next_share) {                                // wave-uniform
@@ -203,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
       }
     }
     if (g < n_groups) {                                         // odd group count: ga holds group g
-      consume_group<K>(qd, ga, r, best, worst_d, limit, foreign);
+      consume_group<K, MODE>(qd, ga, r, best, worst_d, limit, foreign);
       r += kGroupRows;
     }
   }
@@ -378,7 +412,8 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radi
   TOD_HIP(hipMemsetAsync(ctx->m_bound.p, 0xFF, (size_t)nq_pad * sizeof(uint32_t), ctx->stream));
   int slot = -1;
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
-  hipLaunchKernelGGL(hamming_topk_tiles<K>, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
+  auto kern = cut <= 38u ? hamming_topk_tiles<K, 2> : (cut <= 46u ? hamming_topk_tiles<K, 1> : hamming_topk_tiles<K, 0>);
+  hipLaunchKernelGGL(kern, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw,
                      blocks_per_xcd, tiles_per_xcd, cut, ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>());
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }

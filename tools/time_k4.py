@@ -10,7 +10,8 @@ ctx = capi.Context(0)
 ctx.db_load(desc, pts, off)
 d_q = torch.from_numpy(q).cuda(); n = B * nq
 d_c = torch.empty(n, dtype=torch.int32, device='cuda'); d_m = torch.empty((n * k, 4), dtype=torch.int32, device='cuda'); d_x = torch.empty((n * k, 3), device='cuda')
-def run(): ctx.match_device(d_q.data_ptr(), n, k, 35, d_c.data_ptr(), d_m.data_ptr(), d_x.data_ptr())
+RADIUS = int(os.environ.get("RADIUS", "35"))
+def run(): ctx.match_device(d_q.data_ptr(), n, k, RADIUS, d_c.data_ptr(), d_m.data_ptr(), d_x.data_ptr())
 for _ in range(2): run()
 ctx.synchronize(); ctx.set_kernel_timing(True); c0 = ctx.counters()
 t = time.perf_counter()
