@@ -49,3 +49,13 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.lower(), f
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/todhip.h must compile as C99 (no C++ types in the signatures)."""
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write('#include "todhip.h"\nint main(void) { todhip_rng r; todhip_rng_seed(&r, 1); return 0; }\n')
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-c", src, "-o", os.path.join(d, "t.o")], check=True)

@@ -15,6 +15,7 @@
 // The RANSAC bookkeeping (ransac.h:95-135: strictly-better test, adaptive k with pow/log) is replayed on the
 // host from the per-iteration consensus counts, so that libm results are those of the CPU reference.
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(256) void copy_words_kernel(Slots<CopyArgs> S) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += gridDim.x * 256u) a.dst[i] = a.src ? a.src[i] : 0u;
 }
 
-#define TOD_DBG(...) do { if (getenv("TODHIP_DEBUG")) { fprintf(stderr, "[todhip] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+inline bool tod_debug() { static const bool on = getenv("TODHIP_DEBUG") != nullptr; return on; }   // read once
+#define TOD_DBG(...) do { if (tod_debug()) { fprintf(stderr, "[todhip] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 // ------------------------------------------------------------------------------------------------ K6
 __global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs> S) {
@@ -1447,13 +1449,13 @@ inline uint32_t rng_next(todhip_rng& r) {
 }
 
 int set_big_lds_once(todhip_ctx* ctx) {
-  static bool done = false;
-  if (!done) {
+  static std::atomic<bool> done{false};                   // contexts may be driven from several host threads
+  if (!done.load(std::memory_order_acquire)) {
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kEvalLdsBig));
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clique_test_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
-    done = true;
+    done.store(true, std::memory_order_release);
   }
   return TODHIP_OK;
 }
@@ -1795,7 +1797,7 @@ struct Engine {
     }
     if (s.ph == PH_EVAL_WAIT || s.ph == PH_EVAL2_WAIT) {
       if (m[12] != 0) {
-        if (getenv("TODHIP_DEBUG"))
+        if (tod_debug())
           fprintf(stderr, "[todhip] eval status %u: g=%u value=%u m=%u it=%u (n=%u W=%u)\n", m[12], m[16], m[17], m[18], m[19],
                   s.job.n, s.job.W);
         fail(s, TODHIP_ESCRATCH);
