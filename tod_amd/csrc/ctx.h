@@ -19,6 +19,13 @@
   } while (0)
 
 // Growable device buffer: the hot path never calls hipMalloc once sizes have been seen.
+// The short, latency-bound kernels (ORB, verifier, merges) raise their wave priority: beside the matcher's
+// VALU-saturating waves a wave at default priority gets ~1/5 of a SIMD's issue slots.
+#ifndef TOD_LATENCY_PRIO_LEVEL
+#define TOD_LATENCY_PRIO_LEVEL 3
+#endif
+#define TOD_LATENCY_PRIO() __builtin_amdgcn_s_setprio(TOD_LATENCY_PRIO_LEVEL)
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kBlock) void merge_tiles_kernel(const uint32_t* __r
                                                              uint32_t nq_pad, uint32_t n_tiles,
                                                              uint32_t rows_per_tile, uint64_t first_global_row,
                                                              uint32_t n_groups, uint64_t* __restrict__ keys) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t grp = blockIdx.y;
   if (qi >= nq) return;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void merge_tiles_kernel(const uint32_t* __r
 // K4s: per query, the k smallest of n_lists ascending lists (layout [list][nq][k]) -> keys[nq][k].
 __global__ __launch_bounds__(kBlock) void select_keys_kernel(const uint64_t* __restrict__ lists, uint32_t n_lists,
                                                              uint32_t nq, uint32_t k, uint64_t* __restrict__ keys) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
   if (qi >= nq) return;
   uint64_t last = 0;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __rest
                                                           uint32_t* __restrict__ counts,
                                                           todhip_dmatch* __restrict__ matches,
                                                           float* __restrict__ xyz) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
   if (qi >= nq) return;
   uint32_t kept = 0;

@@ -62,7 +62,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restrict__ src, uint32_t stride, uint8_t* dst,
                                                         uint32_t h, uint32_t w, size_t src_fs, size_t dst_fs) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   src += blockIdx.y * src_fs; dst += blockIdx.y * dst_fs;   // frame
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restric
 // 11-bit fixed-point bilinear resize, sample positions (x + 0.5) * sx - 0.5, replicate border
 __global__ __launch_bounds__(256) void resize_kernel(const uint8_t* __restrict__ src, uint32_t sh, uint32_t sw, uint8_t* dst,
                                                      uint32_t dh, uint32_t dw, size_t fs) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   src += blockIdx.y * fs; dst += blockIdx.y * fs;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= dh * dw) return;
@@ -109,7 +109,7 @@ __device__ __forceinline__ int arc9_max(const int (&d)[16]) {
 
 __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, uint32_t h, uint32_t w, int* score,
                                                          size_t fs) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   img += blockIdx.z * fs; score += blockIdx.z * fs;
   const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restri
 __global__ __launch_bounds__(256) void nms_kernel(const int* __restrict__ score, uint32_t h, uint32_t w, Cand* cand,
                                                   uint32_t cap, uint32_t* counter, uint32_t* hist,
                                                   const uint8_t* __restrict__ mask, uint32_t H0, uint32_t W0, size_t fs) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   score += blockIdx.z * fs; cand += (size_t)blockIdx.z * cap; counter += blockIdx.z * kCtlWords; hist += blockIdx.z * kCtlWords;
   if (mask) mask += blockIdx.z * fs;
   const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void level_reset_kernel(uint32_t* ctl) {
 // gives the score threshold T: everything above T is kept, and of the candidates at exactly T the first
 // keep - count(> T) in (y, x) order.
 __global__ void fast_threshold_kernel(uint32_t* ctl, uint32_t cand_cap, uint32_t keep) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   ctl += blockIdx.x * kCtlWords;
   if (threadIdx.x != 0) return;
   const uint32_t n = min(ctl[W_NCAND], cand_cap);
@@ -197,7 +197,7 @@ __global__ void fast_threshold_kernel(uint32_t* ctl, uint32_t cand_cap, uint32_t
 
 __global__ __launch_bounds__(256) void split_kernel(const Cand* __restrict__ cand, uint32_t* ctl, uint32_t keep, Cand* sel1,
                                                     Cand* eq, uint32_t cand_cap, uint32_t sel1_cap) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   cand += (size_t)blockIdx.y * cand_cap; eq += (size_t)blockIdx.y * cand_cap; sel1 += (size_t)blockIdx.y * sel1_cap;
   ctl += blockIdx.y * kCtlWords;
   const uint32_t n = ctl[W_NCAND];
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void rank_tiled_kernel(const Cand* __restrict_
                                                          const uint32_t* __restrict__ keep_ptr, uint32_t keep_val,
                                                          int by_harris, Cand* out, const uint32_t* __restrict__ off_ptr,
                                                          uint32_t* n_out, uint32_t in_fs, uint32_t out_fs) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   __shared__ unsigned long long keys[kRankTile];
   in += (size_t)blockIdx.y * in_fs; out += (size_t)blockIdx.y * out_fs;      // frame: buffers by their strides,
   n_ptr += blockIdx.y * kCtlWords;                                           // control words by kCtlWords
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void rank_tiled_kernel(const Cand* __restrict_
 
 __global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__ img, uint32_t w, Cand* cand,
                                                      const uint32_t* __restrict__ n_ptr, size_t fs, uint32_t cand_fs) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   img += blockIdx.y * fs; cand += (size_t)blockIdx.y * cand_fs; n_ptr += blockIdx.y * kCtlWords;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= *n_ptr) return;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__
 __constant__ int c_gauss7[7] = {18, 33, 49, 56, 49, 33, 18};
 
 __global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst, size_t fs) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   src += blockIdx.y * fs; dst += blockIdx.y * fs;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__
   dst[i] = (uint8_t)((s + 128) >> 8);
 }
 __global__ __launch_bounds__(256) void blur_v_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst, size_t fs) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   src += blockIdx.y * fs; dst += blockIdx.y * fs;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
@@ -300,7 +300,7 @@ struct DescribeArgs {
 
 // one wave per keypoint: integer moments over the radius-15 disc (lane = row), then 4 tests per lane
 __global__ __launch_bounds__(256) void describe_kernel(DescribeArgs A) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   {
     const uint32_t f = blockIdx.y;
     A.img += f * A.fs; A.blur += f * A.fs; A.sel += (size_t)f * A.sel_fs;

@@ -60,7 +60,7 @@ inline bool tod_debug() { static const bool on = getenv("TODHIP_DEBUG") != nullp
 
 // ------------------------------------------------------------------------------------------------ K6
 __global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs> S) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.z].job;
   const float span = S.a[blockIdx.z].span, err = S.a[blockIdx.z].err;
   const uint32_t i = blockIdx.x;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs> S) {
 }
 
 __global__ __launch_bounds__(256) void finite_kernel(Slots<JobArgs> S) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.y].job;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   bool f = false;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void finite_kernel(Slots<JobArgs> S) {
 
 // per round: sample degree inside the valid set, the ">= 7" filter mask (:211-213), |valid|
 __global__ __launch_bounds__(256) void round_prep_kernel(Slots<PrepArgs> S) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.y].job;
   uint32_t* const nvalid = S.a[blockIdx.y].nvalid;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void round_prep_kernel(Slots<PrepArgs> S) {
 
 // ------------------------------------------------------------------------------------------------ K7a
 __global__ __launch_bounds__(256) void draw_table_kernel(Slots<DrawArgs> SL) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = SL.a[blockIdx.y].job;
   const uint32_t* __restrict__ rnd = SL.a[blockIdx.y].rnd;
   const uint32_t window_len = SL.a[blockIdx.y].window_len, S = SL.a[blockIdx.y].S;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void draw_table_kernel(Slots<DrawArgs> SL) {
 
 // ------------------------------------------------------------------------------------------------ K7b
 __global__ void chain_kernel(Slots<ChainArgs> SL) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   if (threadIdx.x != 0) return;
   const ChainArgs& a = SL.a[blockIdx.x];
   const DrawEntry* __restrict__ table = a.table;
@@ -743,7 +743,7 @@ struct EvalArgs {
 // launched with 64 threads; the bound is deliberately larger so that hipcc keeps __syncthreads() as a real,
 // convergent s_barrier (with a 64-thread bound it drops the barrier and may split the lanes of the wave)
 __global__ __launch_bounds__(128) void eval_kernel(Slots<EvalArgs> SL) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const EvalArgs& A = SL.a[blockIdx.y];
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const uint32_t l = lane_id();
@@ -1054,7 +1054,7 @@ struct GrowthArgs {
   u64 *inl, *rest, *extra; uint32_t* kp_list; u64* kp_bits; uint32_t kp_words; GrowthOut* out;
 };
 __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const GrowthArgs& ga = SL.a[blockIdx.x];
   const ObjJob& job = ga.job;
   const uint32_t s0 = ga.triple[0], s1 = ga.triple[1], s2 = ga.triple[2];
@@ -1244,7 +1244,7 @@ struct InvArgs { ObjJob job; const u64* kp_bits; u64* scratch; };
 // 256 threads (one wave per SIMD): a block this size still finds wave slots on a CU whose other slots are held by the
 // matcher's resident grid; a 1024-thread block had to wait for a whole matcher launch to end (1.4 ms on average)
 __global__ __launch_bounds__(256) void invalidate_kernel(Slots<InvArgs> SL) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = SL.a[blockIdx.x].job;
   const u64* const kp_bits = SL.a[blockIdx.x].kp_bits; u64* const scratch = SL.a[blockIdx.x].scratch;
   __shared__ uint32_t sAny;
@@ -1299,7 +1299,7 @@ struct LookupArgs {
 // (x = (u - cx) z / fx, y = (v - cy) z / fy), uint16 depth in millimetres with 0 = no measurement -> NaN as
 // cv::rescaleDepth does (third-party conventions, recalled; parity unpinned).
 __global__ __launch_bounds__(256) void cluster_lookup_kernel(Slots<LookupArgs> SL) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const LookupArgs& a = SL.a[blockIdx.y];
   const uint32_t q = blockIdx.x * 256u + threadIdx.x;
   if (q >= a.nq) return;
@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(256) void cluster_lookup_kernel(Slots<LookupArgs> S
 // exclusive scan of kept[0..nq) into offs[0..nq], one block
 struct ScanArgs { const uint32_t* kept; uint32_t nq; uint32_t* offs; };
 __global__ __launch_bounds__(256) void cluster_scan_kernel(Slots<ScanArgs> SL) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t* __restrict__ kept = SL.a[blockIdx.x].kept;
   const uint32_t nq = SL.a[blockIdx.x].nq;
   uint32_t* const offs = SL.a[blockIdx.x].offs;
@@ -1357,7 +1357,7 @@ struct ScatterArgs {
   uint32_t* fqidx; float* fkp; uint32_t* err;
 };
 __global__ __launch_bounds__(256) void cluster_scatter_kernel(Slots<ScatterArgs> SL) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ScatterArgs& a = SL.a[blockIdx.y];
   const float* __restrict__ kp_xy = a.kp_xy; const uint32_t nq = a.nq, k = a.k, n_objs = a.n_objs;
   const todhip_dmatch* __restrict__ matches = a.matches; const float* __restrict__ mxyz = a.mxyz;
@@ -1384,7 +1384,7 @@ struct GroupArgs {
   const uint32_t* fqidx; const float* fkp; float* train; float* query; uint32_t* qidx; float* kpxy;
 };
 __global__ __launch_bounds__(256) void cluster_group_kernel(Slots<GroupArgs> SL) {
-  __builtin_amdgcn_s_setprio(3);   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const GroupArgs& a = SL.a[blockIdx.y];
   const uint32_t n_all = a.n_all;
   const uint32_t* __restrict__ obj_of = a.obj_of; const uint32_t* __restrict__ goff = a.goff;
