@@ -222,3 +222,35 @@ def test_c5_shape_1080p_orb2000_2m_rows(ctx):
         want = [int(kk) for kk in keys[i] if (int(kk) >> 32) <= 35]
         got = [(int(d) << 32) | int(r) for d, r in zip(m["distance"][row_ptr[q]:row_ptr[q + 1]], rows[row_ptr[q]:row_ptr[q + 1]])]
         assert got == want
+
+
+def test_batch_of_frames_in_one_launch_equals_frame_by_frame(ctx):
+    """The bench's launch shape: the descriptors of 16 frames share one pass over the DB (16 x Q queries in one
+    todhip_match_device call). Every frame's slice must equal that frame's own call, and the oracle on two of them."""
+    import torch
+    desc, pts, off = synth.make_db(20)                                   # C2: 100k rows
+    ctx.db_load(desc, pts, off)
+    F, nq, k = 16, 500, 2
+    frames = [synth.make_frame(desc, pts, off, nq, frame=40 + f, visible_object=f % 20) for f in range(F)]
+    d_q = torch.from_numpy(np.concatenate([fr["q_desc"] for fr in frames])).cuda()
+    cb = torch.empty(F * nq, dtype=torch.int32, device="cuda"); mb = torch.empty((F * nq * k, 4), dtype=torch.int32, device="cuda")
+    xb = torch.empty((F * nq * k, 3), dtype=torch.float32, device="cuda")
+    ctx.match_device(d_q.data_ptr(), F * nq, k, 35, cb.data_ptr(), mb.data_ptr(), xb.data_ptr())
+    ctx.synchronize()
+    c1 = torch.empty(nq, dtype=torch.int32, device="cuda"); m1 = torch.empty((nq * k, 4), dtype=torch.int32, device="cuda")
+    x1 = torch.empty((nq * k, 3), dtype=torch.float32, device="cuda")
+    for f in range(F):
+        ctx.match_device(d_q[f * nq:].data_ptr(), nq, k, 35, c1.data_ptr(), m1.data_ptr(), x1.data_ptr())
+        ctx.synchronize()
+        cnt = c1.cpu().numpy()
+        assert np.array_equal(cb[f * nq:(f + 1) * nq].cpu().numpy(), cnt)
+        got = mb[f * nq * k:(f + 1) * nq * k].cpu().numpy().reshape(nq, k, 4).copy()
+        one = m1.cpu().numpy().reshape(nq, k, 4).copy()
+        got[:, :, 0] -= f * nq                                            # queryIdx counts from the start of the batch
+        valid = np.arange(k)[None, :] < cnt[:, None]
+        assert np.array_equal(got[valid], one[valid])
+        assert np.array_equal(xb[f * nq * k:(f + 1) * nq * k].cpu().numpy().reshape(nq, k, 3)[valid],
+                              x1.cpu().numpy().reshape(nq, k, 3)[valid])
+    for f in (0, 9):
+        rc, row_ptr, m, xyz = O.match(desc, off, pts, frames[f]["q_desc"], k, 35)
+        assert np.array_equal(cb[f * nq:(f + 1) * nq].cpu().numpy(), np.diff(row_ptr.astype(np.int64)))
