@@ -139,19 +139,40 @@ __global__ __launch_bounds__(256) void nms_kernel(const int* __restrict__ score,
   score += blockIdx.z * fs; cand += (size_t)blockIdx.z * cap; counter += blockIdx.z * kCtlWords; hist += blockIdx.z * kCtlWords;
   if (mask) mask += blockIdx.z * fs;
   const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
-  if (x < (uint32_t)kEdge || x >= w - kEdge || y < (uint32_t)kEdge || y >= h - kEdge) return;
-  const int s = score[(size_t)y * w + x];
-  if (s == 0) return;
-  for (int dy = -1; dy <= 1; ++dy)
-    for (int dx = -1; dx <= 1; ++dx)
-      if ((dx || dy) && score[(size_t)(y + dy) * w + (x + dx)] >= s) return;
-  if (mask) {   // level-0 mask sampled at the nearest pixel (the training cell passes obs.mask to the detector, Trainer.cpp:144-150)
+  __shared__ uint32_t s_hist[256];
+  s_hist[threadIdx.x] = 0u;
+  __syncthreads();
+  int s = 0;
+  bool keep = !(x < (uint32_t)kEdge || x >= w - kEdge || y < (uint32_t)kEdge || y >= h - kEdge);
+  if (keep) {
+    s = score[(size_t)y * w + x];
+    keep = s != 0;
+  }
+  if (keep) {
+    for (int dy = -1; dy <= 1 && keep; ++dy)
+      for (int dx = -1; dx <= 1; ++dx)
+        if ((dx || dy) && score[(size_t)(y + dy) * w + (x + dx)] >= s) { keep = false; break; }
+  }
+  if (keep && mask) {   // level-0 mask sampled at the nearest pixel (the training cell passes obs.mask to the detector, Trainer.cpp:144-150)
     uint32_t my = (uint32_t)floorf(((float)y + 0.5f) * (float)H0 / (float)h), mx = (uint32_t)floorf(((float)x + 0.5f) * (float)W0 / (float)w);
     my = min(my, H0 - 1u); mx = min(mx, W0 - 1u);
-    if (!mask[(size_t)my * W0 + mx]) return;
+    keep = mask[(size_t)my * W0 + mx] != 0;
   }
-  const uint32_t i = atomicAdd(counter, 1u);
-  if (i < cap) { Cand c; c.x = (int)x; c.y = (int)y; c.score = s; c.harris = 0.f; cand[i] = c; atomicAdd(&hist[s & 255], 1u); }
+  // one counter atomic per wave (the candidate order is free: the ranking kernels fix it), histogram through LDS
+  const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+  if (bal != 0ull) {
+    const uint32_t lane = threadIdx.x & 63u, first = (uint32_t)__ffsll((long long)bal) - 1u;
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(counter, (uint32_t)__popcll(bal));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+    const uint32_t i = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (keep && i < cap) {
+      Cand c; c.x = (int)x; c.y = (int)y; c.score = s; c.harris = 0.f; cand[i] = c;
+      atomicAdd(&s_hist[s & 255], 1u);
+    }
+  }
+  __syncthreads();
+  if (s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 }
 
 __device__ __forceinline__ unsigned long long key_of(const Cand& c, bool by_harris) {
@@ -176,23 +197,35 @@ __global__ __launch_bounds__(256) void level_reset_kernel(uint32_t* ctl) {
 // "keep the 2n best by FAST score" only defines a SET (the Harris ranking re-orders it), so a 256-bin histogram
 // gives the score threshold T: everything above T is kept, and of the candidates at exactly T the first
 // keep - count(> T) in (y, x) order.
-__global__ void fast_threshold_kernel(uint32_t* ctl, uint32_t cand_cap, uint32_t keep) {
+__global__ __launch_bounds__(64) void fast_threshold_kernel(uint32_t* ctl, uint32_t cand_cap, uint32_t keep) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   ctl += blockIdx.x * kCtlWords;
-  if (threadIdx.x != 0) return;
+  const uint32_t l = threadIdx.x;                          // one wave per frame: lane l owns score bins 4 l .. 4 l + 3
   const uint32_t n = min(ctl[W_NCAND], cand_cap);
-  uint32_t above = 0, thr = 0, need = 0;
+  uint32_t b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = ctl[W_HIST + 4u * l + i];
+  const uint32_t mine = b[0] + b[1] + b[2] + b[3];
+  uint32_t suf = mine;                                     // candidates in this lane's bins and all higher ones
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_down(suf, d); if (l + d < 64u) suf += t; }
+  uint32_t above = suf - mine, thr = 0, need = 0;
+  bool hit = false;
   if (n > keep) {
-    for (int sc = 255; sc >= 0; --sc) {
-      const uint32_t c = ctl[W_HIST + sc];
-      if (above + c >= keep) { thr = (uint32_t)sc; need = keep - above; break; }
-      above += c;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {                         // the highest score at which the count reaches `keep`
+      if (!hit && above + b[i] >= keep) { hit = true; thr = 4u * l + (uint32_t)i; need = keep - above; }
+      above += b[i];
     }
   }
-  ctl[W_NCAND] = n;
-  ctl[W_THR] = thr; ctl[W_NEED_EQ] = (n > keep) ? need : 0u;
-  ctl[W_NSEL1] = min(n, keep);
-  ctl[W_NGT] = 0u; ctl[W_NEQ] = 0u;
+  const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+  const uint32_t winner = bal ? 63u - (uint32_t)__clzll((long long)bal) : 0u;
+  if (l == winner) {
+    ctl[W_NCAND] = n;
+    ctl[W_THR] = thr; ctl[W_NEED_EQ] = (n > keep) ? need : 0u;
+    ctl[W_NSEL1] = min(n, keep);
+    ctl[W_NGT] = 0u; ctl[W_NEQ] = 0u;
+  }
 }
 
 __global__ __launch_bounds__(256) void split_kernel(const Cand* __restrict__ cand, uint32_t* ctl, uint32_t keep, Cand* sel1,
@@ -202,10 +235,32 @@ __global__ __launch_bounds__(256) void split_kernel(const Cand* __restrict__ can
   ctl += blockIdx.y * kCtlWords;
   const uint32_t n = ctl[W_NCAND];
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const Cand c = cand[i];
-  if (n <= keep || (uint32_t)c.score > ctl[W_THR]) sel1[atomicAdd(&ctl[W_NGT], 1u)] = c;
-  else if ((uint32_t)c.score == ctl[W_THR]) eq[atomicAdd(&ctl[W_NEQ], 1u)] = c;
+  if (blockIdx.x * 256u >= n) return;                       // block-uniform
+  Cand c = {};
+  bool gt = false, eqv = false;
+  if (i < n) {
+    c = cand[i];
+    gt = n <= keep || (uint32_t)c.score > ctl[W_THR];
+    eqv = !gt && (uint32_t)c.score == ctl[W_THR];
+  }
+  // one atomic per wave and list (the order inside both lists is free)
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long bg = __builtin_amdgcn_ballot_w64(gt), be = __builtin_amdgcn_ballot_w64(eqv);
+  if (bg != 0ull) {
+    const uint32_t first = (uint32_t)__ffsll((long long)bg) - 1u;
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(&ctl[W_NGT], (uint32_t)__popcll(bg));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+    if (gt) sel1[base + (uint32_t)__popcll(bg & lt)] = c;
+  }
+  if (be != 0ull) {
+    const uint32_t first = (uint32_t)__ffsll((long long)be) - 1u;
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(&ctl[W_NEQ], (uint32_t)__popcll(be));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+    if (eqv) eq[base + (uint32_t)__popcll(be & lt)] = c;
+  }
 }
 
 // keep the `keep` best of in[0..n) at out[out_off + rank]: rank by counting against LDS-staged key tiles
