@@ -6,8 +6,9 @@ one 640x480 synthetic frame = 1000 ORB descriptors matched against the 1M-descri
 (200 objects x 5000), Hamming brute force k=2, radius 35, then geometric verification.
 With N GPUs (tod_amd/sharded.py) the descriptor rows are split into N object-aligned shards and a step
 processes N frames, one per rank: descriptors are all-gathered, every rank matches all N frames against
-its shard, the per-shard candidates are exchanged with one RCCL all-gather, and every rank merges (order:
-distance asc, global row asc) and verifies its own frame. Per-GPU work is constant as N grows.
+its shard, the per-shard candidates are exchanged with one RCCL collective (all-to-all by default: a rank only needs
+the candidates of its own frames; --exchange all_gather for the literal all-gather), and every rank merges (order:
+distance asc, global row asc) and verifies its own frames. Per-GPU work is constant as N grows.
 
 One JSON line on rank 0; see the task contract for the fields. `roofline` is for the dominant kernel
 (hamming_topk_tiles); `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
@@ -49,6 +50,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
     ap.add_argument("--stages", default="orb,match,verify", help="comma list of: orb,match,verify")
     ap.add_argument("--batch", type=int, default=16, help="frames per rank per step")
+    ap.add_argument("--exchange", choices=("all_to_all", "all_gather"), default="all_to_all",
+                    help="several ranks: how the per-shard candidates travel. A rank only merges its own frames, so an "
+                         "all-to-all moves 1/world of an all-gather's bytes over the point-to-point xGMI links")
     ap.add_argument("--matcher-contexts", type=int, default=1,
                     help="single device only: 2 alternates steps between two matcher contexts so that consecutive DB passes "
                          "overlap (+4 %% frames/s); off by default because a launch's own duration then no longer says what "
@@ -193,6 +197,14 @@ def main():
             dist.all_gather(parts, inp.contiguous().view(-1).cpu())
             out.view(-1).copy_(torch.cat(parts).to(out.device))
 
+    def all_to_all(out, inp):
+        if backend == "nccl":
+            dist.all_to_all_single(out.view(-1), inp.contiguous().view(-1))
+        else:                                           # gloo rehearsal: stage through the host
+            o = torch.empty(out.numel(), dtype=out.dtype)
+            dist.all_to_all_single(o, inp.contiguous().view(-1).cpu())
+            out.view(-1).copy_(o.to(out.device))
+
     def orb_task(i):
         t = time.perf_counter()
         n = octx.orb_batch_device(IMG_B[i % period].data_ptr(), B, H * W, H, W, W, nq, 3, 1.2, orb_out[0].data_ptr(),
@@ -225,9 +237,13 @@ def main():
             q_all = alloc((world, B, nq, 32), "uint8")
             all_gather(q_all, q)
             ctx.match_shard_device(q_all.data_ptr(), world * B * nq, k, args.radius, d_keys.data_ptr())
-            keys_all = alloc((world, world, B, nq, k), "int64")                     # [shard][rank][b][Q][k]
-            all_gather(keys_all, d_keys)
-            km = keys_all[:, rank].contiguous()                                     # [shard][B*Q][k]
+            if args.exchange == "all_to_all":
+                km = alloc((world, B * nq, k), "int64")                             # chunk j <- shard j's keys of MY frames
+                all_to_all(km, d_keys)                                              # d_keys is [frame owner][B*Q][k]
+            else:
+                keys_all = alloc((world, world, B, nq, k), "int64")                 # [shard][rank][b][Q][k]
+                all_gather(keys_all, d_keys)
+                km = keys_all[:, rank].contiguous()                                 # [shard][B*Q][k]
             ctx.merge_shards_device(km.data_ptr(), world, B * nq, k, args.radius, o["counts"].data_ptr(),
                                     o["matches"].data_ptr(), o["xyz"].data_ptr())
 
@@ -331,7 +347,7 @@ def main():
                               (args.nq, n_kp_total[0] / max(n_steps_done[0] * B, 1)) if do_orb else None,
                        "frames_per_step": world * B,
                        "parallelism": ("DB rows sharded x%d (object aligned), %d frames per rank per step, RCCL all-gather of "
-                                       "descriptors and of per-shard candidates" % (world, B)) if world > 1 else "1 GPU"},
+                                       "descriptors, %s of per-shard candidates" % (world, B, args.exchange)) if world > 1 else "1 GPU"},
             "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,

@@ -34,7 +34,7 @@ def _merge_numpy(keys_mine, off, pts, radius, k):
     return row_ptr, out_m, np.array(out_xyz, np.float32).reshape(-1, 3)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, exchange):
     import oracle_lib as O
     from tod_amd import capi, sharded, synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -51,6 +51,9 @@ def _worker(rank, world, port, ret):
 
         def all_gather(out, inp):
             dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1))
+
+        def all_to_all(out, inp):
+            dist.all_to_all_single(out.view(-1), inp.contiguous().view(-1))
 
         def match_shard(q_all):
             keys = O.knn_keys(desc[row_lo:row_hi], q_all.numpy(), K) if row_hi > row_lo else \
@@ -70,7 +73,8 @@ def _worker(rank, world, port, ret):
             return row_ptr, marr, xyz, poses, rng.draws
 
         row_ptr, marr, xyz, poses, draws = sharded.sharded_step(dist, world, rank, torch.from_numpy(fr["q_desc"]),
-                                                                match_shard, merge, verify, alloc, all_gather)
+                                                                match_shard, merge, verify, alloc, all_gather,
+                                                                all_to_all if exchange == "all_to_all" else None)
         # unsharded reference on this rank's frame
         rc, o_rp, o_m, o_xyz = O.match(desc, off, pts, fr["q_desc"], K, RADIUS)
         rng = O.rng_new(1)
@@ -86,12 +90,12 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_step_equals_unsharded(world):
+@pytest.mark.parametrize("world,exchange", [(2, "all_gather"), (3, "all_gather"), (2, "all_to_all"), (3, "all_to_all")])
+def test_sharded_step_equals_unsharded(world, exchange):
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29511 + world
-    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    port = 29511 + world + (10 if exchange == "all_to_all" else 0)
+    mp.spawn(_worker, args=(world, port, ret, exchange), nprocs=world, join=True)
     assert len(ret) == world
     rows = sorted(v[3] for v in ret.values())
     assert rows[0][0] == 0 and all(a[1] == b[0] for a, b in zip(rows, rows[1:])) and rows[-1][1] == 2605

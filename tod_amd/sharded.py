@@ -5,8 +5,10 @@ batch are dealt one per rank. One step =
 
   1. all-gather of the ranks' frame descriptors          (world x Q x 32 B, so every rank holds every frame)
   2. every rank matches ALL frames against ITS shard      -> per-shard top-k keys (distance << 32 | global row)
-  3. all-gather of those candidate keys                   (the "final RCCL all-gather of per-shard match
-                                                           candidates" of BASELINE.json's north star)
+  3. exchange of those candidate keys: all-gather         (the "final RCCL all-gather of per-shard match
+     candidates" of BASELINE.json's north star) or, with the `all_to_all` callable, an all-to-all -- a rank only
+     merges ITS OWN frames, so it only needs 1/world of what an all-gather delivers (xGMI is point to point: the
+     traffic, not the latency, is what a ring all-gather of F*Q*k*8 B per rank pays for)
   4. every rank merges the world candidate lists of ITS frame with the order (distance asc, global row asc)
      -- identical to the 1-GPU result -- and verifies that frame.
 
@@ -39,10 +41,11 @@ def shard_bounds(obj_off, rank, world):
     return lo, hi, int(obj_off[lo]), int(obj_off[hi])
 
 
-def sharded_step(dist, world, rank, my_q, match_shard, merge, verify, alloc, all_gather):
+def sharded_step(dist, world, rank, my_q, match_shard, merge, verify, alloc, all_gather, all_to_all=None):
     """One step. my_q: this rank's frame descriptors [Q, B]. Callables:
          alloc(shape, dtype_name) -> tensor on the compute device
          all_gather(out, inp)     -> dist.all_gather_into_tensor on flat views
+         all_to_all(out, inp)     -> dist.all_to_all_single on flat views (optional: step 3 as an all-to-all)
          match_shard(q_all)       -> keys [world*Q, k] int64 of this rank's shard for all frames
          merge(keys_mine)         -> merged matches of this rank's frame from keys [world, Q, k]
          verify(matches)          -> poses of this rank's frame
@@ -55,6 +58,10 @@ def sharded_step(dist, world, rank, my_q, match_shard, merge, verify, alloc, all
     all_gather(q_all, my_q)
     keys = match_shard(q_all.reshape(world * Q, -1))                 # [world*Q, k]
     k = keys.shape[-1]
+    if all_to_all is not None:
+        mine = alloc((world, Q, k), "int64")                         # chunk j <- shard j's keys of MY frame
+        all_to_all(mine, keys)                                       # keys is [frame owner][Q][k]: chunk j -> rank j
+        return verify(merge(mine))
     keys_all = alloc((world, world, Q, k), "int64")                  # [shard][frame][Q][k]
     all_gather(keys_all, keys)
     mine = keys_all[:, rank].contiguous()                            # [shard][Q][k] of my frame
