@@ -107,68 +107,68 @@ __device__ __forceinline__ int arc9_max(const int (&d)[16]) {
   return best;
 }
 
-__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, uint32_t h, uint32_t w, int* score,
-                                                         size_t fs) {
-  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
-  img += blockIdx.z * fs; score += blockIdx.z * fs;
-  const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
-  if (x >= w || y >= h) return;
-  int s = 0;
-  if (x >= (uint32_t)(kEdge - 1) && x < w - kEdge + 1 && y >= (uint32_t)(kEdge - 1) && y < h - kEdge + 1) {
-    const uint8_t* c = img + (size_t)y * w + x;
-    const int p = c[0];
-    const int W = (int)w;
-    int d[16], nd[16];
-    d[0] = c[3 * W] - p;       d[1] = c[3 * W + 1] - p;   d[2] = c[2 * W + 2] - p;   d[3] = c[W + 3] - p;
-    d[4] = c[3] - p;           d[5] = c[-W + 3] - p;      d[6] = c[-2 * W + 2] - p;  d[7] = c[-3 * W + 1] - p;
-    d[8] = c[-3 * W] - p;      d[9] = c[-3 * W - 1] - p;  d[10] = c[-2 * W - 2] - p; d[11] = c[-W - 3] - p;
-    d[12] = c[-3] - p;         d[13] = c[W - 3] - p;      d[14] = c[2 * W - 2] - p;  d[15] = c[3 * W - 1] - p;
+__device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ img, uint32_t h, uint32_t w, int x, int y) {
+  if (x < kEdge - 1 || x >= (int)w - kEdge + 1 || y < kEdge - 1 || y >= (int)h - kEdge + 1) return 0;
+  const uint8_t* c = img + (size_t)y * w + x;
+  const int p = c[0];
+  const int W = (int)w;
+  int d[16], nd[16];
+  d[0] = c[3 * W] - p;       d[1] = c[3 * W + 1] - p;   d[2] = c[2 * W + 2] - p;   d[3] = c[W + 3] - p;
+  d[4] = c[3] - p;           d[5] = c[-W + 3] - p;      d[6] = c[-2 * W + 2] - p;  d[7] = c[-3 * W + 1] - p;
+  d[8] = c[-3 * W] - p;      d[9] = c[-3 * W - 1] - p;  d[10] = c[-2 * W - 2] - p; d[11] = c[-W - 3] - p;
+  d[12] = c[-3] - p;         d[13] = c[W - 3] - p;      d[14] = c[2 * W - 2] - p;  d[15] = c[3 * W - 1] - p;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) nd[i] = -d[i];
-    const int best = max(0, max(arc9_max(d), arc9_max(nd)));
-    s = best > kFastThr ? best : 0;
-  }
-  score[(size_t)y * w + x] = s;
+  for (int i = 0; i < 16; ++i) nd[i] = -d[i];
+  const int best = max(0, max(arc9_max(d), arc9_max(nd)));
+  return best > kFastThr ? best : 0;
 }
 
-// 3x3 strict non-maximum suppression + compaction (order is fixed later by the ranking)
-__global__ __launch_bounds__(256) void nms_kernel(const int* __restrict__ score, uint32_t h, uint32_t w, Cand* cand,
-                                                  uint32_t cap, uint32_t* counter, uint32_t* hist,
-                                                  const uint8_t* __restrict__ mask, uint32_t H0, uint32_t W0, size_t fs) {
+// FAST score + 3x3 strict non-maximum suppression + compaction in one pass: a block scores a 64 x 16 pixel tile and
+// its 1-pixel halo into LDS (the score image never goes to memory), then suppresses and appends. The candidate order
+// is fixed later by the ranking kernels, so appends are aggregated per wave (one counter atomic per wave).
+constexpr int kNmsTileW = 64, kNmsTileH = 16;
+__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ img, uint32_t h, uint32_t w, Cand* cand,
+                                                       uint32_t cap, uint32_t* counter, uint32_t* hist,
+                                                       const uint8_t* __restrict__ mask, uint32_t H0, uint32_t W0, size_t fs) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
-  score += blockIdx.z * fs; cand += (size_t)blockIdx.z * cap; counter += blockIdx.z * kCtlWords; hist += blockIdx.z * kCtlWords;
+  img += blockIdx.z * fs; cand += (size_t)blockIdx.z * cap; counter += blockIdx.z * kCtlWords; hist += blockIdx.z * kCtlWords;
   if (mask) mask += blockIdx.z * fs;
-  const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+  __shared__ int s_score[(kNmsTileH + 2) * (kNmsTileW + 2)];
   __shared__ uint32_t s_hist[256];
+  const int x0 = (int)blockIdx.x * kNmsTileW, y0 = (int)blockIdx.y * kNmsTileH;
   s_hist[threadIdx.x] = 0u;
+  for (int p = (int)threadIdx.x; p < (kNmsTileH + 2) * (kNmsTileW + 2); p += 256)
+    s_score[p] = fast_score_at(img, h, w, x0 - 1 + p % (kNmsTileW + 2), y0 - 1 + p / (kNmsTileW + 2));
   __syncthreads();
-  int s = 0;
-  bool keep = !(x < (uint32_t)kEdge || x >= w - kEdge || y < (uint32_t)kEdge || y >= h - kEdge);
-  if (keep) {
-    s = score[(size_t)y * w + x];
-    keep = s != 0;
-  }
-  if (keep) {
-    for (int dy = -1; dy <= 1 && keep; ++dy)
-      for (int dx = -1; dx <= 1; ++dx)
-        if ((dx || dy) && score[(size_t)(y + dy) * w + (x + dx)] >= s) { keep = false; break; }
-  }
-  if (keep && mask) {   // level-0 mask sampled at the nearest pixel (the training cell passes obs.mask to the detector, Trainer.cpp:144-150)
-    uint32_t my = (uint32_t)floorf(((float)y + 0.5f) * (float)H0 / (float)h), mx = (uint32_t)floorf(((float)x + 0.5f) * (float)W0 / (float)w);
-    my = min(my, H0 - 1u); mx = min(mx, W0 - 1u);
-    keep = mask[(size_t)my * W0 + mx] != 0;
-  }
-  // one counter atomic per wave (the candidate order is free: the ranking kernels fix it), histogram through LDS
-  const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
-  if (bal != 0ull) {
-    const uint32_t lane = threadIdx.x & 63u, first = (uint32_t)__ffsll((long long)bal) - 1u;
-    uint32_t base = 0;
-    if (lane == first) base = atomicAdd(counter, (uint32_t)__popcll(bal));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
-    const uint32_t i = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    if (keep && i < cap) {
-      Cand c; c.x = (int)x; c.y = (int)y; c.score = s; c.harris = 0.f; cand[i] = c;
-      atomicAdd(&s_hist[s & 255], 1u);
+  const uint32_t lane = threadIdx.x & 63u;
+  const int tx = (int)lane;
+#pragma unroll
+  for (int j = 0; j < kNmsTileH / 4; ++j) {
+    const int ty = (int)(threadIdx.x >> 6) + 4 * j;
+    const uint32_t x = (uint32_t)(x0 + tx), y = (uint32_t)(y0 + ty);
+    const int* c = &s_score[(ty + 1) * (kNmsTileW + 2) + tx + 1];
+    const int s = c[0];
+    bool keep = s != 0 && !(x < (uint32_t)kEdge || x >= w - kEdge || y < (uint32_t)kEdge || y >= h - kEdge);
+    if (keep) {
+      constexpr int R = kNmsTileW + 2;
+      keep = c[-R - 1] < s && c[-R] < s && c[-R + 1] < s && c[-1] < s && c[1] < s && c[R - 1] < s && c[R] < s && c[R + 1] < s;
+    }
+    if (keep && mask) {   // level-0 mask sampled at the nearest pixel (the training cell passes obs.mask to the detector, Trainer.cpp:144-150)
+      uint32_t my = (uint32_t)floorf(((float)y + 0.5f) * (float)H0 / (float)h), mx = (uint32_t)floorf(((float)x + 0.5f) * (float)W0 / (float)w);
+      my = min(my, H0 - 1u); mx = min(mx, W0 - 1u);
+      keep = mask[(size_t)my * W0 + mx] != 0;
+    }
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64(keep);
+    if (bal != 0ull) {
+      const uint32_t first = (uint32_t)__ffsll((long long)bal) - 1u;
+      uint32_t base = 0;
+      if (lane == first) base = atomicAdd(counter, (uint32_t)__popcll(bal));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+      const uint32_t i = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      if (keep && i < cap) {
+        Cand cd; cd.x = (int)x; cd.y = (int)y; cd.score = s; cd.harris = 0.f; cand[i] = cd;
+        atomicAdd(&s_hist[s & 255], 1u);
+      }
     }
   }
   __syncthreads();
@@ -471,7 +471,7 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, size_t gray_fs, const uin
   const uint32_t cand_cap = (uint32_t)(px / 4 + 64);
   const uint32_t sel1_cap = 2u * n_features + 16u, sel2_cap = n_features + 16u;
   TOD_HIP(ws->img[0].reserve(F * px)); TOD_HIP(ws->img[1].reserve(F * px));
-  TOD_HIP(ws->blur.reserve(F * px)); TOD_HIP(ws->tmp.reserve(F * px)); TOD_HIP(ws->score.reserve(F * px * sizeof(int)));
+  TOD_HIP(ws->blur.reserve(F * px)); TOD_HIP(ws->tmp.reserve(F * px));
   TOD_HIP(ws->cand.reserve((size_t)F * cand_cap * sizeof(Cand)));
   TOD_HIP(ws->eq.reserve((size_t)F * cand_cap * sizeof(Cand)));
   TOD_HIP(ws->sel1.reserve((size_t)F * sel1_cap * sizeof(Cand)));
@@ -527,13 +527,11 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, size_t gray_fs, const uin
         }
         if (h <= 2u * kEdge || w <= 2u * kEdge) continue;     // level count stays 0
         const uint8_t* img = ws->img[cur].as<uint8_t>();
-        const dim3 grid2((w + 63u) / 64u, (h + 3u) / 4u, F);
         const uint32_t want = per_level[lvl];
         if (want == 0) continue;
         hipLaunchKernelGGL(level_reset_kernel, dim3(F), dim3(256), 0, st, d_small);
-        hipLaunchKernelGGL(fast_score_kernel, grid2, dim3(256), 0, st, img, h, w, ws->score.as<int>(), px);
-        hipLaunchKernelGGL(nms_kernel, grid2, dim3(256), 0, st, ws->score.as<int>(), h, w, ws->cand.as<Cand>(), cand_cap, d_small,
-                           d_small + W_HIST, d_mask, H, W, px);
+        hipLaunchKernelGGL(fast_nms_kernel, dim3((w + kNmsTileW - 1) / kNmsTileW, (h + kNmsTileH - 1) / kNmsTileH, F), dim3(256), 0, st,
+                           img, h, w, ws->cand.as<Cand>(), cand_cap, d_small, d_small + W_HIST, d_mask, H, W, px);
         hipLaunchKernelGGL(fast_threshold_kernel, dim3(F), dim3(64), 0, st, d_small, cand_cap, 2u * want);
         hipLaunchKernelGGL(split_kernel, dim3((cand_cap + 255u) / 256u, F), dim3(256), 0, st, ws->cand.as<Cand>(), d_small, 2u * want,
                            ws->sel1.as<Cand>(), ws->eq.as<Cand>(), cand_cap, sel1_cap);
