@@ -186,36 +186,58 @@ __global__ __launch_bounds__(256) void draw_table_kernel(Slots<DrawArgs> SL) {
 }
 
 // ------------------------------------------------------------------------------------------------ K7b
-__global__ void chain_kernel(Slots<ChainArgs> SL) {
+// The walk is a pointer chase (position -> position + consumed): through global memory every hop costs a DRAM/L2
+// round trip (~1.5 us; 2500 iterations of a hopeless object = 4 ms), so the hop data (status, consumed) of the whole
+// window is first packed into LDS by all threads, one lane walks it there, recording where each successful attempt
+// started, and all threads then fetch those attempts' triples.
+constexpr uint32_t kChainLdsEntries = 36u * 1024u;       // 144 KB of packed (consumed << 2 | status) words
+constexpr uint32_t kChainMaxReq = 4096u;                  // == kMaxEvalWaves
+__global__ __launch_bounds__(256) void chain_kernel(Slots<ChainArgs> SL) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
-  if (threadIdx.x != 0) return;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  uint32_t* s_hop = reinterpret_cast<uint32_t*>(lds_raw);                       // min(S, kChainLdsEntries)
   const ChainArgs& a = SL.a[blockIdx.x];
   const DrawEntry* __restrict__ table = a.table;
   const uint32_t S = a.S, n_req = a.n_req, attempts0 = a.attempts0, out_base = a.out_base;
   uint32_t* const iter_samples = a.iter_samples; uint32_t* const iter_pos_after = a.iter_pos_after; ChainOut* const out = a.out;
-  uint32_t p = 0, done = 0, attempts = attempts0, flag = 0;
-  while (done < n_req) {
-    bool got = false;
-    while (true) {
-      if (p >= S) { flag = 1; break; }
-      const DrawEntry e = table[p];
-      if (e.status == DRAW_OVERFLOW) { flag = 1; break; }
-      p += e.consumed;
-      if (e.status == DRAW_OK) {
-        iter_samples[3 * (out_base + done) + 0] = e.s0;
-        iter_samples[3 * (out_base + done) + 1] = e.s1;
-        iter_samples[3 * (out_base + done) + 2] = e.s2;
-        iter_pos_after[out_base + done] = p;
-        got = true;
-        break;
+  const uint32_t n_lds = min(S, kChainLdsEntries);
+  uint32_t* s_start = s_hop + n_lds;                                            // n_req: table position of each drawn iteration
+  __shared__ uint32_t s_done;
+  for (uint32_t i = threadIdx.x; i < n_lds; i += 256u) s_hop[i] = (table[i].consumed << 2) | table[i].status;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t p = 0, done = 0, attempts = attempts0, flag = 0;
+    while (done < n_req) {
+      bool got = false;
+      while (true) {
+        if (p >= S) { flag = 1; break; }
+        const uint32_t hop = p < n_lds ? s_hop[p] : ((table[p].consumed << 2) | table[p].status);
+        const uint32_t status = hop & 3u;
+        if (status == DRAW_OVERFLOW) { flag = 1; break; }
+        const uint32_t at = p;
+        p += hop >> 2;
+        if (status == DRAW_OK) {
+          s_start[done] = at;
+          iter_pos_after[out_base + done] = p;
+          got = true;
+          break;
+        }
+        if (++attempts >= kMaxSampleChecks) { flag = 2; break; }   // getSamples gives up: samples.clear(), :167
       }
-      if (++attempts >= kMaxSampleChecks) { flag = 2; break; }   // getSamples gives up: samples.clear(), :167
+      if (!got) break;
+      attempts = 0;
+      ++done;
     }
-    if (!got) break;
-    attempts = 0;
-    ++done;
+    out->n_done = done; out->pos_end = p; out->attempts = attempts; out->flag = flag;
+    s_done = done;
   }
-  out->n_done = done; out->pos_end = p; out->attempts = attempts; out->flag = flag;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < s_done; i += 256u) {
+    const DrawEntry e = table[s_start[i]];
+    iter_samples[3 * (out_base + i) + 0] = e.s0;
+    iter_samples[3 * (out_base + i) + 1] = e.s1;
+    iter_samples[3 * (out_base + i) + 2] = e.s2;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ K8
@@ -1426,7 +1448,7 @@ struct VerifyPool { std::vector<VerifyWs*> slots; };
 constexpr uint32_t kEvalLdsSmall = 48u * 1024u;
 constexpr uint32_t kEvalLdsBig = 160u * 1024u - 512u;
 constexpr uint32_t kStackCap = 128u * 1024u;       // u16 entries per wave beyond the LDS part of the stack (256 KB)
-constexpr uint32_t kMaxEvalWaves = 1024u;          // hypotheses per evaluation batch
+constexpr uint32_t kMaxEvalWaves = 4096u;          // hypotheses per evaluation batch
 constexpr uint32_t kMailSmallWords = 128u;         // [0, 64) = the slot's device control words, [64] = n_all
 
 VerifyPool* pool_of(todhip_ctx* ctx) {
@@ -1455,6 +1477,8 @@ int set_big_lds_once(todhip_ctx* ctx) {
                                 (int)kEvalLdsBig));
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clique_test_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kEvalLdsBig));
     done.store(true, std::memory_order_release);
   }
   return TODHIP_OK;
@@ -1487,6 +1511,7 @@ struct RoundState {                                       // computeModel (ransa
   uint32_t nvalid = 0, total_iters = 0;
   uint32_t it_begin = 0, want = 0, got = 0, S = 0, window_len = 0;   // the evaluation batch being drawn
   uint32_t n_def = 0;
+  uint32_t s_floor = 0;                                   // grows x4 whenever a window ran out before the request was served
 };
 
 struct Slot {
@@ -1617,7 +1642,13 @@ struct Engine {
     }
     if (s.ph == PH_DRAW) {
       RoundState& r = s.r;
-      r.S = std::min<uint32_t>(4u * (r.want - r.got) + 256u, 1u << 20);
+      // window = stream positions the requested iterations are expected to consume: 4 per iteration for a start
+      // (3 draws + the odd failed attempt), then 1.5 x what this round's iterations consumed so far -- objects without
+      // a consistent subset burn hundreds of draws per iteration in failed attempts, and a window sized for 4 made
+      // them crawl through dozens of ticks
+      const uint64_t seen_it = (uint64_t)r.it_begin + r.got;
+      const uint64_t per_it = seen_it ? std::max<uint64_t>(4u, (3u * r.consumed / seen_it + 1u) / 2u + 1u) : 4u;
+      r.S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per_it * (r.want - r.got) + 512u, r.s_floor), 1u << 20);
       r.window_len = r.S + r.lookahead;
       while (r.stream.size() < r.consumed + r.window_len) r.stream.push_back(rng_next(r.gen));
       SLOT_HIP(ws->rnd.reserve((size_t)r.window_len * sizeof(uint32_t)));
@@ -1642,6 +1673,8 @@ struct Engine {
       A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>(); A.stacks = ws->stacks.as<uint16_t>();
       A.stack_cap = kStackCap; A.lds_bytes = second ? kEvalLdsBig : eval_lds_small(s.job.n); A.from_deferred = second ? 1u : 0u;
       A.n_deferred = second ? r.n_def : 0u;
+      SLOT_HIP(ws->stacks.reserve((size_t)std::max(r.it_drawn - r.it_begin, 64u) * kStackCap * sizeof(uint16_t)));
+      A.stacks = ws->stacks.as<uint16_t>();
       A.adjc_scratch = nullptr; A.dbg = nullptr; A.dbg_stride = 0; A.stop_level = 0;
       if (second) {                                         // graphs that need the whole LDS of a CU, or global scratch
         SLOT_HIP(ws->adjc_scratch.reserve((size_t)r.n_def * kAdjcScratchWords * sizeof(u64)));
@@ -1706,7 +1739,13 @@ struct Engine {
       ++r.iterations;
       if (r.iterations > (int)prm->n_ransac_iterations) { r.loop_done = true; r.pos_after_stop = hp[r.iterations - 1]; }
     }
-    r.batch = std::min<uint32_t>(r.batch * 4u, kMaxEvalWaves);
+    // next batch = what the loop still needs given the best model so far (k of :130): a hopeless object (k >> the
+    // iteration budget) gets all of its remaining iterations evaluated at once instead of in 16/64/256/1024 steps
+    {
+      const double need = r.k - (double)r.iterations;
+      const uint32_t want = need >= (double)kMaxEvalWaves ? kMaxEvalWaves : (uint32_t)std::max(1.0, std::ceil(need));
+      r.batch = std::max(std::min<uint32_t>(r.batch * 4u, kMaxEvalWaves), std::min(want, kMaxEvalWaves));
+    }
     if (!r.loop_done) { begin_batch(s); return; }
     // advance the caller's generator by exactly the draws the reference would have consumed
     for (uint64_t i = 0; i < r.pos_after_stop; ++i) (void)rng_next(*s.rng);
@@ -1773,7 +1812,6 @@ struct Engine {
       SLOT_HIP(ws->deferred.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
       SLOT_HIP(ws->m_counts.reserve((size_t)(r.total_iters + 1) * sizeof(int32_t)));
       SLOT_HIP(ws->m_pos.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
-      SLOT_HIP(ws->stacks.reserve((size_t)kMaxEvalWaves * kStackCap * sizeof(uint16_t)));
       begin_batch(s);
       return;
     }
@@ -1787,6 +1825,7 @@ struct Engine {
       r.consumed += co.pos_end;
       r.attempts_carry = co.attempts;
       if (co.flag == 2) r.selection_empty = true;
+      if (co.flag == 1) r.s_floor = std::min<uint32_t>(std::max(r.S, 1024u) * 4u, 1u << 20);   // e.g. 1000 failing attempts in a row
       if (co.flag == 1 && co.n_done == 0 && co.pos_end == 0) {
         // a single attempt longer than the window: enlarge the look-ahead, give up beyond 64M draws
         if (r.lookahead >= (1u << 26)) { fail(s, TODHIP_ESCRATCH); return; }
@@ -1881,7 +1920,12 @@ struct Engine {
     launch_list(st, adjacency_kernel, L.adj, 256, 0, 2, [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
     launch_list(st, round_prep_kernel, L.prep, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
     launch_list(st, draw_table_kernel, L.draw, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 3u) / 4u); });
-    launch_list(st, chain_kernel, L.chain, 64, 0, 0, [](const ChainArgs&) { return dim3(1); });
+    {
+      // dynamic LDS: the packed hop words of the largest window of the launch + the per-iteration start positions
+      uint32_t lds = 0;
+      for (const ChainArgs& c : L.chain) lds = std::max(lds, (std::min(c.S, kChainLdsEntries) + std::min(c.n_req, kChainMaxReq)) * 4u);
+      launch_list(st, chain_kernel, L.chain, 256, lds, 0, [](const ChainArgs&) { return dim3(1); });
+    }
     {
       // one dynamic LDS size per launch: the largest any slot of the launch wants; every slot carves that much
       uint32_t lds = 8192u;
