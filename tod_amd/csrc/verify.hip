@@ -1426,18 +1426,18 @@ __global__ __launch_bounds__(256) void cluster_group_kernel(Slots<GroupArgs> SL)
 
 // ------------------------------------------------------------------------------------------------ host side
 struct VerifyWs {
-  DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, rnd, table, iter_samples, counts, gate_m,
+  DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, nvalid, rnd, table, iter_samples, counts, gate_m,
       small, deferred, stacks, kp_bits, clique_adj, adjc_scratch, c_kept, c_offs, c_qpt, c_obj, c_hist, c_goff, f_train,
       f_query, f_qidx, f_kp;
   // the slot's mailbox: pinned host memory that kernels read and write directly (see copy_words_kernel)
-  HostBuf m_small, m_hist, m_goff, m_rnd, m_pos, m_counts, m_kp;
+  HostBuf m_small, m_hist, m_goff, m_rnd, m_pos, m_counts, m_kp, m_nvalid;
   HostBuf h_small;                                          // staging of the test hooks
   void release() {
-    DevBuf* bufs[] = {&train, &query, &qidx, &kpxy, &phys, &samp, &bits, &sampdeg, &rnd, &table, &iter_samples, &counts, &gate_m,
+    DevBuf* bufs[] = {&train, &query, &qidx, &kpxy, &phys, &samp, &bits, &sampdeg, &nvalid, &rnd, &table, &iter_samples, &counts, &gate_m,
                       &small, &deferred, &stacks, &kp_bits, &clique_adj, &adjc_scratch, &c_kept, &c_offs, &c_qpt, &c_obj, &c_hist,
                       &c_goff, &f_train, &f_query, &f_qidx, &f_kp};
     for (DevBuf* b : bufs) b->release();
-    HostBuf* hb[] = {&m_small, &m_hist, &m_goff, &m_rnd, &m_pos, &m_counts, &m_kp, &h_small};
+    HostBuf* hb[] = {&m_small, &m_hist, &m_goff, &m_rnd, &m_pos, &m_counts, &m_kp, &m_nvalid, &h_small};
     for (HostBuf* b : hb) b->release();
   }
 };
@@ -1484,7 +1484,12 @@ int set_big_lds_once(todhip_ctx* ctx) {
   return TODHIP_OK;
 }
 
-struct ObjSpan { uint32_t obj, offset, n; };
+struct ObjSpan {
+  uint32_t obj, offset, n;
+  // this object's slices of the slot's adjacency / bitset / degree buffers (all objects of a frame are prepared in
+  // one tick, so each needs its own), and its first round's |valid|
+  uint64_t adj_off = 0; uint32_t bits_off = 0, deg_off = 0, nvalid = 0;
+};
 struct DepthInput { const void* d_depth; int is_u16; float fx, fy, cx, cy; };
 
 // ---------------------------------------------------------------------------------------------- the batch engine
@@ -1494,7 +1499,8 @@ struct DepthInput { const void* d_depth; int is_u16; float fx, fy, cx, cy; };
 // advanced together: a TICK lets every live slot issue the kernels of its next phase into per-kernel lists, launches
 // each non-empty list once (all slots in one grid), synchronizes once, and lets every slot consume its results
 // (the ransac.h:95-135 bookkeeping is replayed on the host so that pow/log are libm's).
-enum Phase { PH_CLUSTER, PH_CLUSTER_WAIT, PH_GROUP, PH_OBJECT, PH_ROUND, PH_PREP_WAIT, PH_DRAW, PH_DRAW_WAIT, PH_EVAL,
+enum Phase { PH_CLUSTER, PH_CLUSTER_WAIT, PH_GROUP, PH_PREPALL, PH_PREPALL_WAIT, PH_OBJECT, PH_ROUND, PH_PREP_WAIT, PH_DRAW,
+             PH_DRAW_WAIT, PH_EVAL,
              PH_EVAL_WAIT, PH_EVAL2, PH_EVAL2_WAIT, PH_GROWTH, PH_GROWTH_WAIT, PH_DONE };
 
 struct RoundState {                                       // computeModel (ransac.h:80-143) in flight
@@ -1578,6 +1584,39 @@ struct Engine {
   void fail(Slot& s, int rc) { s.rc = rc; s.ph = PH_DONE; }
 #define SLOT_HIP(expr) do { if ((expr) != hipSuccess) { fail(s, TODHIP_EHIP); return; } } while (0)
 
+  static ObjJob make_job(const Slot& s, const ObjSpan& o) {
+    VerifyWs* ws = s.ws;
+    ObjJob job;
+    const uint32_t n = o.n, W = (n + 63u) / 64u;
+    job.n = n; job.W = W;
+    job.train = ws->train.as<float>() + 3 * (size_t)o.offset; job.query = ws->query.as<float>() + 3 * (size_t)o.offset;
+    job.qidx = ws->qidx.as<uint32_t>() + o.offset; job.kpxy = ws->kpxy.as<float>() + 2 * (size_t)o.offset;
+    job.phys = ws->phys.as<u64>() + o.adj_off; job.samp = ws->samp.as<u64>() + o.adj_off;
+    u64* bits = ws->bits.as<u64>() + o.bits_off;            // finite | valid | deg7 | inl | rest | extra | scratch
+    job.finite = bits; job.valid = bits + W; job.deg7 = bits + 2 * W;
+    job.sampdeg = ws->sampdeg.as<uint32_t>() + o.deg_off;
+    return job;
+  }
+  u64* obj_bits(const Slot& s) const { return s.ws->bits.as<u64>() + s.objs[s.oi].bits_off; }
+
+  // one AdjacencyRansac::Ransac call starts with |valid| known (adjacency_ransac.cpp:234-241)
+  void start_round(Slot& s, uint32_t nvalid) {
+    VerifyWs* ws = s.ws;
+    RoundState& r = s.r;
+    TOD_DBG("round: n=%u W=%u nvalid=%u", s.job.n, s.job.W, nvalid);
+    if (nvalid < 3) { round_done(s, false); return; }      // :238-241
+    r = RoundState();
+    r.nvalid = nvalid;
+    r.total_iters = prm->n_ransac_iterations + 1u;          // iterations_ runs 0 .. max_iterations (ransac.h:132-134)
+    r.gen = *s.rng;
+    SLOT_HIP(ws->iter_samples.reserve((size_t)(r.total_iters + 1) * 3 * sizeof(uint32_t)));
+    SLOT_HIP(ws->gate_m.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
+    SLOT_HIP(ws->deferred.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
+    SLOT_HIP(ws->m_counts.reserve((size_t)(r.total_iters + 1) * sizeof(int32_t)));
+    SLOT_HIP(ws->m_pos.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
+    begin_batch(s);
+  }
+
   // ---- issue: queue the kernels of the slot's next phase
   void issue(Slot& s) {
     VerifyWs* ws = s.ws;
@@ -1605,31 +1644,38 @@ struct Engine {
                       ws->f_qidx.as<uint32_t>(), ws->f_kp.as<float>(), ws->train.as<float>(), ws->query.as<float>(),
                       ws->qidx.as<uint32_t>(), ws->kpxy.as<float>()};
       L.group.push_back(ga);
-      s.ph = PH_OBJECT;
+      s.ph = PH_PREPALL;
     }
-    if (s.ph == PH_OBJECT) {
+    if (s.ph == PH_PREPALL) {
+      // FillAdjacency and the first round's validity/degree pass of EVERY object of the frame in this one tick: they
+      // do not depend on the rand() stream, and an object with < 3 valid matches then costs no tick at all
+      L.zero.push_back({nullptr, ws->nvalid.as<uint32_t>(), (uint32_t)std::max<size_t>(s.objs.size(), 1)});
+      for (size_t i = 0; i < s.objs.size(); ++i) {
+        if (s.objs[i].n < 3) continue;
+        const ObjJob job = make_job(s, s.objs[i]);
+        L.finite.push_back({job});
+        L.adj.push_back({job, spans[s.objs[i].obj], prm->sensor_error});
+        L.prep.push_back({job, ws->nvalid.as<uint32_t>() + i});
+      }
+      L.copy_out.push_back({ws->nvalid.as<uint32_t>(), ws->m_nvalid.as<uint32_t>(), (uint32_t)std::max<size_t>(s.objs.size(), 1)});
+      s.ph = PH_PREPALL_WAIT;
+      return;
+    }
+    while (s.ph == PH_OBJECT) {
       // Ransac returns no inliers for < 3 valid matches and draws nothing (:238-241)
       while (s.oi < s.objs.size() && s.objs[s.oi].n < 3) ++s.oi;
       if (s.oi >= s.objs.size()) { s.ph = PH_DONE; return; }
       const ObjSpan& o = s.objs[s.oi];
-      const uint32_t n = o.n, W = (n + 63u) / 64u;
-      ObjJob& job = s.job;
-      job.n = n; job.W = W;
-      job.train = ws->train.as<float>() + 3 * (size_t)o.offset; job.query = ws->query.as<float>() + 3 * (size_t)o.offset;
-      job.qidx = ws->qidx.as<uint32_t>() + o.offset; job.kpxy = ws->kpxy.as<float>() + 2 * (size_t)o.offset;
-      job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
-      u64* bits = ws->bits.as<u64>();                       // finite | valid | deg7 | inl | rest | extra | scratch
-      job.finite = bits; job.valid = bits + W; job.deg7 = bits + 2 * W;
-      job.sampdeg = ws->sampdeg.as<uint32_t>();
-      L.finite.push_back({job});
-      L.adj.push_back({job, spans[o.obj], prm->sensor_error});
+      s.job = make_job(s, o);
       ctx->counters.last_objects_verified += 1;
       s.pending_invalidate = false;
-      s.ph = PH_ROUND;
+      s.tr = todhip_round_trace();
+      s.tr.object = o.obj; s.tr.draws_before = s.rng->draws; s.tr.best_count = -INT_MAX;
+      start_round(s, o.nvalid);                             // -> PH_DRAW, or straight on to the next object
     }
     if (s.ph == PH_ROUND) {                                 // one AdjacencyRansac::Ransac call (GuessGenerator.cpp:192-231)
       if (s.pending_invalidate) {
-        L.inval.push_back({s.job, ws->kp_bits.as<u64>(), ws->bits.as<u64>() + 6 * s.job.W});
+        L.inval.push_back({s.job, ws->kp_bits.as<u64>(), obj_bits(s) + 6 * s.job.W});
         s.pending_invalidate = false;
       }
       L.zero.push_back({nullptr, d_small, 64u});
@@ -1691,7 +1737,7 @@ struct Engine {
     }
     if (s.ph == PH_GROWTH) {                                // growth (adjacency_ransac.cpp:255-308)
       const uint32_t kp_words = (nq + 63u) / 64u, W = s.job.W;
-      u64* d_bits = ws->bits.as<u64>();
+      u64* d_bits = obj_bits(s);
       GrowthArgs ga = {s.job, ws->iter_samples.as<uint32_t>() + 3 * (size_t)s.r.best_it, prm->sensor_error, d_bits + 3 * W,
                        d_bits + 4 * W, d_bits + 5 * W, ws->m_kp.as<uint32_t>(), ws->kp_bits.as<u64>(), kp_words,
                        reinterpret_cast<GrowthOut*>(d_small + 32)};
@@ -1799,20 +1845,14 @@ struct Engine {
       s.ph = PH_GROUP;
       return;
     }
-    if (s.ph == PH_PREP_WAIT) {
-      const uint32_t nvalid = m[0];
-      TOD_DBG("round: n=%u W=%u nvalid=%u", s.job.n, s.job.W, nvalid);
-      if (nvalid < 3) { round_done(s, false); return; }    // :238-241
-      r = RoundState();
-      r.nvalid = nvalid;
-      r.total_iters = prm->n_ransac_iterations + 1u;        // iterations_ runs 0 .. max_iterations (ransac.h:132-134)
-      r.gen = *s.rng;
-      SLOT_HIP(ws->iter_samples.reserve((size_t)(r.total_iters + 1) * 3 * sizeof(uint32_t)));
-      SLOT_HIP(ws->gate_m.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
-      SLOT_HIP(ws->deferred.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
-      SLOT_HIP(ws->m_counts.reserve((size_t)(r.total_iters + 1) * sizeof(int32_t)));
-      SLOT_HIP(ws->m_pos.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
-      begin_batch(s);
+    if (s.ph == PH_PREPALL_WAIT) {
+      const uint32_t* nv = ws->m_nvalid.as<uint32_t>();
+      for (size_t i = 0; i < s.objs.size(); ++i) s.objs[i].nvalid = nv[i];
+      s.ph = PH_OBJECT;
+      return;
+    }
+    if (s.ph == PH_PREP_WAIT) {                             // a further round of the same object, after an accepted pose
+      start_round(s, m[0]);
       return;
     }
     if (s.ph == PH_DRAW_WAIT) {
@@ -1864,13 +1904,19 @@ struct Engine {
   bool reserve_objects(Slot& s, uint32_t max_n) {
     VerifyWs* ws = s.ws;
     if (max_n > (uint32_t)kMaxWords * 64u) { fail(s, TODHIP_ESCRATCH); return false; }
-    if (max_n >= 3) {
-      const uint32_t Wm = (max_n + 63u) / 64u;
-      if (ws->phys.reserve((size_t)max_n * Wm * 8) != hipSuccess || ws->samp.reserve((size_t)max_n * Wm * 8) != hipSuccess ||
-          ws->bits.reserve((size_t)8 * Wm * 8) != hipSuccess || ws->sampdeg.reserve((size_t)max_n * 4) != hipSuccess) {
-        fail(s, TODHIP_EHIP);
-        return false;
-      }
+    uint64_t adj = 0, bits = 0, deg = 0;
+    for (ObjSpan& o : s.objs) {
+      if (o.n < 3) continue;
+      const uint64_t W = (o.n + 63u) / 64u;
+      o.adj_off = adj; o.bits_off = (uint32_t)bits; o.deg_off = (uint32_t)deg;
+      adj += (uint64_t)o.n * W; bits += 8u * W; deg += o.n;
+    }
+    const size_t n_objs_here = std::max<size_t>(s.objs.size(), 1);
+    if (ws->phys.reserve((size_t)std::max<uint64_t>(adj, 1) * 8) != hipSuccess || ws->samp.reserve((size_t)std::max<uint64_t>(adj, 1) * 8) != hipSuccess ||
+        ws->bits.reserve((size_t)std::max<uint64_t>(bits, 8) * 8) != hipSuccess || ws->sampdeg.reserve((size_t)std::max<uint64_t>(deg, 1) * 4) != hipSuccess ||
+        ws->nvalid.reserve(n_objs_here * 4) != hipSuccess || ws->m_nvalid.reserve(n_objs_here * 4) != hipSuccess) {
+      fail(s, TODHIP_EHIP);
+      return false;
     }
     return true;
   }
@@ -2078,7 +2124,7 @@ int todhip_verify(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float*
   rc = E.reserve_common(s);
   if (rc != TODHIP_OK) return rc;
   if (!E.reserve_objects(s, max_n)) return s.rc;
-  s.ph = PH_OBJECT;
+  s.ph = PH_PREPALL;
   std::vector<Slot*> live = {&s};
   rc = E.run(live);
   const int rc2 = collect(ctx, slots, poses, pose_cap, n_poses, nullptr, inlier_kp, kp_cap, n_inlier_kp);
