@@ -23,6 +23,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "ctx.h"
@@ -183,6 +184,67 @@ __global__ __launch_bounds__(256) void draw_table_kernel(Slots<DrawArgs> SL) {
     e.status = status; e.consumed = pos - s; e.s0 = s0; e.s1 = s1; e.s2 = s2; e.pad = 0;
     table[s] = e;
   }
+}
+
+// K7a for objects of at most 128 matches (W <= 2): ONE LANE per stream position instead of one wave -- the bitsets fit
+// two 64-bit registers, so a lane runs the helper's three levels on its own. Distractor objects (a few dozen random
+// matches, hopeless, burning their whole iteration budget and hundreds of failed attempts) are what makes the table
+// large, and they are small: 64 x fewer waves for the same table.
+__device__ __forceinline__ uint32_t nth_set_bit128(u64 w0, u64 w1, uint32_t n) {   // n-th set bit (ascending), n < popc
+  const uint32_t c0 = (uint32_t)__popcll(w0);
+  u64 w = w0; uint32_t base = 0;
+  if (n >= c0) { n -= c0; w = w1; base = 64u; }
+  uint32_t pos = 0;
+#pragma unroll
+  for (uint32_t shift = 32; shift > 0; shift >>= 1) {
+    const uint32_t cnt = (uint32_t)__popcll((w >> pos) & ((1ull << shift) - 1ull));
+    if (n >= cnt) { n -= cnt; pos += shift; }
+  }
+  return base + pos;
+}
+__global__ __launch_bounds__(256) void draw_table_small_kernel(Slots<DrawArgs> SL) {
+  TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const ObjJob& job = SL.a[blockIdx.y].job;
+  const uint32_t* __restrict__ rnd = SL.a[blockIdx.y].rnd;
+  const uint32_t window_len = SL.a[blockIdx.y].window_len, S = SL.a[blockIdx.y].S;
+  DrawEntry* const table = SL.a[blockIdx.y].table;
+  const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+  if (s >= S) return;
+  const uint32_t W = job.W;                                // 1 or 2
+  u64 a0 = job.valid[0], a1 = W > 1u ? job.valid[1] : 0ull;
+  uint32_t nA = (uint32_t)(__popcll(a0) + __popcll(a1));
+  uint32_t pos = s, status = DRAW_FAIL, s0 = 0, s1 = 0, s2 = 0;
+  while (nA > 0) {                                          // level "3 samples left"
+    if (pos >= window_len) { status = DRAW_OVERFLOW; break; }
+    const uint32_t a = nth_set_bit128(a0, a1, rnd[pos++] % nA);   // valid_samples[rand() % size], :111
+    if (a >= job.n) break;                                  // cannot happen; keeps every address in bounds
+    u64 b0 = a0 & job.samp[(size_t)a * W], b1 = W > 1u ? (a1 & job.samp[(size_t)a * W + 1]) : 0ull;   // :113-117
+    uint32_t nB = (uint32_t)(__popcll(b0) + __popcll(b1));
+    bool ok = false;
+    uint32_t b = 0, c = 0;
+    while (nB > 0) {                                        // level "2 samples left"
+      if (pos >= window_len) { status = DRAW_OVERFLOW; break; }
+      b = nth_set_bit128(b0, b1, rnd[pos++] % nB);
+      if (b >= job.n) { nB = 0; break; }
+      const u64 c0 = b0 & job.samp[(size_t)b * W], c1 = W > 1u ? (b1 & job.samp[(size_t)b * W + 1]) : 0ull;
+      const uint32_t nC = (uint32_t)(__popcll(c0) + __popcll(c1));
+      if (nC > 0) {                                         // level "1 sample left": any pick succeeds
+        if (pos >= window_len) { status = DRAW_OVERFLOW; break; }
+        c = nth_set_bit128(c0, c1, rnd[pos++] % nC);
+        ok = true;
+        break;
+      }
+      if (b < 64u) b0 &= ~(1ull << b); else b1 &= ~(1ull << (b - 64u));   // std::remove of the failed pick, :125-128
+      --nB;
+    }
+    if (status == DRAW_OVERFLOW) break;
+    if (ok) { status = DRAW_OK; s0 = c; s1 = b; s2 = a; break; }   // samples_ is deepest-first, :118-121
+    if (a < 64u) a0 &= ~(1ull << a); else a1 &= ~(1ull << (a - 64u));
+    --nA;
+  }
+  DrawEntry e;
+  e.status = status; e.consumed = pos - s; e.s0 = s0; e.s1 = s1; e.s2 = s2; e.pad = 0;
+  table[s] = e;
 }
 
 // ------------------------------------------------------------------------------------------------ K7b
@@ -1465,10 +1527,36 @@ VerifyWs* ws_of(todhip_ctx* ctx, size_t slot = 0) {
 inline uint32_t rng_next(todhip_rng& r) {
   r.s[r.f] += r.s[r.b];
   const uint32_t out = r.s[r.f] >> 1;
-  r.f = (r.f + 1) % 31; r.b = (r.b + 1) % 31;
+  r.f = r.f == 30u ? 0u : r.f + 1u; r.b = r.b == 30u ? 0u : r.b + 1u;
   ++r.draws;
   return out;
 }
+
+// The rand() stream of a frame, generated once and shared: every round of every object reads a window of it, and
+// frames that start from the same generator state (a harness restarting rand() per frame, decision D4) share one
+// copy. Snapshots of the generator every kSnap draws give the state at any position without replaying the stream.
+struct StreamCache {
+  static constexpr uint64_t kSnap = 4096;
+  todhip_rng init, gen;
+  std::vector<uint32_t> vals;                              // vals[i] = i-th draw after `init`
+  std::vector<todhip_rng> snaps;                           // snaps[j] = generator state before draw j * kSnap
+  explicit StreamCache(const todhip_rng& r) : init(r), gen(r) {}
+  bool same_start(const todhip_rng& r) const {
+    return r.f == init.f && r.b == init.b && std::memcmp(r.s, init.s, sizeof(init.s)) == 0;
+  }
+  void extend_to(uint64_t n) {
+    while (vals.size() < n) {
+      if (vals.size() % kSnap == 0) snaps.push_back(gen);
+      vals.push_back(rng_next(gen));
+    }
+  }
+  todhip_rng state_at(uint64_t pos) {                      // generator after `pos` draws (draw counter relative to init)
+    extend_to(pos + 1);
+    todhip_rng g = snaps[pos / kSnap];
+    for (uint64_t i = (pos / kSnap) * kSnap; i < pos; ++i) (void)rng_next(g);
+    return g;
+  }
+};
 
 int set_big_lds_once(todhip_ctx* ctx) {
   static std::atomic<bool> done{false};                   // contexts may be driven from several host threads
@@ -1504,9 +1592,7 @@ enum Phase { PH_CLUSTER, PH_CLUSTER_WAIT, PH_GROUP, PH_PREPALL, PH_PREPALL_WAIT,
              PH_EVAL_WAIT, PH_EVAL2, PH_EVAL2_WAIT, PH_GROWTH, PH_GROWTH_WAIT, PH_DONE };
 
 struct RoundState {                                       // computeModel (ransac.h:80-143) in flight
-  todhip_rng gen;                                         // generator that fills stream windows
-  std::vector<uint32_t> stream;                           // stream[i] = i-th draw after the caller's generator
-  uint64_t consumed = 0;                                  // draws used by completed getSamples calls
+  uint64_t consumed = 0;                                  // draws used by completed getSamples calls of this round
   uint32_t it_drawn = 0, attempts_carry = 0;
   bool selection_empty = false, loop_done = false;
   int iterations = 0, n_best = -INT_MAX;
@@ -1525,7 +1611,9 @@ struct Slot {
   // inputs (device-resident form)
   const float* d_kp_xy = nullptr; const float* d_cloud = nullptr; DepthInput dep = {}; bool use_depth = false;
   const uint32_t* d_counts = nullptr; const todhip_dmatch* d_matches = nullptr; const float* d_mxyz = nullptr;
-  todhip_rng* rng = nullptr;
+  todhip_rng* rng = nullptr;                              // caller's generator: set to the final state when the slot is done
+  StreamCache* stream = nullptr;                          // shared with the slots that start from the same state
+  uint64_t start_draws = 0, abs_pos = 0;                  // rng->draws at entry; draws consumed by the completed rounds
   // results
   std::vector<todhip_pose> poses;
   std::vector<uint32_t> inliers;
@@ -1546,7 +1634,7 @@ struct Launches {
   std::vector<CopyArgs> copy_in, zero, copy_out;
   std::vector<LookupArgs> lookup; std::vector<ScanArgs> scan; std::vector<ScatterArgs> scatter; std::vector<GroupArgs> group;
   std::vector<InvArgs> inval; std::vector<JobArgs> finite; std::vector<AdjArgs> adj; std::vector<PrepArgs> prep;
-  std::vector<DrawArgs> draw; std::vector<ChainArgs> chain; std::vector<EvalArgs> eval_small, eval_big;
+  std::vector<DrawArgs> draw, draw_small; std::vector<ChainArgs> chain; std::vector<EvalArgs> eval_small, eval_big;
   std::vector<GrowthArgs> growth;
 };
 
@@ -1608,7 +1696,6 @@ struct Engine {
     r = RoundState();
     r.nvalid = nvalid;
     r.total_iters = prm->n_ransac_iterations + 1u;          // iterations_ runs 0 .. max_iterations (ransac.h:132-134)
-    r.gen = *s.rng;
     SLOT_HIP(ws->iter_samples.reserve((size_t)(r.total_iters + 1) * 3 * sizeof(uint32_t)));
     SLOT_HIP(ws->gate_m.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
     SLOT_HIP(ws->deferred.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
@@ -1670,7 +1757,7 @@ struct Engine {
       ctx->counters.last_objects_verified += 1;
       s.pending_invalidate = false;
       s.tr = todhip_round_trace();
-      s.tr.object = o.obj; s.tr.draws_before = s.rng->draws; s.tr.best_count = -INT_MAX;
+      s.tr.object = o.obj; s.tr.draws_before = s.start_draws + s.abs_pos; s.tr.best_count = -INT_MAX;
       start_round(s, o.nvalid);                             // -> PH_DRAW, or straight on to the next object
     }
     if (s.ph == PH_ROUND) {                                 // one AdjacencyRansac::Ransac call (GuessGenerator.cpp:192-231)
@@ -1682,7 +1769,7 @@ struct Engine {
       L.prep.push_back({s.job, d_small});
       export_small(s);
       s.tr = todhip_round_trace();
-      s.tr.object = s.objs[s.oi].obj; s.tr.draws_before = s.rng->draws; s.tr.best_count = -INT_MAX;
+      s.tr.object = s.objs[s.oi].obj; s.tr.draws_before = s.start_draws + s.abs_pos; s.tr.best_count = -INT_MAX;
       s.ph = PH_PREP_WAIT;
       return;
     }
@@ -1696,13 +1783,13 @@ struct Engine {
       const uint64_t per_it = seen_it ? std::max<uint64_t>(4u, (3u * r.consumed / seen_it + 1u) / 2u + 1u) : 4u;
       r.S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per_it * (r.want - r.got) + 512u, r.s_floor), 1u << 20);
       r.window_len = r.S + r.lookahead;
-      while (r.stream.size() < r.consumed + r.window_len) r.stream.push_back(rng_next(r.gen));
+      s.stream->extend_to(s.abs_pos + r.consumed + r.window_len);
       SLOT_HIP(ws->rnd.reserve((size_t)r.window_len * sizeof(uint32_t)));
       SLOT_HIP(ws->m_rnd.reserve((size_t)r.window_len * sizeof(uint32_t)));
       SLOT_HIP(ws->table.reserve((size_t)r.S * sizeof(DrawEntry)));
-      std::memcpy(ws->m_rnd.p, r.stream.data() + r.consumed, (size_t)r.window_len * sizeof(uint32_t));
+      std::memcpy(ws->m_rnd.p, s.stream->vals.data() + s.abs_pos + r.consumed, (size_t)r.window_len * sizeof(uint32_t));
       L.copy_in.push_back({ws->m_rnd.as<uint32_t>(), ws->rnd.as<uint32_t>(), r.window_len});
-      L.draw.push_back({s.job, ws->rnd.as<uint32_t>(), r.window_len, r.S, ws->table.as<DrawEntry>()});
+      (s.job.W <= 2u ? L.draw_small : L.draw).push_back({s.job, ws->rnd.as<uint32_t>(), r.window_len, r.S, ws->table.as<DrawEntry>()});
       ChainArgs ca = {ws->table.as<DrawEntry>(), r.S, r.want - r.got, r.attempts_carry, r.it_begin + r.got,
                       ws->iter_samples.as<uint32_t>(), ws->m_pos.as<uint32_t>(), reinterpret_cast<ChainOut*>(d_small + 1)};
       L.chain.push_back(ca);
@@ -1794,7 +1881,7 @@ struct Engine {
     }
     if (!r.loop_done) { begin_batch(s); return; }
     // advance the caller's generator by exactly the draws the reference would have consumed
-    for (uint64_t i = 0; i < r.pos_after_stop; ++i) (void)rng_next(*s.rng);
+    s.abs_pos += r.pos_after_stop;
     s.tr.iterations = (uint32_t)r.iterations; s.tr.best_iteration = r.best_it; s.tr.best_count = r.n_best;
     if (r.n_best <= 0) { round_done(s, false); return; }   // inliers_.empty(): computeModel() == false (:137-138)
     s.ph = PH_GROWTH;
@@ -1803,7 +1890,7 @@ struct Engine {
     const GrowthOut* go = reinterpret_cast<const GrowthOut*>(mail(s) + 32);
     const uint32_t n_kp = have_pose ? go->n_kp_inliers : 0u;
     ctx->counters.last_rounds += 1;
-    s.tr.draws_after = s.rng->draws; s.tr.n_inlier_kp = n_kp; s.tr.accepted = n_kp >= prm->min_inliers;
+    s.tr.draws_after = s.start_draws + s.abs_pos; s.tr.n_inlier_kp = n_kp; s.tr.accepted = n_kp >= prm->min_inliers;
     s.traces.push_back(s.tr);
     if (n_kp < prm->min_inliers) { ++s.oi; s.ph = PH_OBJECT; return; }   // GuessGenerator.cpp:205-206
     todhip_pose p;
@@ -1966,6 +2053,7 @@ struct Engine {
     launch_list(st, adjacency_kernel, L.adj, 256, 0, 2, [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
     launch_list(st, round_prep_kernel, L.prep, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
     launch_list(st, draw_table_kernel, L.draw, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 3u) / 4u); });
+    launch_list(st, draw_table_small_kernel, L.draw_small, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 255u) / 256u); });
     {
       // dynamic LDS: the packed hop words of the largest window of the launch + the per-iteration start positions
       uint32_t lds = 0;
@@ -1987,6 +2075,20 @@ struct Engine {
 
   // slots: live frames (phase set by the caller). Returns the first slot error, if any.
   int run(std::vector<Slot*>& slots) {
+    std::vector<std::unique_ptr<StreamCache>> caches;
+    for (Slot* s : slots) {
+      s->start_draws = s->rng->draws; s->abs_pos = 0;
+      for (auto& c : caches) if (c->same_start(*s->rng)) { s->stream = c.get(); break; }
+      if (!s->stream) { caches.emplace_back(new StreamCache(*s->rng)); s->stream = caches.back().get(); }
+    }
+    const int rc_run = run_ticks(slots);
+    for (Slot* s : slots) {                                 // the caller's generator ends where the reference's would
+      if (s->abs_pos) { const uint64_t d0 = s->start_draws; *s->rng = s->stream->state_at(s->abs_pos); s->rng->draws = d0 + s->abs_pos; }
+      s->stream = nullptr;
+    }
+    return rc_run;
+  }
+  int run_ticks(std::vector<Slot*>& slots) {
     while (true) {
       bool any = false;
       for (Slot* s : slots)
