@@ -1505,7 +1505,8 @@ struct VerifyWs {
 };
 
 // one workspace per frame slot of a batch; slot 0 also serves the single-frame entry points and the test hooks
-struct VerifyPool { std::vector<VerifyWs*> slots; };
+struct StreamCache;
+struct VerifyPool { std::vector<VerifyWs*> slots; std::vector<StreamCache*> streams; };
 
 constexpr uint32_t kEvalLdsSmall = 48u * 1024u;
 constexpr uint32_t kEvalLdsBig = 160u * 1024u - 512u;
@@ -1549,6 +1550,26 @@ struct StreamCache {
       if (vals.size() % kSnap == 0) snaps.push_back(gen);
       vals.push_back(rng_next(gen));
     }
+  }
+  // device copy of the stream (append-only): a round's window is an offset into it, nothing is copied per tick
+  DevBuf dev;
+  uint64_t dev_valid = 0;
+  hipError_t ensure_device(uint64_t n, hipStream_t st) {
+    extend_to(n);
+    if (n <= dev_valid) return hipSuccess;
+    const uint64_t want = std::max<uint64_t>(n, 2 * dev_valid);
+    extend_to(want);
+    if (dev.cap < want * sizeof(uint32_t)) {                // grow: DevBuf::reserve drops the old contents, upload all again
+      hipError_t e = hipStreamSynchronize(st);              // kernels of earlier ticks may still read the old buffer
+      if (e != hipSuccess) return e;
+      e = dev.reserve((size_t)want * 2 * sizeof(uint32_t));
+      if (e != hipSuccess) return e;
+      dev_valid = 0;
+    }
+    hipError_t e = hipMemcpyAsync(dev.as<uint32_t>() + dev_valid, vals.data() + dev_valid, (size_t)(want - dev_valid) * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) dev_valid = want;
+    return e;
   }
   todhip_rng state_at(uint64_t pos) {                      // generator after `pos` draws (draw counter relative to init)
     extend_to(pos + 1);
@@ -1634,7 +1655,10 @@ struct Launches {
   std::vector<CopyArgs> copy_in, zero, copy_out;
   std::vector<LookupArgs> lookup; std::vector<ScanArgs> scan; std::vector<ScatterArgs> scatter; std::vector<GroupArgs> group;
   std::vector<InvArgs> inval; std::vector<JobArgs> finite; std::vector<AdjArgs> adj; std::vector<PrepArgs> prep;
-  std::vector<DrawArgs> draw, draw_small; std::vector<ChainArgs> chain; std::vector<EvalArgs> eval_small, eval_big;
+  std::vector<DrawArgs> draw, draw_small; std::vector<ChainArgs> chain;
+  // the rnd pointers of the draw lists are resolved at launch time: a later slot of the same tick may grow (move)
+  // the shared stream buffer
+  std::vector<std::pair<StreamCache*, uint64_t>> draw_src, draw_small_src; std::vector<EvalArgs> eval_small, eval_big;
   std::vector<GrowthArgs> growth;
 };
 
@@ -1783,13 +1807,10 @@ struct Engine {
       const uint64_t per_it = seen_it ? std::max<uint64_t>(4u, (3u * r.consumed / seen_it + 1u) / 2u + 1u) : 4u;
       r.S = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per_it * (r.want - r.got) + 512u, r.s_floor), 1u << 20);
       r.window_len = r.S + r.lookahead;
-      s.stream->extend_to(s.abs_pos + r.consumed + r.window_len);
-      SLOT_HIP(ws->rnd.reserve((size_t)r.window_len * sizeof(uint32_t)));
-      SLOT_HIP(ws->m_rnd.reserve((size_t)r.window_len * sizeof(uint32_t)));
+      SLOT_HIP(s.stream->ensure_device(s.abs_pos + r.consumed + r.window_len, st));
       SLOT_HIP(ws->table.reserve((size_t)r.S * sizeof(DrawEntry)));
-      std::memcpy(ws->m_rnd.p, s.stream->vals.data() + s.abs_pos + r.consumed, (size_t)r.window_len * sizeof(uint32_t));
-      L.copy_in.push_back({ws->m_rnd.as<uint32_t>(), ws->rnd.as<uint32_t>(), r.window_len});
-      (s.job.W <= 2u ? L.draw_small : L.draw).push_back({s.job, ws->rnd.as<uint32_t>(), r.window_len, r.S, ws->table.as<DrawEntry>()});
+      (s.job.W <= 2u ? L.draw_small : L.draw).push_back({s.job, nullptr, r.window_len, r.S, ws->table.as<DrawEntry>()});
+      (s.job.W <= 2u ? L.draw_small_src : L.draw_src).push_back({s.stream, s.abs_pos + r.consumed});
       ChainArgs ca = {ws->table.as<DrawEntry>(), r.S, r.want - r.got, r.attempts_carry, r.it_begin + r.got,
                       ws->iter_samples.as<uint32_t>(), ws->m_pos.as<uint32_t>(), reinterpret_cast<ChainOut*>(d_small + 1)};
       L.chain.push_back(ca);
@@ -2052,6 +2073,9 @@ struct Engine {
     launch_list(st, finite_kernel, L.finite, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
     launch_list(st, adjacency_kernel, L.adj, 256, 0, 2, [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
     launch_list(st, round_prep_kernel, L.prep, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+    for (size_t i = 0; i < L.draw.size(); ++i) L.draw[i].rnd = L.draw_src[i].first->dev.as<uint32_t>() + L.draw_src[i].second;
+    for (size_t i = 0; i < L.draw_small.size(); ++i)
+      L.draw_small[i].rnd = L.draw_small_src[i].first->dev.as<uint32_t>() + L.draw_small_src[i].second;
     launch_list(st, draw_table_kernel, L.draw, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 3u) / 4u); });
     launch_list(st, draw_table_small_kernel, L.draw_small, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 255u) / 256u); });
     {
@@ -2075,11 +2099,21 @@ struct Engine {
 
   // slots: live frames (phase set by the caller). Returns the first slot error, if any.
   int run(std::vector<Slot*>& slots) {
-    std::vector<std::unique_ptr<StreamCache>> caches;
+    // stream caches live in the context (a harness that restarts rand() per frame reuses one stream for ever); a
+    // few of the most recent start states are kept
+    std::vector<StreamCache*>& caches = pool_of(ctx)->streams;
     for (Slot* s : slots) {
-      s->start_draws = s->rng->draws; s->abs_pos = 0;
-      for (auto& c : caches) if (c->same_start(*s->rng)) { s->stream = c.get(); break; }
-      if (!s->stream) { caches.emplace_back(new StreamCache(*s->rng)); s->stream = caches.back().get(); }
+      s->start_draws = s->rng->draws; s->abs_pos = 0; s->stream = nullptr;
+      for (StreamCache* c : caches) if (c->same_start(*s->rng)) { s->stream = c; break; }
+      if (!s->stream) {
+        if (caches.size() >= 64) {                          // none of the live slots can be using the oldest ones
+          bool in_use = false;
+          for (Slot* t : slots) in_use = in_use || t->stream == caches.front();
+          if (!in_use) { TOD_HIP(hipStreamSynchronize(st)); caches.front()->dev.release(); delete caches.front(); caches.erase(caches.begin()); }
+        }
+        caches.push_back(new StreamCache(*s->rng));
+        s->stream = caches.back();
+      }
     }
     const int rc_run = run_ticks(slots);
     for (Slot* s : slots) {                                 // the caller's generator ends where the reference's would
@@ -2113,6 +2147,7 @@ void tod_verify_ws_free(todhip_ctx* ctx) {
   if (!ctx->verify_ws) return;
   VerifyPool* p = reinterpret_cast<VerifyPool*>(ctx->verify_ws);
   for (VerifyWs* ws : p->slots) { ws->release(); delete ws; }
+  for (StreamCache* c : p->streams) { c->dev.release(); delete c; }
   delete p;
   ctx->verify_ws = nullptr;
 }
