@@ -497,8 +497,11 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, size_t gray_fs, const uin
   uint32_t* d_totals = d_small + (size_t)F * kCtlWords;
   TOD_HIP(hipMemsetAsync(d_small, 0, (size_t)(F + 1) * kCtlWords * sizeof(uint32_t), st));
   const uint32_t px_blocks = (uint32_t)((px + 255) / 256);
-  hipLaunchKernelGGL(copy_rows_kernel, dim3(px_blocks, F), dim3(256), 0, st, d_gray, stride, ws->img[0].as<uint8_t>(), H, W,
-                     gray_fs, px);
+  if (stride == W && (F == 1 || gray_fs == px))            // densely packed input: one device-to-device copy
+    TOD_HIP(hipMemcpyAsync(ws->img[0].p, d_gray, (size_t)F * px, hipMemcpyDeviceToDevice, st));
+  else
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(px_blocks, F), dim3(256), 0, st, d_gray, stride, ws->img[0].as<uint8_t>(), H, W,
+                       gray_fs, px);
   if (d_mask) {
     hipLaunchKernelGGL(copy_rows_kernel, dim3(px_blocks, F), dim3(256), 0, st, d_mask, W, ws->maskbuf.as<uint8_t>(), H, W, px, px);
     d_mask = ws->maskbuf.as<uint8_t>();
