@@ -290,6 +290,17 @@ def main():
     dt = time.perf_counter() - t0
     dt_local = dt
     c1 = [c.counters() for c in mctx]
+    # outside the timed region, single device only: the same launch with the radius cut switched off (radius 256) --
+    # what the DB pass costs when no lower bound can prune (correlated descriptors); reported beside the roofline
+    dense_ms = None
+    if world == 1:
+        o = outs[0]
+        d0 = ctx.counters()
+        for _ in range(3):
+            ctx.match_device(Q_B[0].data_ptr(), B * nq, k, 256, o["counts"].data_ptr(), o["matches"].data_ptr(), o["xyz"].data_ptr())
+        torch.cuda.synchronize()
+        d1 = ctx.counters()
+        dense_ms = (d1.sum_match_kernel_ms - d0.sum_match_kernel_ms) / max(d1.n_match_kernel_launches - d0.n_match_kernel_launches, 1)
     for c in mctx:
         c.set_kernel_timing(False)
 
@@ -355,6 +366,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,
                          "binding_roof": "integer VALU (see valu_roofline)", "valu_frac": valu_frac,
+                         "dense_launch_ms": dense_ms,
+                         "dense_launch_note": "same launch without the radius bound (no partial-distance elimination possible), "
+                                              "measured after the timed region, alone",
                          "queries_per_launch": world * B * nq,
                          "concurrent_matcher_contexts": len(mctx),
                          "note": "at %d queries per DB pass this kernel is bound by integer VALU issue, not HBM "
