@@ -464,3 +464,22 @@ def test_batch_larger_than_one_launch_group(ctx):
         assert rngs[f].draws == want[f][1] and len(got[f]) == len(want[f][0])
         for a, b in zip(got[f], want[f][0]):
             assert a["object"] == b["object"] and np.array_equal(a["inliers"], b["inliers"]) and np.array_equal(a["R"], b["R"])
+
+
+@pytest.mark.parametrize("n_obj", [40, 200])
+def test_many_small_distractor_objects(ctx, n_obj):
+    """One true object among many that only collect random matches (15-75 each): every distractor burns its iteration
+    budget or walks 1000 failing sample attempts. Exercises the lane-per-position draw table (objects of <= 128
+    matches), windows that grow past the LDS part of the chain walk, evaluation batches of thousands of hypotheses and
+    the all-objects preparation tick. Must equal the oracle draw for draw."""
+    sc = synth.make_verify_scene(600, n_objects=n_obj, visible=((1, 0.30),), matches_per_kp=5, seed=77)
+    rng_g, rng_o = capi.rng_new(1), O.rng_new(1)
+    poses = ctx.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 2500, 0.01, rng_g)
+    tr = [(r.object, r.iterations, r.best_iteration, r.best_count, r.draws_after) for r in ctx.verify_trace()]
+    rc, o_poses, o_tr = O.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 2500,
+                                 0.01, rng_o)
+    assert rc == 0 and rng_g.draws == rng_o.draws and list(rng_g.s) == list(rng_o.s) and rng_g.draws > 500000
+    assert len(poses) == len(o_poses) == 1 and poses[0]["object"] == o_poses[0]["object"] == 1
+    assert np.array_equal(poses[0]["inliers"], o_poses[0]["inliers"])
+    assert np.abs(poses[0]["R"] - o_poses[0]["R"]).max() < POSE_TOL and np.abs(poses[0]["t"] - o_poses[0]["t"]).max() < POSE_TOL
+    assert len(tr) >= n_obj // 2
