@@ -194,11 +194,22 @@ int todhip_orb_batch_device(todhip_ctx*, const void* d_gray, uint32_t n_frames, 
 typedef struct todhip_model todhip_model;
 int  todhip_model_begin(todhip_ctx*, uint32_t capacity_rows, todhip_model** out);
 /* gray/mask: H x W u8 (mask != 0 = object); depth: H x W float metres (NaN = none) or uint16 millimetres (0 = none),
- * same size as the image (rescale_depth's equal-size branch, Trainer.cpp:63-72); K9, R9 row-major; T3. */
+ * of the image size (other sizes: todhip_rescale_depth first, as Trainer.cpp:142-143 does); K9, R9 row-major; T3. */
 int  todhip_model_add_observation(todhip_ctx*, todhip_model*, const uint8_t* gray, const uint8_t* mask, const void* depth,
                                   int depth_is_u16, uint32_t H, uint32_t W, const float* K9, const float* R9, const float* T3,
                                   uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern,
                                   uint32_t* n_added);
+/* rescale_depth (Trainer.cpp:62-81; on the detection side ecto_opencv's RescaledRegisteredDepth cell, detector.py:26,62):
+ * depth_in dH x dW, float metres or uint16 millimetres -> depth_out H x W float metres (NaN = none). Equal sizes: the
+ * unit conversion only (:68-71). Otherwise a resize into the top int(dH * (W / dW)) rows, NaN below (:73-80):
+ * nearest == 0 is what the reference executes -- its cv::resize call passes CV_INTER_NN in the `fx` position (:78), so
+ * cv::resize's default bilinear interpolation runs; nearest != 0 is the nearest-neighbour resize its comment intends.
+ * TODHIP_EINVAL where the reference's rowRange/resize would throw (that row count is 0 or exceeds H). The output feeds
+ * todhip_model_add_observation / todhip_verify_device_depth (depth_is_u16 = 0). */
+int  todhip_rescale_depth(todhip_ctx*, const void* depth_in, int depth_is_u16, uint32_t dH, uint32_t dW, float* depth_out,
+                          uint32_t H, uint32_t W, int nearest);
+int  todhip_rescale_depth_device(todhip_ctx*, const void* d_depth_in, int depth_is_u16, uint32_t dH, uint32_t dW,
+                                 void* d_depth_out, uint32_t H, uint32_t W, int nearest);
 /* *n: capacity in rows in, rows out. desc: rows x 32, pts_xyz: rows x 3 (object/world frame). */
 int  todhip_model_finish(todhip_ctx*, todhip_model*, uint8_t* desc, float* pts_xyz, uint32_t* n);
 void todhip_model_free(todhip_ctx*, todhip_model*);

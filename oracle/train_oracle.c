@@ -3,7 +3,7 @@
  *
  * CPU restatement of the per-observation arithmetic of the reference's training cell
  * (src/training/Trainer.cpp:121-187 and src/training/training.cpp:57-195), SURVEY 8(f) row N2:
- *   rescale_depth        Trainer.cpp:63-81   (same-size case: cv::rescaleDepth to float metres, uint16 0 -> NaN)
+ *   rescale_depth        Trainer.cpp:63-81   (cv::rescaleDepth to float metres, uint16 0 -> NaN; resize when sizes differ)
  *   validateKeyPoints    training.cpp:57-145 (mask eroded 4x with the 3x3 element == 9x9 minimum inside the image;
  *                                             nearest masked pixel in a +-2 window; depth validity)
  *   depthTo3dSparse      Trainer.cpp:168     (third-party cv::depthTo3dSparse: x = (u-cx) z / fx, y = (v-cy) z / fy)
@@ -11,9 +11,9 @@
  *   mergePoints          training.cpp:147-173  (concatenation in observation order)
  * PARITY UNPINNED: the reference holds no fixture for this path, and cv::erode / rescaleDepth / depthTo3dSparse /
  * isValidDepth are third-party (recalled). Two reference quirks are not reproduced: roundWithinBounds clamps to
- * [0, width] and can index one past the last column (training.cpp:53-55,77) -- clamped to width-1 here; and when
- * depth and image sizes differ the reference's cv::resize call passes CV_INTER_NN as `fx` (Trainer.cpp:78), i.e.
- * it interpolates bilinearly -- only the equal-size case is restated.
+ * [0, width] and can index one past the last column (training.cpp:53-55,77) -- clamped to width-1 here. When depth
+ * and image sizes differ the reference's cv::resize call passes CV_INTER_NN as `fx` (Trainer.cpp:78), i.e. it
+ * interpolates bilinearly: train_rescale_depth() below restates that (and the nearest-neighbour intent as an option).
  * The keypoints come from this repo's ORB restatement with a mask (level-i mask = nearest-neighbour sample of the
  * level-0 mask; a candidate needs mask != 0), because cv::ORB is third-party.
  */
@@ -81,4 +81,75 @@ uint32_t train_observation(const float* kp_xy, const uint8_t* desc, uint32_t n_k
   }
   free(er);
   return n;
+}
+
+/* rescale_depth (src/training/Trainer.cpp:62-81). in: dH x dW, float metres (is_u16 = 0) or uint16 millimetres
+ * (cv::rescaleDepth: value / 1000, 0 -> NaN). out: H x W float metres. Equal sizes: conversion only (:68-71).
+ * Otherwise (:73-80) a resize into the top (int)(dH * factor) rows, factor = (float)W / dW, NaN below. The reference
+ * calls cv::resize(depth, subregion, subregion.size(), CV_INTER_NN): the constant lands in the `fx` parameter, so
+ * the interpolation that RUNS is cv::resize's default, bilinear (nearest = 0 here); nearest = 1 is what the
+ * comment at :77 intends. cv::resize's float paths, third-party and recalled -- PARITY UNPINNED:
+ *   nearest : src = min(floor(x * ifx), src_w - 1), ifx = 1 / (dst_w / src_w), double
+ *   bilinear: fx = (float)((x + .5) * scale - .5); sx = floor(fx); fx -= sx; sx < 0 -> sx = 0, fx = 0;
+ *             sx + 1 >= src_w -> single tap S[src_w - 1] * 1; row indices sy, sy + 1 clamped, weights kept;
+ *             horizontal pass then vertical pass, float, no fma
+ *   2x shrink in both directions: INTER_LINEAR is replaced by the INTER_AREA fast path (S00 + S01 + S10 + S11) * .25f
+ * Returns 0, or -1 where cv::Mat::rowRange / cv::resize would throw. */
+static float depth_metres(const void* in, int is_u16, size_t i) {
+  if (!is_u16) return ((const float*)in)[i];
+  const uint16_t d = ((const uint16_t*)in)[i];
+  return d ? (float)d * 0.001f : NAN;
+}
+int train_rescale_depth(const void* in, int is_u16, uint32_t dH, uint32_t dW, float* out, uint32_t H, uint32_t W, int nearest) {
+  if (dH == H && dW == W) {
+    for (size_t i = 0; i < (size_t)H * W; ++i) out[i] = depth_metres(in, is_u16, i);
+    return 0;
+  }
+  const float factor = (float)W / (float)dW;
+  const int rows = (int)((float)dH * factor);
+  if (rows <= 0 || (uint32_t)rows > H) return -1;
+  const double scale_x = 1.0 / ((double)W / (double)dW), scale_y = 1.0 / ((double)rows / (double)dH);
+  const int area2 = !nearest && dW == 2u * W && dH == 2u * (uint32_t)rows;
+  for (uint32_t y = 0; y < H; ++y)
+    for (uint32_t x = 0; x < W; ++x) {
+      volatile float z = NAN;
+      if (y < (uint32_t)rows) {
+        if (nearest) {
+          uint32_t sx = (uint32_t)floor((double)x * scale_x), sy = (uint32_t)floor((double)y * scale_y);
+          if (sx > dW - 1) sx = dW - 1;
+          if (sy > dH - 1) sy = dH - 1;
+          z = depth_metres(in, is_u16, (size_t)sy * dW + sx);
+        } else if (area2) {
+          const size_t o = (size_t)(2u * y) * dW + 2u * x;
+          volatile float s = depth_metres(in, is_u16, o) + depth_metres(in, is_u16, o + 1);
+          s = s + depth_metres(in, is_u16, o + dW);
+          s = s + depth_metres(in, is_u16, o + dW + 1);
+          z = s * 0.25f;
+        } else {
+          float fx = (float)(((double)x + 0.5) * scale_x - 0.5), fy = (float)(((double)y + 0.5) * scale_y - 0.5);
+          int sx = (int)floorf(fx), sy = (int)floorf(fy);
+          fx -= (float)sx; fy -= (float)sy;
+          if (sx < 0) { sx = 0; fx = 0.f; }
+          const int one_tap = sx + 1 >= (int)dW;
+          if (one_tap) sx = (int)dW - 1;
+          int sy0 = sy < 0 ? 0 : (sy > (int)dH - 1 ? (int)dH - 1 : sy);
+          int sy1 = sy + 1 < 0 ? 0 : (sy + 1 > (int)dH - 1 ? (int)dH - 1 : sy + 1);
+          volatile float h0, h1, p0, p1;
+          if (one_tap) {
+            h0 = depth_metres(in, is_u16, (size_t)sy0 * dW + sx);
+            h1 = depth_metres(in, is_u16, (size_t)sy1 * dW + sx);
+          } else {
+            const float a0 = 1.f - fx, a1 = fx;
+            p0 = depth_metres(in, is_u16, (size_t)sy0 * dW + sx) * a0; p1 = depth_metres(in, is_u16, (size_t)sy0 * dW + sx + 1) * a1;
+            h0 = p0 + p1;
+            p0 = depth_metres(in, is_u16, (size_t)sy1 * dW + sx) * a0; p1 = depth_metres(in, is_u16, (size_t)sy1 * dW + sx + 1) * a1;
+            h1 = p0 + p1;
+          }
+          p0 = h0 * (1.f - fy); p1 = h1 * fy;
+          z = p0 + p1;
+        }
+      }
+      out[(size_t)y * W + x] = z;
+    }
+  return 0;
 }

@@ -286,6 +286,15 @@ def train_observation(kp_xy, desc, mask, depth_m, K, R, T):
     return od[:n].copy(), op[:n].copy(), src[:n].copy()
 
 
+def train_rescale_depth(depth, H, W, nearest=False):
+    u16 = depth.dtype == np.uint16
+    d = np.ascontiguousarray(depth, np.uint16 if u16 else np.float32)
+    out = np.empty((H, W), np.float32)
+    rc = lib().train_rescale_depth(d.ctypes.data_as(C.c_void_p), C.c_int(1 if u16 else 0), C.c_uint32(d.shape[0]),
+                                   C.c_uint32(d.shape[1]), _p(out, C.c_float), C.c_uint32(H), C.c_uint32(W), C.c_int(1 if nearest else 0))
+    return out if rc == 0 else None
+
+
 def train_erode4(mask):
     mk = np.ascontiguousarray(mask, np.uint8)
     out = np.zeros_like(mk)

@@ -198,3 +198,29 @@ def test_l2_oracle_against_numpy():
     r0 = float(m["distance"][1])
     rc, row_ptr2, m2, _ = O.l2_match(desc, off, pts, q[:1], k, r0)
     assert row_ptr2[1] == 2 and np.array_equal(m2["trainIdx"], m["trainIdx"][:2])
+
+
+def test_rescale_depth_known_answers():
+    """rescale_depth (Trainer.cpp:62-81) on hand cases. The reference's cv::resize call runs BILINEAR (CV_INTER_NN lands
+    in `fx`, :78); cv::resize maps [0, 1] -> [0, .25, .75, 1] when doubling. PARITY UNPINNED (third-party cv::resize)."""
+    d = np.array([[0.0, 1.0], [2.0, 3.0]], np.float32)
+    out = O.train_rescale_depth(d, 4, 4)
+    row = np.array([0, .25, .75, 1], np.float32)
+    assert np.array_equal(out[0], row) and np.array_equal(out[3], row + 2)
+    assert np.array_equal(out[:, 0], np.array([0, .5, 1.5, 2], np.float32))
+    nn = O.train_rescale_depth(d, 4, 4, nearest=True)
+    assert np.array_equal(nn, np.repeat(np.repeat(d, 2, 0), 2, 1))
+    # aspect mismatch: 2 x 4 depth on a 6 x 8 image fills int(2 * 2.0) = 4 rows, NaN below (:74-76)
+    out = O.train_rescale_depth(np.ones((2, 4), np.float32), 6, 8)
+    assert np.all(out[:4] == 1) and np.isnan(out[4:]).all()
+    # uint16 millimetres, 0 = no measurement; equal size = conversion only (:68-71)
+    d16 = np.array([[0, 1000], [1500, 65535]], np.uint16)
+    out = O.train_rescale_depth(d16, 2, 2)
+    assert np.isnan(out[0, 0]) and out[0, 1] == np.float32(1000) * np.float32(0.001) and out[1, 0] == np.float32(1500) * np.float32(0.001)
+    # exact 2x shrink: the mean of each 2 x 2 block; a NaN poisons its block
+    big = np.arange(16, dtype=np.float32).reshape(4, 4)
+    big[3, 3] = np.nan
+    out = O.train_rescale_depth(big, 2, 2)
+    assert out[0, 0] == 2.5 and out[0, 1] == 4.5 and out[1, 0] == 10.5 and np.isnan(out[1, 1])
+    # a depth whose scaled height exceeds the image: cv::Mat::rowRange throws in the reference
+    assert O.train_rescale_depth(np.ones((8, 4), np.float32), 6, 8) is None

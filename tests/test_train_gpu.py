@@ -61,3 +61,40 @@ def test_masked_orb_only_returns_keypoints_inside_the_mask():
     n = model.add_observation(img, np.zeros_like(mask), depth, K, R, T)
     assert n == 0
     model.close(); ctx.close()
+
+
+@pytest.mark.parametrize("u16", [False, True])
+@pytest.mark.parametrize("shape", [(480, 640), (240, 320), (300, 400), (200, 320), (960, 1280), (1024, 1280), (97, 131)])
+@pytest.mark.parametrize("nearest", [False, True])
+def test_rescale_depth(shape, u16, nearest):
+    """rescale_depth (Trainer.cpp:62-81) for depth images of other sizes than the 480 x 640 image: bit-identical to
+    the CPU restatement, bilinear (what the reference executes) and nearest (what it intends)."""
+    rng = np.random.Generator(np.random.PCG64(shape[0] * 7 + shape[1]))
+    z = (0.4 + 3.0 * rng.random(shape)).astype(np.float32)
+    z[rng.random(shape) < 0.05] = np.nan
+    depth = np.where(np.isnan(z), 0, np.rint(z * 1000)).astype(np.uint16) if u16 else z
+    ctx = capi.Context(0)
+    want = O.train_rescale_depth(depth, 480, 640, nearest)
+    if want is None:                                              # (1024, 1280): scaled height 512 > 480 rows
+        with pytest.raises(capi.TodError):
+            ctx.rescale_depth(depth, 480, 640, nearest)
+        return
+    got = ctx.rescale_depth(depth, 480, 640, nearest)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.isfinite(got).any()
+
+
+def test_rescaled_depth_feeds_the_verifier_lookup():
+    """uint16 depth through todhip_rescale_depth_device (equal size) and then the float lookup gives the same query
+    points as the fused uint16 lookup of todhip_verify_device_depth."""
+    import torch
+    H, W, nq = 480, 640, 300
+    rng = np.random.Generator(np.random.PCG64(5))
+    d16 = rng.integers(0, 4000, (H, W)).astype(np.uint16)
+    ctx = capi.Context(0)
+    t_in = torch.from_numpy(d16.view(np.int16)).cuda()
+    t_out = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    ctx.rescale_depth_device(t_in.data_ptr(), True, H, W, t_out.data_ptr(), H, W)
+    ctx.synchronize()
+    want = np.where(d16 == 0, np.nan, d16.astype(np.float32) * np.float32(0.001)).astype(np.float32)
+    assert np.array_equal(t_out.cpu().numpy().view(np.uint32), want.view(np.uint32))

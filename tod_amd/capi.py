@@ -60,6 +60,7 @@ EXPORTS = [
     "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
     "todhip_match_l2", "todhip_match_l2_device",
     "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
+    "todhip_rescale_depth", "todhip_rescale_depth_device",
 ]
 
 _lib = None
@@ -413,6 +414,27 @@ def _orb_batch_device(self, d_gray, n_frames, frame_stride, H, W, stride, n_feat
 Context.orb_batch_device = _orb_batch_device
 
 
+def _rescale_depth(self, depth, H, W, nearest=False):
+    """rescale_depth (Trainer.cpp:62-81): depth [dH, dW] float32 metres / uint16 mm -> [H, W] float32 metres."""
+    u16 = depth.dtype == np.uint16
+    d = np.ascontiguousarray(depth, np.uint16 if u16 else np.float32)
+    out = np.empty((H, W), np.float32)
+    rc = lib().todhip_rescale_depth(self._h, _np_ptr(d), C.c_int(1 if u16 else 0), C.c_uint32(d.shape[0]), C.c_uint32(d.shape[1]),
+                                    _np_ptr(out), C.c_uint32(H), C.c_uint32(W), C.c_int(1 if nearest else 0))
+    _check(rc, "todhip_rescale_depth")
+    return out
+
+
+def _rescale_depth_device(self, d_depth_in, is_u16, dH, dW, d_depth_out, H, W, nearest=False):
+    rc = lib().todhip_rescale_depth_device(self._h, C.c_void_p(d_depth_in), C.c_int(1 if is_u16 else 0), C.c_uint32(dH),
+                                           C.c_uint32(dW), C.c_void_p(d_depth_out), C.c_uint32(H), C.c_uint32(W), C.c_int(1 if nearest else 0))
+    _check(rc, "todhip_rescale_depth_device")
+
+
+Context.rescale_depth = _rescale_depth
+Context.rescale_depth_device = _rescale_depth_device
+
+
 class Model:
     """One object's model being trained (todhip_model): add observations, then finish() -> (desc, pts)."""
 
@@ -425,9 +447,11 @@ class Model:
     def add_observation(self, gray, mask, depth, K, R, T, n_features=500, n_levels=8, scale_factor=1.2):
         g = np.ascontiguousarray(gray, np.uint8)
         mk = np.ascontiguousarray(mask, np.uint8)
+        H, W = g.shape
+        if tuple(depth.shape) != (H, W):                       # rescale_depth's resize branch (Trainer.cpp:73-80)
+            depth = self._ctx.rescale_depth(depth, H, W)
         u16 = depth.dtype == np.uint16
         d = np.ascontiguousarray(depth, np.uint16 if u16 else np.float32)
-        H, W = g.shape
         K9 = np.ascontiguousarray(K, np.float32).reshape(9)
         R9 = np.ascontiguousarray(R, np.float32).reshape(9)
         T3 = np.ascontiguousarray(T, np.float32).reshape(3)

@@ -39,6 +39,78 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 struct Cam { float fx, fy, cx, cy, R[9], T[3]; };
 
+// rescale_depth (Trainer.cpp:62-81; the detection side does the same in ecto_opencv's RescaledRegisteredDepth,
+// detector.py:26,62): cv::rescaleDepth to float metres, then -- when the depth image is not of the image size --
+// a resize into the top int(dH * factor) rows of an H x W image, the rest NaN. The reference's call
+// cv::resize(depth, subregion, subregion.size(), CV_INTER_NN) (:78) hands CV_INTER_NN (== 0) to the `fx` parameter,
+// so what it EXECUTES is cv::resize's default, bilinear interpolation; `nearest` selects what its comment (:77)
+// intends. Both follow cv::resize's float path (third-party arithmetic, recalled; parity unpinned):
+//   nearest : source = floor(x * (1 / (dst / src))) clamped to the last column / row, in double
+//   bilinear: f = (float)((x + 0.5) * (src / dst) - 0.5), s = floor(f), f -= s; s < 0 -> s = 0, f = 0; s + 1 >= src
+//             width -> the single tap S[src - 1] * 1; rows: the two row indices are clamped, the weights are kept;
+//             out = (S00 * (1 - fx) + S01 * fx) * (1 - fy) + (S10 * (1 - fx) + S11 * fx) * fy in float, no fma
+//             (a NaN tap poisons the pixel even under a zero weight, as in the reference).
+//   exact 2x shrink: cv::resize turns INTER_LINEAR into its INTER_AREA fast path: (S00 + S01 + S10 + S11) * 0.25f.
+__device__ __forceinline__ float depth_metres(const void* src, int is_u16, size_t i) {
+  if (!is_u16) return reinterpret_cast<const float*>(src)[i];
+  const uint16_t d = reinterpret_cast<const uint16_t*>(src)[i];
+  return d ? (float)d * 0.001f : __builtin_nanf("");                 // cv::rescaleDepth
+}
+__global__ __launch_bounds__(256) void rescale_depth_kernel(const void* __restrict__ src, int is_u16, uint32_t dH, uint32_t dW,
+                                                            uint32_t sub_rows, int mode, double sx_scale, double sy_scale,
+                                                            float* __restrict__ dst, uint32_t H, uint32_t W) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= H * W) return;
+  const uint32_t x = i % W, y = i / W;
+  float z = __builtin_nanf("");
+  if (y < sub_rows) {
+    if (mode == 0) {                                                 // sizes equal: conversion only (:68-71)
+      z = depth_metres(src, is_u16, i);
+    } else if (mode == 1) {                                          // nearest
+      const uint32_t sx = min((uint32_t)floor((double)x * sx_scale), dW - 1u), sy = min((uint32_t)floor((double)y * sy_scale), dH - 1u);
+      z = depth_metres(src, is_u16, (size_t)sy * dW + sx);
+    } else if (mode == 3) {                                          // exact 2x shrink
+      const size_t o = (size_t)(2u * y) * dW + 2u * x;
+      z = (depth_metres(src, is_u16, o) + depth_metres(src, is_u16, o + 1) + depth_metres(src, is_u16, o + dW) +
+           depth_metres(src, is_u16, o + dW + 1)) * 0.25f;
+    } else {                                                         // bilinear
+      float fx = (float)(((double)x + 0.5) * sx_scale - 0.5), fy = (float)(((double)y + 0.5) * sy_scale - 0.5);
+      int sx = (int)floorf(fx), sy = (int)floorf(fy);
+      fx -= (float)sx; fy -= (float)sy;
+      if (sx < 0) { sx = 0; fx = 0.f; }
+      const bool one_tap = sx + 1 >= (int)dW;
+      if (one_tap) sx = (int)dW - 1;
+      const int sy0 = clampi(sy, 0, (int)dH - 1), sy1 = clampi(sy + 1, 0, (int)dH - 1);
+      float h0, h1;
+      if (one_tap) {
+        h0 = depth_metres(src, is_u16, (size_t)sy0 * dW + sx) * 1.f;
+        h1 = depth_metres(src, is_u16, (size_t)sy1 * dW + sx) * 1.f;
+      } else {
+        const float a0 = 1.f - fx, a1 = fx;
+        h0 = depth_metres(src, is_u16, (size_t)sy0 * dW + sx) * a0 + depth_metres(src, is_u16, (size_t)sy0 * dW + sx + 1) * a1;
+        h1 = depth_metres(src, is_u16, (size_t)sy1 * dW + sx) * a0 + depth_metres(src, is_u16, (size_t)sy1 * dW + sx + 1) * a1;
+      }
+      z = h0 * (1.f - fy) + h1 * fy;
+    }
+  }
+  dst[i] = z;
+}
+
+// host part of rescale_depth: the geometry of the resize. Returns false when cv::Mat::rowRange / cv::resize would throw.
+bool rescale_geometry(uint32_t dH, uint32_t dW, uint32_t H, uint32_t W, int nearest, uint32_t* sub_rows, int* mode, double* sx,
+                      double* sy) {
+  if (dH == H && dW == W) { *sub_rows = H; *mode = 0; *sx = 1.0; *sy = 1.0; return true; }
+  const float factor = (float)W / (float)dW;                     // :73
+  const int rows = (int)((float)dH * factor);                    // rowRange(0, dsize.height * factor), :76
+  if (rows <= 0 || (uint32_t)rows > H) return false;
+  *sub_rows = (uint32_t)rows;
+  const double inv_x = (double)W / (double)dW, inv_y = (double)rows / (double)dH;   // cv::resize: inv_scale = dst / src
+  *mode = nearest ? 1 : ((dW == 2u * W && dH == 2u * (uint32_t)rows) ? 3 : 2);
+  *sx = 1.0 / inv_x; *sy = 1.0 / inv_y;                          // ifx (nearest) == scale_x (bilinear) == 1 / inv_scale
+  return true;
+}
+
+
 // validateKeyPoints (training.cpp:57-145) + depthTo3dSparse + cameraToWorld (:175-195) for one keypoint per thread.
 // roundWithinBounds clamps to [0, width] in the reference (:53-55), which can index one column past the image;
 // here the clamp is to width-1 / height-1.
@@ -187,6 +259,37 @@ int todhip_model_add_observation(todhip_ctx* ctx, todhip_model* m, const uint8_t
   TOD_HIP(hipStreamSynchronize(st));                     // also keeps gray/mask/depth/n_kp alive until the copies are done
   if (n_added) *n_added = h[1];
   return TODHIP_OK;
+}
+
+// rescale_depth (Trainer.cpp:62-81) on device-resident images: d_depth_in dH x dW (float metres or uint16 mm),
+// d_depth_out H x W float metres. Asynchronous on the context's stream.
+int todhip_rescale_depth_device(todhip_ctx* ctx, const void* d_depth_in, int depth_is_u16, uint32_t dH, uint32_t dW,
+                                void* d_depth_out, uint32_t H, uint32_t W, int nearest) {
+  if (!ctx || !d_depth_in || !d_depth_out || !dH || !dW || !H || !W || (uint64_t)H * W > 0xFFFFFFFFull) return TODHIP_EINVAL;
+  uint32_t sub_rows; int mode; double sx, sy;
+  if (!rescale_geometry(dH, dW, H, W, nearest, &sub_rows, &mode, &sx, &sy)) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(rescale_depth_kernel, dim3((uint32_t)(((size_t)H * W + 255) / 256)), dim3(256), 0, ctx->stream, d_depth_in,
+                     depth_is_u16, dH, dW, sub_rows, mode, sx, sy, static_cast<float*>(d_depth_out), H, W);
+  TOD_HIP(hipGetLastError());
+  return TODHIP_OK;
+}
+
+// Host-buffer form (what Trainer::process does per observation before validateKeyPoints, :142-143).
+int todhip_rescale_depth(todhip_ctx* ctx, const void* depth_in, int depth_is_u16, uint32_t dH, uint32_t dW, float* depth_out,
+                         uint32_t H, uint32_t W, int nearest) {
+  if (!ctx || !depth_in || !depth_out || !dH || !dW || !H || !W) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  const size_t in_bytes = (size_t)dH * dW * (depth_is_u16 ? 2 : 4), out_bytes = (size_t)H * W * 4;
+  DevBuf in, out;
+  int rc = TODHIP_OK;
+  if (in.reserve(in_bytes) != hipSuccess || out.reserve(out_bytes) != hipSuccess) rc = TODHIP_EHIP;
+  if (rc == TODHIP_OK && hipMemcpyAsync(in.p, depth_in, in_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = TODHIP_EHIP;
+  if (rc == TODHIP_OK) rc = todhip_rescale_depth_device(ctx, in.p, depth_is_u16, dH, dW, out.p, H, W, nearest);
+  if (rc == TODHIP_OK && hipMemcpyAsync(depth_out, out.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = TODHIP_EHIP;
+  (void)hipStreamSynchronize(ctx->stream);
+  in.release(); out.release();
+  return rc;
 }
 
 // mergePoints (training.cpp:147-173) + ModelFiller (ModelFiller.cpp:20-26): the stacked descriptors and points.
