@@ -483,3 +483,28 @@ def test_many_small_distractor_objects(ctx, n_obj):
     assert np.array_equal(poses[0]["inliers"], o_poses[0]["inliers"])
     assert np.abs(poses[0]["R"] - o_poses[0]["R"]).max() < POSE_TOL and np.abs(poses[0]["t"] - o_poses[0]["t"]).max() < POSE_TOL
     assert len(tr) >= n_obj // 2
+
+
+def test_object_with_more_than_4096_matches(ctx):
+    """6500 matches on one object: bitset rows span 102 words, i.e. more than one word per lane of a wave (the
+    reference has no size limit, adjacency_ransac.h:48-133; here the limit is 16384 matches per object)."""
+    sc = synth.make_verify_scene(1300, n_objects=1, per_object=3000, visible=((0, 0.25),), matches_per_kp=5, seed=90,
+                                 nan_frac=0.0)
+    poses, rounds = _compare_frame(ctx, sc, 8, 30)
+    assert len(poses) >= 1 and len(poses[0]["inliers"]) > 100
+
+
+def test_maximum_object_size_and_one_beyond(ctx):
+    """Exactly 16384 matches on one object (the documented maximum) equals the oracle; one keypoint more is refused
+    with TODHIP_ESCRATCH instead of computing something else."""
+    sc = synth.make_verify_scene(4096, n_objects=1, per_object=6000, visible=((0, 0.2),), matches_per_kp=4, seed=91,
+                                 nan_frac=0.0)
+    assert len(sc["matches"]) == 16384
+    poses, rounds = _compare_frame(ctx, sc, 8, 100)
+    assert len(poses) == 1 and len(poses[0]["inliers"]) > 500
+    sc = synth.make_verify_scene(4097, n_objects=1, per_object=6000, visible=((0, 0.1),), matches_per_kp=4, seed=91,
+                                 nan_frac=0.0)
+    rng = capi.rng_new(1)
+    with pytest.raises(capi.TodError) as e:
+        ctx.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 6, 0.01, rng)
+    assert e.value.status == capi.ESCRATCH
