@@ -82,3 +82,27 @@ def test_integer_valued_descriptors_and_duplicates(ctx):
     ctx.db_load(desc, pts, off)
     row_ptr, m = _assert_same(ctx, desc, pts, off, q, 3, 1.0e9)
     assert list(off[m["imgIdx"][:3]] + m["trainIdx"][:3]) == [100, 2500, 4000] and (m["distance"][:3] == 0).all()
+
+
+def test_c4_full_size_properties(ctx):
+    """BASELINE configs[3] at full size (1000 SIFT-128 queries x 500k rows, k = 2): the oracle would take minutes on
+    all of it, so 24 queries are checked against it bit for bit and the rest through size-independent properties --
+    the planted row is the nearest one, distances ascend with ties in row order, and every reported distance is the
+    exact f32 distance of the reported row."""
+    desc, pts, off = synth.make_sift_db(100, per_object=5000)
+    q, truth = synth.make_sift_queries(desc, 1000, frame=0)
+    ctx.db_load(desc, pts, off)
+    row_ptr, m, xyz = ctx.match_l2(q, 2, 1.0e9)
+    assert (np.diff(row_ptr.astype(np.int64)) == 2).all()
+    glob = off[m["imgIdx"]].astype(np.int64) + m["trainIdx"]
+    g2, d2 = glob.reshape(1000, 2), m["distance"].reshape(1000, 2)
+    planted = truth >= 0
+    assert (g2[planted, 0] == truth[planted]).all()
+    assert ((d2[:, 0] < d2[:, 1]) | ((d2[:, 0] == d2[:, 1]) & (g2[:, 0] < g2[:, 1]))).all()
+    assert np.array_equal(xyz, pts[glob])
+    pick = np.r_[np.flatnonzero(planted)[:12], np.flatnonzero(~planted)[:12]]
+    rc, o_row_ptr, o_m, o_xyz = O.l2_match(desc, off, pts, q[pick], 2, 1.0e9)
+    assert rc == 0
+    sel = (pick[:, None] * 2 + np.arange(2)).ravel()
+    for f in ("trainIdx", "imgIdx", "distance"):
+        assert np.array_equal(m[f][sel], o_m[f]), f
