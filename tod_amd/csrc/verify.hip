@@ -15,6 +15,7 @@
 // The RANSAC bookkeeping (ransac.h:95-135: strictly-better test, adaptive k with pow/log) is replayed on the
 // host from the per-iteration consensus counts, so that libm results are those of the CPU reference.
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <climits>
 #include <cmath>
@@ -1186,21 +1187,29 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
     __syncthreads();
     const uint32_t cnt = sCount;
     const bool staged = cnt <= kGrowthLdsPoints;
-    if (staged && tid < W) {
-      u64 bits = inl[tid];
-      uint32_t o = sPre[tid];
-      while (bits) {
-        const uint32_t v = tid * 64u + (uint32_t)__ffsll((long long)bits) - 1u;
-        for (int c = 0; c < 3; ++c) { sPts[o * 6u + c] = job.train[3 * v + c]; sPts[o * 6u + 3 + c] = job.query[3 * v + c]; }
-        ++o;
-        bits &= bits - 1ull;
+    if (staged) {                                          // one thread per match: its slot = inliers below it
+      for (uint32_t v = tid; v < W * 64u; v += 256u) {
+        const u64 bits = inl[v >> 6];
+        if ((bits >> (v & 63u)) & 1ull) {
+          const uint32_t o = sPre[v >> 6] + (uint32_t)__popcll(bits & ((1ull << (v & 63u)) - 1ull));
+          for (int c = 0; c < 3; ++c) { sPts[o * 6u + c] = job.train[3 * v + c]; sPts[o * 6u + 3 + c] = job.query[3 * v + c]; }
+        }
       }
     }
     __syncthreads();
     if (tid < 6) {                                         // 6 sequential float sums: centroids
       float s = 0.f;
       if (staged) {
-        for (uint32_t i = 0; i < cnt; ++i) s += sPts[i * 6u + tid];
+        // 8 LDS reads in flight at once; the additions stay in list order
+        uint32_t i = 0;
+        for (; i + 8u <= cnt; i += 8u) {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = sPts[(i + j) * 6u + tid];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; i < cnt; ++i) s += sPts[i * 6u + tid];
       } else {
         const float* src = tid < 3 ? job.train : job.query;
         const uint32_t c = tid % 3u;
@@ -1222,7 +1231,15 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
       const float ct = sC[r], cq = sC[3 + c];
       double h = 0.0;
       if (staged) {
-        for (uint32_t i = 0; i < cnt; ++i) {
+        uint32_t i = 0;
+        for (; i + 8u <= cnt; i += 8u) {
+          float va[8], vb[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { va[j] = sPts[(i + j) * 6u + r]; vb[j] = sPts[(i + j) * 6u + 3 + c]; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h += (double)(va[j] - ct) * (double)(vb[j] - cq);
+        }
+        for (; i < cnt; ++i) {
           const float a = sPts[i * 6u + r] - ct, b = sPts[i * 6u + 3 + c] - cq;
           h += (double)a * (double)b;
         }
@@ -1304,20 +1321,57 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
       out->T[r] = s;
       for (int c = 0; c < 3; ++c) out->R[3 * r + c] = Rt[r][c];
     }
+  }
+  // unique keypoint indices in ascending match order (:306-308). qidx is non-decreasing in the match index (App. A Q4),
+  // so an inlier starts a new keypoint iff the inlier before it has another qidx: one wave per 64-match word, the word
+  // boundaries are stitched by one lane.
+  uint32_t* const sFirstQ = sPre;                          // sPre is free after the last pass
+  __shared__ uint32_t sLastQ[kMaxWords], sNewIn[kMaxWords], sOff[kMaxWords];
+  const uint32_t lane = tid & 63u;
+  for (uint32_t w = tid >> 6; w < W; w += 4u) {
+    const u64 bits = inl[w];
+    const bool in = (bits >> lane) & 1ull;
+    const uint32_t q = in ? job.qidx[w * 64u + lane] : 0u;
+    const u64 lower = bits & ((1ull << lane) - 1ull);
+    const uint32_t pq = __shfl(q, lower ? 63u - (uint32_t)__clzll((long long)lower) : 0u);
+    const u64 fresh = __ballot(in && lower != 0ull && q != pq);      // new keypoint, previous inlier in the same word
+    if (lane == 0) sNewIn[w] = (uint32_t)__popcll(fresh);
+    if (bits) {
+      const uint32_t lo = (uint32_t)__ffsll((long long)bits) - 1u, hi = 63u - (uint32_t)__clzll((long long)bits);
+      if (lane == lo) sFirstQ[w] = q;
+      if (lane == hi) sLastQ[w] = q;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
     uint32_t nm = 0, nk = 0, last = 0xFFFFFFFFu;
     for (uint32_t w = 0; w < W; ++w) {
-      u64 bits = inl[w];
-      while (bits) {
-        const uint32_t v = w * 64u + (uint32_t)__ffsll((long long)bits) - 1u;
-        const uint32_t qi = job.qidx[v];                   // non-decreasing in v (App. A Q4)
-        if (qi != last) { kp_list[nk++] = qi; kp_bits[qi >> 6] |= 1ull << (qi & 63u); last = qi; }
-        ++nm;
-        bits &= bits - 1ull;
-      }
+      const u64 bits = inl[w];
+      uint32_t first_new = 0;
+      if (bits) { first_new = sFirstQ[w] != last ? 1u : 0u; last = sLastQ[w]; }
+      sOff[w] = nk | (first_new << 31);
+      nk += first_new + sNewIn[w];
+      nm += (uint32_t)__popcll(bits);
     }
     out->n_match_inliers = nm;
     out->n_kp_inliers = nk;
     out->passes = passes;
+  }
+  __syncthreads();
+  for (uint32_t w = tid >> 6; w < W; w += 4u) {
+    const u64 bits = inl[w];
+    if (!bits) continue;                                   // wave-uniform
+    const bool in = (bits >> lane) & 1ull;
+    const uint32_t q = in ? job.qidx[w * 64u + lane] : 0u;
+    const u64 lower = bits & ((1ull << lane) - 1ull);
+    const uint32_t pq = __shfl(q, lower ? 63u - (uint32_t)__clzll((long long)lower) : 0u);
+    const bool first_new = (sOff[w] >> 31) != 0u;
+    const bool is_new = in && (lower != 0ull ? q != pq : first_new);
+    const u64 bal = __ballot(is_new);
+    if (is_new) {
+      kp_list[(sOff[w] & 0x7FFFFFFFu) + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = q;
+      atomicOr(&kp_bits[q >> 6], 1ull << (q & 63u));
+    }
   }
 }
 
@@ -2128,9 +2182,19 @@ struct Engine {
       for (Slot* s : slots)
         if (s->ph != PH_DONE) { issue(*s); any = any || s->ph != PH_DONE; }
       if (!any) break;
+      char what[128] = "";
+      std::chrono::steady_clock::time_point t0;
+      if (tod_debug()) {                                    // TODHIP_DEBUG=1: what a tick launches and how long it takes
+        snprintf(what, sizeof(what), "lookup %zu adj %zu prep %zu draw %zu+%zu chain %zu eval %zu+%zu growth %zu inval %zu", L.lookup.size(),
+                 L.adj.size(), L.prep.size(), L.draw.size(), L.draw_small.size(), L.chain.size(), L.eval_small.size(),
+                 L.eval_big.size(), L.growth.size(), L.inval.size());
+        t0 = std::chrono::steady_clock::now();
+      }
       launch_all();
       TOD_HIP(hipGetLastError());
       TOD_HIP(hipStreamSynchronize(st));
+      if (tod_debug())
+        TOD_DBG("tick %.1f us: %s", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
       for (Slot* s : slots)
         if (s->ph != PH_DONE) consume(*s);
     }
