@@ -97,14 +97,14 @@ def test_adjacency_nan_points_follow_reference_comparisons(ctx):
 
 
 # ------------------------------------------------------------------------------------------ whole frames
-def _compare_frame(ctx, sc, min_inliers, n_iter, err=0.01, seed=1):
+def _compare_frame(ctx, sc, min_inliers, n_iter, err=0.01, seed=1, max_poses=64):
     rng_o = O.rng_new(seed)
     rc, o_poses, o_rounds = O.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"],
-                                     sc["spans"], min_inliers, n_iter, err, rng_o)
+                                     sc["spans"], min_inliers, n_iter, err, rng_o, max_poses=max_poses)
     assert rc == 0
     rng_g = capi.rng_new(seed)
     g_poses = ctx.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"],
-                         min_inliers, n_iter, err, rng_g)
+                         min_inliers, n_iter, err, rng_g, max_poses=max_poses)
     g_rounds = ctx.verify_trace()
     # the oracle also traces rounds of objects with < 3 matches (no draws, no iterations); the GPU path skips them
     o_rounds = [r for r in o_rounds if not (r.iterations == 0 and r.draws_after == r.draws_before and r.best_count == 0)]
