@@ -85,3 +85,116 @@ def test_orb_random_shapes(ctx, seed):
     if seed % 5 == 4:
         img = rng.integers(0, 256, (H, W)).astype(np.uint8)   # white noise: corners everywhere
     orb_same(ctx, img, int(rng.integers(1, 1600)), int(rng.integers(1, 9)), float(rng.choice([1.1, 1.2, 1.3, 1.5, 2.0])))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_verifier_random_batches_against_the_oracle(ctx, seed):
+    """todhip_verify_batch_device on 2..24 random frames (more than one launch group when > 16) that share a model
+    set but differ in what is visible, in noise, missing depth and generator seed: every frame equals the oracle's
+    result for that frame alone -- poses, inlier lists and the final generator state."""
+    import torch
+    from test_verify_gpu import _pack_scene, POSE_TOL
+    rng = np.random.Generator(np.random.PCG64(34000 + seed))
+    F, nq, k = int(rng.integers(2, 25)), int(rng.integers(60, 400)), int(rng.integers(1, 6))
+    n_objects, per_object = int(rng.integers(2, 8)), int(rng.integers(100, 600))
+    mpk = int(rng.integers(1, k + 1))
+    scenes = []
+    for f in range(F):
+        n_vis = int(rng.integers(0, 3))
+        objs = rng.choice(n_objects, n_vis, replace=False)
+        visible = tuple((int(o), float(rng.uniform(0.1, 0.4))) for o in objs)
+        scenes.append(synth.make_verify_scene(nq, n_objects=n_objects, per_object=per_object, visible=visible, matches_per_kp=mpk,
+                                              seed=700 + seed, noise=float(rng.choice([0.0, 0.002, 0.006])),
+                                              nan_frac=float(rng.choice([0.0, 0.2])), true_match_rank=int(rng.integers(0, mpk))))
+    assert all(np.array_equal(s["spans"], scenes[0]["spans"]) for s in scenes)
+    packed = [_pack_scene(s, k) for s in scenes]
+    d_kp = torch.from_numpy(np.stack([s["kp_xy"] for s in scenes]).astype(np.float32)).cuda()
+    d_cloud = torch.from_numpy(np.stack([s["cloud"] for s in scenes]).astype(np.float32)).cuda()
+    d_counts = torch.from_numpy(np.stack([p[0] for p in packed])).cuda()
+    d_m = torch.from_numpy(np.stack([p[1] for p in packed])).cuda()
+    d_xyz = torch.from_numpy(np.stack([p[2] for p in packed])).cuda()
+    torch.cuda.synchronize()
+    min_inliers, n_iter, err = int(rng.integers(6, 15)), int(rng.integers(50, 500)), 0.01
+    seeds = [int(x) for x in rng.integers(1, 1 << 30, F)]
+    seeds[-1] = seeds[0]                                           # two frames sharing one rand() stream start
+    rngs = (capi.Rng * F)(*[capi.rng_new(s) for s in seeds])
+    got = ctx.verify_batch_device(F, d_kp.data_ptr(), nq, d_cloud.data_ptr(), 480, 640, d_counts.data_ptr(), d_m.data_ptr(),
+                                  d_xyz.data_ptr(), k, scenes[0]["spans"], min_inliers, n_iter, err, rngs, max_poses=256)
+    for f, sc in enumerate(scenes):
+        rng_o = O.rng_new(seeds[f])
+        rc, want, _ = O.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], min_inliers,
+                               n_iter, err, rng_o, max_poses=256)
+        assert rc == 0 and len(got[f]) == len(want), f
+        assert rngs[f].draws == rng_o.draws and list(rngs[f].s) == list(rng_o.s)
+        for a, b in zip(got[f], want):
+            assert a["object"] == b["object"] and np.array_equal(a["inliers"], b["inliers"])
+            assert np.abs(a["R"] - b["R"]).max() < POSE_TOL and np.abs(a["t"] - b["t"]).max() < POSE_TOL
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sharded_matcher_random_configurations(ctx, seed):
+    """Object-aligned shards (1..9 of them, more shards than objects included) + merge == the unsharded oracle, for
+    random object sizes (empty objects too), k, radius and tie-heavy descriptors."""
+    from test_match_gpu import _shard_merge
+    rng = np.random.Generator(np.random.PCG64(35000 + seed))
+    sizes = [int(rng.integers(0, 1500)) for _ in range(int(rng.integers(1, 9)))]
+    if sum(sizes) == 0:
+        sizes[-1] = 7
+    n, nq, k = sum(sizes), int(rng.integers(1, 400)), int(rng.integers(1, 9))
+    radius = int(rng.choice([5, 35, 47, 90, 256, 300]))
+    if seed % 3 == 0:
+        desc = np.zeros((n, 32), np.uint8); desc[:, 9] = rng.choice([0, 1, 3], n)
+        q = np.zeros((nq, 32), np.uint8); q[:, 9] = rng.choice([0, 1, 3, 7], nq)
+    else:
+        desc = rng.integers(0, 256, (n, 32)).astype(np.uint8)
+        q = desc[rng.integers(0, n, nq)] ^ (rng.random((nq, 32)) < 0.1).astype(np.uint8)
+    pts = rng.random((n, 3)).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    q = np.ascontiguousarray(q)
+    counts, m, xyz, infos = _shard_merge(desc, pts, off, q, k, radius, int(rng.integers(1, 10)))
+    rc, o_row_ptr, o_m, o_xyz = O.match(desc, off, pts, q, k, radius)
+    assert rc == 0 and np.array_equal(np.diff(o_row_ptr.astype(np.int64)), counts)
+    for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
+        assert np.array_equal(m[f], o_m[f]), f
+    assert np.array_equal(xyz, o_xyz)
+    assert sum(i["shard_rows"] for i in infos) == n
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_orb_random_batches(ctx, seed):
+    """todhip_orb_batch_device on 1..20 frames of a random common shape == the CPU restatement frame by frame."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(36000 + seed))
+    F, H, W = int(rng.integers(1, 21)), int(rng.integers(80, 400)), int(rng.integers(80, 500))
+    nf, nl, sf = int(rng.integers(20, 900)), int(rng.integers(1, 7)), float(rng.choice([1.15, 1.2, 1.4]))
+    imgs = [synth.make_image(300 + 20 * seed + f, H=H, W=W, n_rect=int(rng.integers(0, 800))) for f in range(F)]
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    kp = torch.zeros((F, nf, 2), device="cuda"); aux = torch.zeros((F, nf, 4), device="cuda")
+    desc = torch.zeros((F, nf, 32), dtype=torch.uint8, device="cuda")
+    n = ctx.orb_batch_device(d.data_ptr(), F, H * W, H, W, W, nf, nl, sf, kp.data_ptr(), aux.data_ptr(), desc.data_ptr(), nf)
+    for f in range(F):
+        o_kp, o_aux, o_desc, _ = O.orb(imgs[f], nf, nl, sf)
+        assert n[f] == len(o_kp)
+        assert np.array_equal(kp[f, :n[f]].cpu().numpy(), o_kp) and np.array_equal(desc[f, :n[f]].cpu().numpy(), o_desc)
+        assert np.array_equal(aux[f, :n[f]].cpu().numpy()[:, [0, 2, 3]], o_aux[:, [0, 2, 3]])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_l2_random_configurations(ctx, seed):
+    """Float-descriptor matcher on random sizes, k, radii and value ranges (integer-valued, tiny, huge norms)."""
+    from test_l2_gpu import _assert_same as l2_same
+    rng = np.random.Generator(np.random.PCG64(37000 + seed))
+    sizes = [int(rng.integers(0, 3000)) for _ in range(int(rng.integers(1, 6)))]
+    if sum(sizes) == 0:
+        sizes[0] = 3
+    n, nq, k = sum(sizes), int(rng.integers(1, 300)), int(rng.integers(1, 9))
+    scale = float(rng.choice([1.0, 255.0, 1e-3, 3e3]))
+    desc = (rng.random((n, 128)) * scale).astype(np.float32)
+    if seed % 2:
+        desc = np.rint(desc).astype(np.float32)
+    q = (desc[rng.integers(0, n, nq)] + rng.normal(0, 0.05 * scale, (nq, 128))).astype(np.float32)
+    pts = rng.random((n, 3)).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    ctx.db_load(desc, pts, off)
+    radius = float(rng.choice([0.3, 0.6, 1.5, 1e9])) * scale
+    l2_same(ctx, desc, pts, off, q, k, radius)
