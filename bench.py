@@ -108,7 +108,12 @@ def main():
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # TOD_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, collectives, shard + merge) with one rank --
+    # the only way to exercise the RCCL calls on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("TOD_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        for key, val in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(key, val)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -227,7 +232,7 @@ def main():
     def match_step(i):
         o = outs[i % D]
         q = Q_B[i % period]
-        if world == 1:
+        if not use_dist:
             # single device: no key exchange; the B frames' descriptors share one pass over the DB
             mctx[i % len(mctx)].match_device(q.data_ptr(), B * nq, k, args.radius, o["counts"].data_ptr(),
                                              o["matches"].data_ptr(), o["xyz"].data_ptr())
@@ -273,7 +278,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -305,7 +310,7 @@ def main():
         c.set_kernel_timing(False)
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -372,8 +377,9 @@ def main():
                          "queries_per_launch": world * B * nq,
                          "concurrent_matcher_contexts": len(mctx),
                          "note": "at %d queries per DB pass this kernel is bound by integer VALU issue, not HBM "
-                                 "(SURVEY F11): see valu_roofline; launch_ms is a launch's own duration, and with %d "
-                                 "matcher contexts consecutive launches overlap" % (world * B * nq, len(mctx))},
+                                 "(SURVEY F11): see valu_roofline; launch_ms is a launch's own duration (%s)"
+                                 % (world * B * nq, "one matcher context: launches do not overlap" if len(mctx) == 1 else
+                                    "%d matcher contexts: consecutive launches overlap" % len(mctx))},
             "valu_roofline": {"bound": "valu", "achieved": valu_rate / 1e12, "peak": VALU_PEAK_LANEOPS / 1e12,
                               "unit": "T lane-op/s", "frac": valu_frac,
                               "basis": "executed lane-ops of all matcher launches of the timed region / its wall time",
@@ -391,7 +397,7 @@ def main():
             c.close()
     for c in mctx:
         c.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
