@@ -5,10 +5,12 @@ Workload (config C3 of BASELINE.json, also run at N=1 because the 1M-descriptor 
 one 640x480 synthetic frame = 1000 ORB descriptors matched against the 1M-descriptor object DB
 (200 objects x 5000), Hamming brute force k=2, radius 35, then geometric verification.
 With N GPUs (tod_amd/sharded.py) the descriptor rows are split into N object-aligned shards and a step
-processes N frames, one per rank: descriptors are all-gathered, every rank matches all N frames against
+processes 16 frames per rank: descriptors are all-gathered, every rank matches all N x 16 frames against
 its shard, the per-shard candidates are exchanged with one RCCL collective (all-to-all by default: a rank only needs
 the candidates of its own frames; --exchange all_gather for the literal all-gather), and every rank merges (order:
-distance asc, global row asc) and verifies its own frames. Per-GPU work is constant as N grows.
+distance asc, global row asc) and verifies its own frames. Per-GPU work is constant as N grows. The collectives and
+the merge run on their own stream, double buffered, so that they overlap the DB passes of the neighbouring steps
+(--serial-exchange puts them back on the matcher's stream in program order).
 
 One JSON line on rank 0; see the task contract for the fields. `roofline` is for the dominant kernel
 (hamming_topk_tiles); `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
@@ -53,6 +55,9 @@ def parse():
     ap.add_argument("--exchange", choices=("all_to_all", "all_gather"), default="all_to_all",
                     help="several ranks: how the per-shard candidates travel. A rank only merges its own frames, so an "
                          "all-to-all moves 1/world of an all-gather's bytes over the point-to-point xGMI links")
+    ap.add_argument("--serial-exchange", action="store_true",
+                    help="several ranks: issue the collectives on the matcher's stream, in program order (gather -> match -> "
+                         "exchange -> merge), instead of on their own stream where they overlap the neighbouring DB passes")
     ap.add_argument("--matcher-contexts", type=int, default=1,
                     help="single device only: 2 alternates steps between two matcher contexts so that consecutive DB passes "
                          "overlap (+4 %% frames/s); off by default because a launch's own duration then no longer says what "
@@ -229,28 +234,84 @@ def main():
         stage_s["verify"] += time.perf_counter() - t
         return sum(len(p) for p in poses)
 
-    def match_step(i):
+    # Several ranks: the collectives and the merge run on their own stream (cstream), so that the DB pass of step i + 1
+    # follows that of step i without a gap. Order on cstream, identical on every rank: gather(0), gather(1), exchange(0),
+    # merge(0), gather(2), exchange(1), merge(1), ... -- one communicator, one stream, one order. Double-buffered
+    # q_all / keys / km; the events below are the only cross-stream edges:
+    #   gathered(i) -> match(i);  matched(i) -> exchange(i);  exchanged(i - 2) -> match(i) (keys buffer reuse);
+    #   gather(i + 2) overwrites q_all[i % 2] after exchange(i), which itself waited for match(i)  (stream order).
+    overlap = use_dist and not args.serial_exchange
+    if overlap:
+        cstream = torch.cuda.Stream(priority=-1)
+        cctx = capi.Context(local_rank, cstream.cuda_stream)
+        cctx.db_load(desc, pts, off, shard_rank=rank, shard_count=world)
+        q_all2 = [torch.empty((world, B, nq, 32), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        keys2 = [torch.empty((world * B * nq, k), dtype=torch.int64, device="cuda") for _ in range(2)]
+        km2 = [torch.empty((world, B * nq, k), dtype=torch.int64, device="cuda") for _ in range(2)]
+        keys_all2 = ([torch.empty((world, world, B * nq, k), dtype=torch.int64, device="cuda") for _ in range(2)]
+                     if args.exchange == "all_gather" else None)
+        ev_gathered, ev_exchanged = {}, {}
+
+    def issue_gather(i):
+        with torch.cuda.stream(cstream):
+            all_gather(q_all2[i % 2], Q_B[i % period])
+            ev_gathered[i] = torch.cuda.Event()
+            ev_gathered[i].record(cstream)
+
+    def match_step_overlapped(i, n_steps):
+        o = outs[i % D]
+        if i == 0:
+            ev_gathered.clear(); ev_exchanged.clear()
+            issue_gather(0)
+        if i + 1 < n_steps:
+            issue_gather(i + 1)
+        stream.wait_event(ev_gathered.pop(i))
+        if i - 2 in ev_exchanged:
+            stream.wait_event(ev_exchanged.pop(i - 2))
+        ctx.match_shard_device(q_all2[i % 2].data_ptr(), world * B * nq, k, args.radius, keys2[i % 2].data_ptr())
+        matched = torch.cuda.Event()
+        matched.record(stream)
+        with torch.cuda.stream(cstream):
+            cstream.wait_event(matched)
+            if args.exchange == "all_to_all":
+                all_to_all(km2[i % 2], keys2[i % 2])                               # keys is [frame owner][B*Q][k]
+                mine = km2[i % 2]
+            else:
+                all_gather(keys_all2[i % 2], keys2[i % 2])                         # [shard][rank][B*Q][k]
+                mine = km2[i % 2]
+                mine.copy_(keys_all2[i % 2][:, rank])
+            ev_exchanged[i] = torch.cuda.Event()
+            ev_exchanged[i].record(cstream)
+            cctx.merge_shards_device(mine.data_ptr(), world, B * nq, k, args.radius, o["counts"].data_ptr(),
+                                     o["matches"].data_ptr(), o["xyz"].data_ptr())
+        return cstream
+
+    def match_step(i, n_steps):
+        """Returns the stream on which this step's matcher outputs become complete."""
+        if overlap:
+            return match_step_overlapped(i, n_steps)
         o = outs[i % D]
         q = Q_B[i % period]
         if not use_dist:
             # single device: no key exchange; the B frames' descriptors share one pass over the DB
             mctx[i % len(mctx)].match_device(q.data_ptr(), B * nq, k, args.radius, o["counts"].data_ptr(),
                                              o["matches"].data_ptr(), o["xyz"].data_ptr())
+            return mstreams[i % len(mstreams)]
+        # tod_amd/sharded.py with B frames per rank, in program order on the matcher's stream: gather descriptors, match
+        # all world*B frames against this rank's shard, exchange the candidates, merge this rank's B frames
+        q_all = alloc((world, B, nq, 32), "uint8")
+        all_gather(q_all, q)
+        ctx.match_shard_device(q_all.data_ptr(), world * B * nq, k, args.radius, d_keys.data_ptr())
+        if args.exchange == "all_to_all":
+            km = alloc((world, B * nq, k), "int64")                             # chunk j <- shard j's keys of MY frames
+            all_to_all(km, d_keys)                                              # d_keys is [frame owner][B*Q][k]
         else:
-            # tod_amd/sharded.py with B frames per rank: gather descriptors, match all world*B frames against this
-            # rank's shard, all-gather the candidates, merge this rank's B frames
-            q_all = alloc((world, B, nq, 32), "uint8")
-            all_gather(q_all, q)
-            ctx.match_shard_device(q_all.data_ptr(), world * B * nq, k, args.radius, d_keys.data_ptr())
-            if args.exchange == "all_to_all":
-                km = alloc((world, B * nq, k), "int64")                             # chunk j <- shard j's keys of MY frames
-                all_to_all(km, d_keys)                                              # d_keys is [frame owner][B*Q][k]
-            else:
-                keys_all = alloc((world, world, B, nq, k), "int64")                 # [shard][rank][b][Q][k]
-                all_gather(keys_all, d_keys)
-                km = keys_all[:, rank].contiguous()                                 # [shard][B*Q][k]
-            ctx.merge_shards_device(km.data_ptr(), world, B * nq, k, args.radius, o["counts"].data_ptr(),
-                                    o["matches"].data_ptr(), o["xyz"].data_ptr())
+            keys_all = alloc((world, world, B, nq, k), "int64")                 # [shard][rank][b][Q][k]
+            all_gather(keys_all, d_keys)
+            km = keys_all[:, rank].contiguous()                                 # [shard][B*Q][k]
+        ctx.merge_shards_device(km.data_ptr(), world, B * nq, k, args.radius, o["counts"].data_ptr(),
+                                o["matches"].data_ptr(), o["xyz"].data_ptr())
+        return stream
 
     def run_steps(n_steps):
         """ORB(i) -> match(i) -> verify(i); ORB runs up to D steps ahead, the matcher up to D - 1 steps ahead of the verifier."""
@@ -266,11 +327,11 @@ def main():
                 if i + D < n_steps:
                     ofut[i + D] = opool.submit(orb_task, i + D)
             t = time.perf_counter()
-            match_step(i)
+            out_stream = match_step(i, n_steps)
             stage_s["match_issue"] += time.perf_counter() - t
             if do_verify:
                 ev = torch.cuda.Event()
-                ev.record(mstreams[i % len(mstreams)])   # the matcher outputs of this step are complete after this
+                ev.record(out_stream)                    # the matcher outputs of this step are complete after this
                 vfut[i] = vpool.submit(verify_task, i, ev)
         for i in sorted(vfut):
             n_pose_total[0] += vfut[i].result()
@@ -360,7 +421,8 @@ def main():
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
                        "poses_per_frame_rank0": n_pose_total[0] / max(n_steps_done[0] * B, 1),
                        "frames_per_rank_per_step": B,
-                       "pipeline": "3 stages on 3 streams, each one batched call per step: ORB | matcher | verifier",
+                       "pipeline": "3 stages on 3 streams, each one batched call per step: ORB | matcher | verifier" +
+                                   ("; collectives + merge on a 4th stream, overlapping the neighbouring DB passes" if overlap else ""),
                        "stage_ms_per_step": {key: 1e3 * v / max(args.steps, 1) for key, v in stage_s.items()},
                        "orb": "ORB-%d, 3 levels, scale 1.2 on the 8(d) synthetic image; %.0f keypoints/frame" %
                               (args.nq, n_kp_total[0] / max(n_steps_done[0] * B, 1)) if do_orb else None,
@@ -392,7 +454,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
                                                args.iterations, args.min_inliers)
         print(json.dumps(out))
-    for c in (octx, vctx):
+    for c in (octx, vctx, cctx if overlap else None):
         if c is not None:
             c.close()
     for c in mctx:
