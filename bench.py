@@ -319,13 +319,18 @@ def main():
         for j in range(min(D, n_steps)):
             if do_orb:
                 ofut[j] = opool.submit(orb_task, j)
+        def orb_done(j):                                              # wait for ORB batch j, keep ORB D batches ahead
+            if do_orb and j in ofut:
+                n_kp_total[0] += ofut.pop(j).result()
+                if j + D < n_steps:
+                    ofut[j + D] = opool.submit(orb_task, j + D)
+
         for i in range(n_steps):
             if do_verify and i - D in vfut:
                 n_pose_total[0] += vfut.pop(i - D).result()          # buffer set i % D is free again
-            if do_orb:
-                n_kp_total[0] += ofut.pop(i).result()
-                if i + D < n_steps:
-                    ofut[i + D] = opool.submit(orb_task, i + D)
+            orb_done(i)
+            if overlap:
+                orb_done(i + 1)                                       # the gather of step i + 1 is issued in step i
             t = time.perf_counter()
             out_stream = match_step(i, n_steps)
             stage_s["match_issue"] += time.perf_counter() - t
