@@ -324,11 +324,15 @@ __host__ __device__ inline uint32_t gate_small_bytes(uint32_t m) {           // 
 }
 // ext_adjc != nullptr: the m x MW matrix lives in global scratch (graphs beyond one CU's LDS); same code path,
 // the pointers are generic
-__device__ inline GateLds gate_carve(unsigned char* base, uint32_t m, uint32_t lds_bytes, u64* ext_adjc = nullptr) {
+// kExt is a template parameter so that, in the LDS instantiation, every pointer provably comes from the LDS allocation:
+// the compiler then emits ds_read/ds_write for the adjacency rows instead of flat loads (the rows are on the critical
+// path of Intersection and ColorSort)
+template <bool kExt>
+__device__ __forceinline__ GateLds gate_carve(unsigned char* base, uint32_t m, uint32_t lds_bytes, u64* ext_adjc = nullptr) {
   const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;
   unsigned char* const base0 = base;
   GateLds L;
-  if (ext_adjc) { L.adjc = ext_adjc; } else { L.adjc = reinterpret_cast<u64*>(base); base += 8u * m * MW; }
+  if constexpr (kExt) { L.adjc = ext_adjc; } else { L.adjc = reinterpret_cast<u64*>(base); base += 8u * m * MW; }
   L.mask = reinterpret_cast<u64*>(base); base += 8u * MW;
   L.C = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
   L.deg = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
@@ -825,6 +829,171 @@ struct EvalArgs {
   uint32_t stop_level;            // 0 = full evaluation, 1 = stop before the clique search (diagnostics)
 };
 
+// The gate of one hypothesis (sac_model_registration_graph.h:219-265): induced sample sub-graph of F, degree test,
+// maximum clique. Returns the consensus count to report (cnt, 0 = rejected, INT_MIN = error).
+template <bool kExt>
+__device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& F, uint32_t m, uint32_t it, uint32_t cnt,
+                                             unsigned char* lds_raw, uint16_t* stack) {
+  const uint32_t l = lane_id();
+  const ObjJob& job = A.job;
+  const uint32_t W = job.W;
+  int32_t result = (int32_t)cnt;
+  GateLds L = gate_carve<kExt>(lds_raw, m, A.lds_bytes, kExt ? A.adjc_scratch + (size_t)blockIdx.x * kAdjcScratchWords : nullptr);
+  const uint32_t MW = (m + 63u) / 64u;
+  const long long t_start = A.dbg ? clock64() : 0;   // phase stamps (diagnostics builds of the call only)
+  // F in ascending order (:219) -> graph index = rank (:241-243)
+  uint32_t base = 0;
+#pragma unroll
+  for (int j = 0; j < kWPL; ++j) {
+    const uint32_t c = (uint32_t)__popcll(F.w[j]);
+    const uint32_t incl = wave_incl_scan(c);
+    u64 w = F.w[j];
+    uint32_t o = base + incl - c;
+    while (w) {
+      const uint32_t bit = (uint32_t)__ffsll((long long)w) - 1u;
+      L.flist[o++] = (uint16_t)((j * 64u + l) * 64u + bit);
+      w &= w - 1ull;
+    }
+    base += uni(__shfl(incl, 63));
+  }
+  __syncthreads();
+  // induced sample sub-graph (:245-256) as an m x MW bit matrix in LDS, plus vertex degrees
+  const long long t_flist = A.dbg ? clock64() : 0;
+  bool bad_index = false;
+  for (uint32_t g = l; g < m; g += 64u) bad_index = bad_index || L.flist[g] >= job.n;
+  bad_index = __ballot(bad_index) != 0ull;           // never dereference an unchecked index
+  if (bad_index && l == 0) { atomicExch(&A.status[0], 4u); A.status[6] = m; A.status[7] = it; }
+  if (!bad_index && A.stop_level != 3u) {
+    if (W <= 8u) {
+      // n <= 512: lane = one row of the induced graph, its whole sample row (<= 16 dwords) in registers;
+      // the members of F are walked once per 64 rows, one v_readlane + bit-field extract + shift-or each.
+      // F is ascending, so the source dword only ever moves forward.
+      uint32_t fl[kRegChunks];
+#pragma unroll
+      for (uint32_t c = 0; c < kRegChunks; ++c) fl[c] = (c * 64u + l) < m ? L.flist[c * 64u + l] : 0u;
+      for (uint32_t rc = 0; rc < MW; ++rc) {
+        const uint32_t grow = rc * 64u + l;
+        const bool have = grow < m;
+        const uint32_t myv = have ? (uint32_t)L.flist[grow] : 0u;
+        uint32_t rw[16];
+        {
+          const uint32_t* src = reinterpret_cast<const uint32_t*>(job.samp + (size_t)myv * W);
+#pragma unroll
+          for (uint32_t w = 0; w < 16u; ++w) rw[w] = (have && w < 2u * W) ? src[w] : 0u;
+        }
+        uint32_t out[2u * kRegChunks];
+#pragma unroll
+        for (uint32_t c = 0; c < 2u * kRegChunks; ++c) out[c] = 0u;
+        uint32_t wcur = 0xFFFFFFFFu, word = 0u;
+#pragma unroll
+        for (uint32_t cj = 0; cj < 2u * kRegChunks; ++cj) {      // 32 positions per step: the target dword is static
+          if (cj * 32u < m) {                                     // wave-uniform
+            const uint32_t cnt = min(32u, m - cj * 32u);
+            for (uint32_t lj = 0; lj < cnt; ++lj) {
+              const uint32_t h = rdlane(fl[cj >> 1], (cj & 1u) * 32u + lj);
+              if ((h >> 5) != wcur) {                             // wave-uniform, at most 2 W times per 64 rows
+                wcur = h >> 5;
+#pragma unroll
+                for (uint32_t w = 0; w < 16u; ++w) if (wcur == w) word = rw[w];
+              }
+              out[cj] |= ((word >> (h & 31u)) & 1u) << lj;
+            }
+          }
+        }
+        if (have) {
+          uint32_t d = 0;
+#pragma unroll
+          for (uint32_t c = 0; c < kRegChunks; ++c) {
+            if (c < MW) {
+              const u64 wv = ((u64)out[2u * c + 1u] << 32) | out[2u * c];
+              L.adjc[(size_t)grow * MW + c] = wv;
+              d += (uint32_t)__popcll(wv);
+            }
+          }
+          L.deg[grow] = d;
+        }
+      }
+    } else if (W <= 64u) {
+      // lane l holds word l of a row; kRows rows are in flight so the global latency is paid once per group
+      constexpr uint32_t kRows = 8;
+      for (uint32_t g0 = 0; g0 < m; g0 += kRows) {
+        u64 rw[kRows];
+#pragma unroll
+        for (uint32_t j = 0; j < kRows; ++j) {
+          const uint32_t g = g0 + j;
+          rw[j] = (g < m && l < W) ? job.samp[(size_t)uni(L.flist[g < m ? g : 0u]) * W + l] : 0ull;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < kRows; ++j) {
+          const uint32_t g = g0 + j;
+          if (g < m) {                               // wave-uniform
+            uint32_t d = 0;
+            for (uint32_t c = 0; c < MW; ++c) {
+              const uint32_t pos = c * 64u + l;
+              const uint32_t h = pos < m ? L.flist[pos] : 0u;
+              const bool adj = row_test(rw[j], h) && pos < m;
+              const u64 bal = __ballot(adj);
+              if (l == 0) L.adjc[(size_t)g * MW + c] = bal;
+              d += (uint32_t)__popcll(bal);
+            }
+            if (l == 0) L.deg[g] = d;
+          }
+        }
+      }
+    } else {
+      for (uint32_t g = 0; g < m; ++g) {
+        const u64* row = job.samp + (size_t)uni(L.flist[g]) * W;
+        uint32_t d = 0;
+        for (uint32_t c = 0; c < MW; ++c) {
+          const uint32_t pos = c * 64u + l;
+          bool adj = false;
+          if (pos < m) { const uint32_t h = L.flist[pos]; adj = (row[h >> 6] >> (h & 63u)) & 1ull; }
+          const u64 bal = __ballot(adj);
+          if (l == 0) L.adjc[(size_t)g * MW + c] = bal;
+          d += (uint32_t)__popcll(bal);
+        }
+        if (l == 0) L.deg[g] = d;
+      }
+    }
+  }
+  __syncthreads();
+  const long long t_adjc = A.dbg ? clock64() : 0;
+  if (A.dbg) {
+    uint32_t* d = A.dbg + (size_t)it * A.dbg_stride;
+    if (l == 0) { d[0] = cnt; d[1] = m; }
+    for (uint32_t g = l; g < m && 2u + 2u * g + 1u < A.dbg_stride; g += 64u) { d[2 + 2 * g] = L.flist[g]; d[3 + 2 * g] = L.deg[g]; }
+  }
+  // "make sure that those inliers have enough neighbors within the inliers themselves" (:221-238)
+  bool any = false;
+  for (uint32_t g = l; g < m; g += 64u) any = any || L.deg[g] > kGateMinimal;
+  if (bad_index) {
+    result = INT_MIN;
+  } else if (A.stop_level != 0u) {
+    result = -(int32_t)m;
+  } else if (__ballot(any) == 0ull) {
+    result = 0;
+  } else {
+    int err = 0;
+    uint32_t steps = 0;
+    uint32_t* prof = (A.dbg && A.dbg_stride >= 16u) ? A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 12u) : nullptr;
+    const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, &steps, prof);
+    if (A.dbg && l == 0 && A.dbg_stride >= 8u) {
+      uint32_t* d = A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 6u);
+      d[0] = (uint32_t)(t_flist - t_start); d[1] = (uint32_t)(t_adjc - t_flist);
+      d[2] = (uint32_t)(clock64() - t_adjc); d[3] = steps; d[4] = q;
+    }
+    if (err) {
+      if (l == 0) atomicExch(&A.status[0], 1u);
+      result = INT_MIN;
+    } else if (q <= kGateMinimal) {
+      result = 0;                                    // :260-265
+    }
+    if (l == 0) atomicAdd(&A.status[1], 1u);
+  }
+  __syncthreads();
+  return result;
+}
+
 // launched with 64 threads; the bound is deliberately larger so that hipcc keeps __syncthreads() as a real,
 // convergent s_barrier (with a 64-thread bound it drops the barrier and may split the lanes of the wave)
 __global__ __launch_bounds__(128) void eval_kernel(Slots<EvalArgs> SL) {
@@ -876,160 +1045,9 @@ __global__ __launch_bounds__(128) void eval_kernel(Slots<EvalArgs> SL) {
           result = INT_MIN + 1;                            // filled in by the second pass
         }
       } else {
-        const bool ext = gate_lds_bytes(m) > A.lds_bytes;   // third tier: adjacency matrix in global scratch
-        GateLds L = gate_carve(lds_raw, m, A.lds_bytes, ext ? A.adjc_scratch + (size_t)blockIdx.x * kAdjcScratchWords : nullptr);
-        const uint32_t MW = (m + 63u) / 64u;
-        const long long t_start = A.dbg ? clock64() : 0;   // phase stamps (diagnostics builds of the call only)
-        // F in ascending order (:219) -> graph index = rank (:241-243)
-        uint32_t base = 0;
-#pragma unroll
-        for (int j = 0; j < kWPL; ++j) {
-          const uint32_t c = (uint32_t)__popcll(F.w[j]);
-          const uint32_t incl = wave_incl_scan(c);
-          u64 w = F.w[j];
-          uint32_t o = base + incl - c;
-          while (w) {
-            const uint32_t bit = (uint32_t)__ffsll((long long)w) - 1u;
-            L.flist[o++] = (uint16_t)((j * 64u + l) * 64u + bit);
-            w &= w - 1ull;
-          }
-          base += uni(__shfl(incl, 63));
-        }
-        __syncthreads();
-        // induced sample sub-graph (:245-256) as an m x MW bit matrix in LDS, plus vertex degrees
-        const long long t_flist = A.dbg ? clock64() : 0;
-        bool bad_index = false;
-        for (uint32_t g = l; g < m; g += 64u) bad_index = bad_index || L.flist[g] >= job.n;
-        bad_index = __ballot(bad_index) != 0ull;           // never dereference an unchecked index
-        if (bad_index && l == 0) { atomicExch(&A.status[0], 4u); A.status[6] = m; A.status[7] = it; }
-        if (!bad_index && A.stop_level != 3u) {
-          if (W <= 8u) {
-            // n <= 512: lane = one row of the induced graph, its whole sample row (<= 16 dwords) in registers;
-            // the members of F are walked once per 64 rows, one v_readlane + bit-field extract + shift-or each.
-            // F is ascending, so the source dword only ever moves forward.
-            uint32_t fl[kRegChunks];
-#pragma unroll
-            for (uint32_t c = 0; c < kRegChunks; ++c) fl[c] = (c * 64u + l) < m ? L.flist[c * 64u + l] : 0u;
-            for (uint32_t rc = 0; rc < MW; ++rc) {
-              const uint32_t grow = rc * 64u + l;
-              const bool have = grow < m;
-              const uint32_t myv = have ? (uint32_t)L.flist[grow] : 0u;
-              uint32_t rw[16];
-              {
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(job.samp + (size_t)myv * W);
-#pragma unroll
-                for (uint32_t w = 0; w < 16u; ++w) rw[w] = (have && w < 2u * W) ? src[w] : 0u;
-              }
-              uint32_t out[2u * kRegChunks];
-#pragma unroll
-              for (uint32_t c = 0; c < 2u * kRegChunks; ++c) out[c] = 0u;
-              uint32_t wcur = 0xFFFFFFFFu, word = 0u;
-#pragma unroll
-              for (uint32_t cj = 0; cj < 2u * kRegChunks; ++cj) {      // 32 positions per step: the target dword is static
-                if (cj * 32u < m) {                                     // wave-uniform
-                  const uint32_t cnt = min(32u, m - cj * 32u);
-                  for (uint32_t lj = 0; lj < cnt; ++lj) {
-                    const uint32_t h = rdlane(fl[cj >> 1], (cj & 1u) * 32u + lj);
-                    if ((h >> 5) != wcur) {                             // wave-uniform, at most 2 W times per 64 rows
-                      wcur = h >> 5;
-#pragma unroll
-                      for (uint32_t w = 0; w < 16u; ++w) if (wcur == w) word = rw[w];
-                    }
-                    out[cj] |= ((word >> (h & 31u)) & 1u) << lj;
-                  }
-                }
-              }
-              if (have) {
-                uint32_t d = 0;
-#pragma unroll
-                for (uint32_t c = 0; c < kRegChunks; ++c) {
-                  if (c < MW) {
-                    const u64 wv = ((u64)out[2u * c + 1u] << 32) | out[2u * c];
-                    L.adjc[(size_t)grow * MW + c] = wv;
-                    d += (uint32_t)__popcll(wv);
-                  }
-                }
-                L.deg[grow] = d;
-              }
-            }
-          } else if (W <= 64u) {
-            // lane l holds word l of a row; kRows rows are in flight so the global latency is paid once per group
-            constexpr uint32_t kRows = 8;
-            for (uint32_t g0 = 0; g0 < m; g0 += kRows) {
-              u64 rw[kRows];
-#pragma unroll
-              for (uint32_t j = 0; j < kRows; ++j) {
-                const uint32_t g = g0 + j;
-                rw[j] = (g < m && l < W) ? job.samp[(size_t)uni(L.flist[g < m ? g : 0u]) * W + l] : 0ull;
-              }
-#pragma unroll
-              for (uint32_t j = 0; j < kRows; ++j) {
-                const uint32_t g = g0 + j;
-                if (g < m) {                               // wave-uniform
-                  uint32_t d = 0;
-                  for (uint32_t c = 0; c < MW; ++c) {
-                    const uint32_t pos = c * 64u + l;
-                    const uint32_t h = pos < m ? L.flist[pos] : 0u;
-                    const bool adj = row_test(rw[j], h) && pos < m;
-                    const u64 bal = __ballot(adj);
-                    if (l == 0) L.adjc[(size_t)g * MW + c] = bal;
-                    d += (uint32_t)__popcll(bal);
-                  }
-                  if (l == 0) L.deg[g] = d;
-                }
-              }
-            }
-          } else {
-            for (uint32_t g = 0; g < m; ++g) {
-              const u64* row = job.samp + (size_t)uni(L.flist[g]) * W;
-              uint32_t d = 0;
-              for (uint32_t c = 0; c < MW; ++c) {
-                const uint32_t pos = c * 64u + l;
-                bool adj = false;
-                if (pos < m) { const uint32_t h = L.flist[pos]; adj = (row[h >> 6] >> (h & 63u)) & 1ull; }
-                const u64 bal = __ballot(adj);
-                if (l == 0) L.adjc[(size_t)g * MW + c] = bal;
-                d += (uint32_t)__popcll(bal);
-              }
-              if (l == 0) L.deg[g] = d;
-            }
-          }
-        }
-        __syncthreads();
-        const long long t_adjc = A.dbg ? clock64() : 0;
-        if (A.dbg) {
-          uint32_t* d = A.dbg + (size_t)it * A.dbg_stride;
-          if (l == 0) { d[0] = cnt; d[1] = m; }
-          for (uint32_t g = l; g < m && 2u + 2u * g + 1u < A.dbg_stride; g += 64u) { d[2 + 2 * g] = L.flist[g]; d[3 + 2 * g] = L.deg[g]; }
-        }
-        // "make sure that those inliers have enough neighbors within the inliers themselves" (:221-238)
-        bool any = false;
-        for (uint32_t g = l; g < m; g += 64u) any = any || L.deg[g] > kGateMinimal;
-        if (bad_index) {
-          result = INT_MIN;
-        } else if (A.stop_level != 0u) {
-          result = -(int32_t)m;
-        } else if (__ballot(any) == 0ull) {
-          result = 0;
-        } else {
-          int err = 0;
-          uint32_t steps = 0;
-          uint32_t* prof = (A.dbg && A.dbg_stride >= 16u) ? A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 12u) : nullptr;
-          const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, &steps, prof);
-          if (A.dbg && l == 0 && A.dbg_stride >= 8u) {
-            uint32_t* d = A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 6u);
-            d[0] = (uint32_t)(t_flist - t_start); d[1] = (uint32_t)(t_adjc - t_flist);
-            d[2] = (uint32_t)(clock64() - t_adjc); d[3] = steps; d[4] = q;
-          }
-          if (err) {
-            if (l == 0) atomicExch(&A.status[0], 1u);
-            result = INT_MIN;
-          } else if (q <= kGateMinimal) {
-            result = 0;                                    // :260-265
-          }
-          if (l == 0) atomicAdd(&A.status[1], 1u);
-        }
-        __syncthreads();
+        // third tier: adjacency matrix in global scratch
+        result = gate_lds_bytes(m) > A.lds_bytes ? gate_eval<true>(A, F, m, it, cnt, lds_raw, stack)
+                                                 : gate_eval<false>(A, F, m, it, cnt, lds_raw, stack);
       }
     }
     if (l == 0) {
@@ -1046,7 +1064,7 @@ __global__ __launch_bounds__(128) void clique_test_kernel(const u64* adj, uint32
                                                          uint32_t* out) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const uint32_t l = lane_id();
-  GateLds L = gate_carve(lds_raw, m, lds_bytes);
+  GateLds L = gate_carve<false>(lds_raw, m, lds_bytes);
   const uint32_t MW = (m + 63u) / 64u;
   for (uint32_t i = l; i < m * MW; i += 64u) L.adjc[i] = adj[i];
   __syncthreads();
