@@ -412,7 +412,10 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radi
   TOD_HIP(hipMemsetAsync(ctx->m_bound.p, 0xFF, (size_t)nq_pad * sizeof(uint32_t), ctx->stream));
   int slot = -1;
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
-  auto kern = cut <= 38u ? hamming_topk_tiles<K, 2> : (cut <= 46u ? hamming_topk_tiles<K, 1> : hamming_topk_tiles<K, 0>);
+  // every schedule is exact; TODHIP_K4_MODE=0/1/2 overrides the choice (diagnostics: tools/k4_on_correlated_descriptors.py)
+  static const int env_mode = getenv("TODHIP_K4_MODE") ? atoi(getenv("TODHIP_K4_MODE")) : -1;
+  const int mode = (env_mode >= 0 && env_mode <= 2 && cut <= 256u) ? env_mode : (cut <= 38u ? 2 : (cut <= 46u ? 1 : 0));
+  auto kern = mode == 2 ? hamming_topk_tiles<K, 2> : (mode == 1 ? hamming_topk_tiles<K, 1> : hamming_topk_tiles<K, 0>);
   hipLaunchKernelGGL(kern, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw,
                      blocks_per_xcd, tiles_per_xcd, cut, ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>());
