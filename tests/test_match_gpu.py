@@ -254,3 +254,33 @@ def test_batch_of_frames_in_one_launch_equals_frame_by_frame(ctx):
     for f in (0, 9):
         rc, row_ptr, m, xyz = O.match(desc, off, pts, frames[f]["q_desc"], k, 35)
         assert np.array_equal(cb[f * nq:(f + 1) * nq].cpu().numpy(), np.diff(row_ptr.astype(np.int64)))
+
+
+def test_ten_million_row_database_properties(ctx):
+    """Beyond the benchmark's size: 10M rows (2000 objects x 5000, 320 MB of descriptors) in one shard -- row indices past
+    2^23, the tile count at its cap. Planted rows are found first, every distance is the pair's true distance, lists
+    ascend, and 16 queries equal the oracle bit for bit. Then the same DB cut into 3 shards and merged."""
+    desc, pts, off = synth.make_db(2000)
+    assert desc.shape[0] == 10_000_000
+    fr = synth.make_frame(desc, pts, off, 512, frame=3, visible_object=1777)
+    planted = fr["truth_rows"] >= 0
+    assert planted.sum() > 100 and fr["truth_rows"][planted].min() >= 1777 * 5000
+    ctx.db_load(desc, pts, off)
+    row_ptr, m, xyz = ctx.match(fr["q_desc"], 3, 255)
+    assert np.array_equal(np.diff(row_ptr.astype(np.int64)), np.full(512, 3))
+    rows = off[m["imgIdx"]].astype(np.int64) + m["trainIdx"]
+    lut = np.array([bin(i).count("1") for i in range(256)], np.uint32)
+    true_d = lut[np.bitwise_xor(desc[rows], fr["q_desc"][m["queryIdx"]])].sum(axis=1)
+    assert np.array_equal(true_d.astype(np.float32), m["distance"])
+    d3, r3 = m["distance"].reshape(512, 3), rows.reshape(512, 3)
+    for a in range(2):
+        assert ((d3[:, a] < d3[:, a + 1]) | ((d3[:, a] == d3[:, a + 1]) & (r3[:, a] < r3[:, a + 1]))).all()
+    assert np.array_equal(r3[planted, 0], fr["truth_rows"][planted])
+    assert np.array_equal(xyz, pts[rows])
+    sub = np.arange(0, 512, 32)
+    keys = O.knn_keys(desc, fr["q_desc"][sub], 3)
+    assert np.array_equal(keys >> np.uint64(32), d3[sub].astype(np.uint64))
+    assert np.array_equal(keys & np.uint64(0xFFFFFFFF), r3[sub].astype(np.uint64))
+    counts, ms, xyzs, infos = _shard_merge(desc, pts, off, fr["q_desc"], 3, 255, 3)
+    assert np.array_equal(ms["trainIdx"], m["trainIdx"]) and np.array_equal(ms["imgIdx"], m["imgIdx"])
+    assert np.array_equal(ms["distance"], m["distance"]) and sum(i["shard_rows"] for i in infos) == 10_000_000
