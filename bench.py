@@ -456,7 +456,9 @@ def main():
                               "distances_per_launch": distances, "valu_ops_per_distance": laneops,
                               "valu_ops_source": laneops_src, "dense_ops_per_distance": LANEOPS_DENSE},
         }
-        if not args.no_cpu_baseline:
+        if world > 1:
+            out["cpu_baseline"] = None                                      # timed at N = 1 only (rank 0)
+        elif not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
                                                args.iterations, args.min_inliers)
         print(json.dumps(out))
