@@ -12,6 +12,15 @@ from test_verify_gpu import _compare_frame
 
 pytestmark = pytest.mark.gpu
 
+# TOD_FUZZ_OFFSET / TOD_FUZZ_SCALE widen the sweep for a one-off hunt (e.g. OFFSET=1000 SCALE=20): other seeds, more of them
+import os
+_OFF = int(os.environ.get("TOD_FUZZ_OFFSET", "0"))
+_SCALE = int(os.environ.get("TOD_FUZZ_SCALE", "1"))
+
+
+def _seeds(n):
+    return range(_OFF, _OFF + n * _SCALE)
+
 
 @pytest.fixture(scope="module")
 def ctx():
@@ -20,7 +29,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", _seeds(48))
 def test_matcher_random_configurations(ctx, seed):
     rng = np.random.Generator(np.random.PCG64(31000 + seed))
     n_obj = int(rng.integers(1, 7))
@@ -54,7 +63,7 @@ def test_matcher_random_configurations(ctx, seed):
     match_same(ctx, np.ascontiguousarray(desc), pts, off, np.ascontiguousarray(q), k, radius)
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", _seeds(48))
 def test_verifier_random_scenes(ctx, seed):
     rng = np.random.Generator(np.random.PCG64(32000 + seed))
     n_objects = int(rng.integers(1, 9))
@@ -77,7 +86,7 @@ def test_verifier_random_scenes(ctx, seed):
         assert e.value.status == capi.ECAPACITY
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", _seeds(24))
 def test_orb_random_shapes(ctx, seed):
     rng = np.random.Generator(np.random.PCG64(33000 + seed))
     H, W = int(rng.integers(70, 620)), int(rng.integers(70, 820))
@@ -87,7 +96,7 @@ def test_orb_random_shapes(ctx, seed):
     orb_same(ctx, img, int(rng.integers(1, 1600)), int(rng.integers(1, 9)), float(rng.choice([1.1, 1.2, 1.3, 1.5, 2.0])))
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _seeds(8))
 def test_verifier_random_batches_against_the_oracle(ctx, seed):
     """todhip_verify_batch_device on 2..24 random frames (more than one launch group when > 16) that share a model
     set but differ in what is visible, in noise, missing depth and generator seed: every frame equals the oracle's
@@ -131,7 +140,7 @@ def test_verifier_random_batches_against_the_oracle(ctx, seed):
             assert np.abs(a["R"] - b["R"]).max() < POSE_TOL and np.abs(a["t"] - b["t"]).max() < POSE_TOL
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _seeds(12))
 def test_sharded_matcher_random_configurations(ctx, seed):
     """Object-aligned shards (1..9 of them, more shards than objects included) + merge == the unsharded oracle, for
     random object sizes (empty objects too), k, radius and tie-heavy descriptors."""
@@ -160,7 +169,7 @@ def test_sharded_matcher_random_configurations(ctx, seed):
     assert sum(i["shard_rows"] for i in infos) == n
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_orb_random_batches(ctx, seed):
     """todhip_orb_batch_device on 1..20 frames of a random common shape == the CPU restatement frame by frame."""
     import torch
@@ -179,7 +188,7 @@ def test_orb_random_batches(ctx, seed):
         assert np.array_equal(aux[f, :n[f]].cpu().numpy()[:, [0, 2, 3]], o_aux[:, [0, 2, 3]])
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", _seeds(6))
 def test_l2_random_configurations(ctx, seed):
     """Float-descriptor matcher on random sizes, k, radii and value ranges (integer-valued, tiny, huge norms)."""
     from test_l2_gpu import _assert_same as l2_same
