@@ -546,13 +546,16 @@ __device__ __forceinline__ void colour_sort_regs(const GateLds& L, uint16_t* lis
 // Same colouring for lists of 65..512 vertices when the launch has LDS to spare: the position-space rows go to
 // LDS (ap[i * nch + c]), Q and the uncoloured set are spread over the lanes (lane c = positions 64c..64c+63). A pick
 // is a ballot, two find-first-set, one LDS row read and an and-not, whatever the list length.
+// NCH = number of 64-position chunks of the list, a template parameter: the per-chunk work is straight-line code (the
+// wave-uniform `c < nch` tests of a run-time chunk count compiled to a branch pair per chunk and row)
+template <uint32_t NCH>
 __device__ __forceinline__ void colour_sort_rows(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW) {
   const uint32_t l = lane_id();
-  const uint32_t nch = (r + 63u) / 64u;
+  constexpr uint32_t nch = NCH;
   u64* ap = L.aprime;
-  uint32_t hoff[kRegChunks], hbit[kRegChunks];             // word offset and bit of this lane's member of every chunk
+  uint32_t hoff[NCH], hbit[NCH];             // word offset and bit of this lane's member of every chunk
 #pragma unroll
-  for (uint32_t c = 0; c < kRegChunks; ++c) {
+  for (uint32_t c = 0; c < NCH; ++c) {
     const uint32_t h = (c * 64u + l) < r ? list[c * 64u + l] : 0xFFFFFFFFu;
     hoff[c] = h == 0xFFFFFFFFu ? 0xFFFFFFFFu : (h >> 6);
     hbit[c] = h & 63u;
@@ -561,37 +564,34 @@ __device__ __forceinline__ void colour_sort_rows(const GateLds& L, uint16_t* lis
   for (uint32_t ci = 0; ci < nch; ++ci) {
     const uint32_t cnt = min(64u, r - ci * 64u);
     const uint32_t myv = (ci * 64u + l) < r ? list[ci * 64u + l] : 0u;
-    uint32_t acc_lo[kRegChunks], acc_hi[kRegChunks];        // row (64 ci + l)
+    uint32_t acc_lo[NCH], acc_hi[NCH];                      // row (64 ci + l)
 #pragma unroll
-    for (uint32_t c = 0; c < kRegChunks; ++c) { acc_lo[c] = 0u; acc_hi[c] = 0u; }
+    for (uint32_t c = 0; c < NCH; ++c) { acc_lo[c] = 0u; acc_hi[c] = 0u; }
     for (uint32_t li0 = 0; li0 < cnt; li0 += kInFlight) {
-      u64 wv[kInFlight][kRegChunks];
+      u64 wv[kInFlight][NCH];
 #pragma unroll
       for (uint32_t jj = 0; jj < kInFlight; ++jj) {
         const uint32_t gi = rdlane(myv, min(li0 + jj, cnt - 1u));
         const u64* grow = L.adjc + (size_t)gi * MW;
 #pragma unroll
-        for (uint32_t c = 0; c < kRegChunks; ++c)
-          wv[jj][c] = (c < nch && hoff[c] != 0xFFFFFFFFu) ? grow[hoff[c]] : 0ull;
+        for (uint32_t c = 0; c < NCH; ++c)
+          wv[jj][c] = hoff[c] != 0xFFFFFFFFu ? grow[hoff[c]] : 0ull;
       }
 #pragma unroll
       for (uint32_t jj = 0; jj < kInFlight; ++jj) {
         const uint32_t li = li0 + jj;
         if (li < cnt) {                                    // wave-uniform
 #pragma unroll
-          for (uint32_t c = 0; c < kRegChunks; ++c) {
-            if (c < nch) {
-              const u64 bal = __ballot(((wv[jj][c] >> hbit[c]) & 1ull) != 0ull);
-              if (l == li) { acc_lo[c] = (uint32_t)bal; acc_hi[c] = (uint32_t)(bal >> 32); }
-            }
+          for (uint32_t c = 0; c < NCH; ++c) {
+            const u64 bal = __ballot(((wv[jj][c] >> hbit[c]) & 1ull) != 0ull);
+            if (l == li) { acc_lo[c] = (uint32_t)bal; acc_hi[c] = (uint32_t)(bal >> 32); }
           }
         }
       }
     }
     if (ci * 64u + l < r) {
 #pragma unroll
-      for (uint32_t c = 0; c < kRegChunks; ++c)
-        if (c < nch) ap[(size_t)(ci * 64u + l) * nch + c] = ((u64)acc_hi[c] << 32) | acc_lo[c];
+      for (uint32_t c = 0; c < NCH; ++c) ap[(size_t)(ci * 64u + l) * nch + c] = ((u64)acc_hi[c] << 32) | acc_lo[c];
     }
   }
   __syncthreads();
@@ -620,12 +620,12 @@ __device__ __forceinline__ void colour_sort_rows(const GateLds& L, uint16_t* lis
   }
   if (l < (outpos & 63u)) { L.keys[(outpos & ~63u) + l] = mypos; L.C[(outpos & ~63u) + l] = myk; }
   __syncthreads();
-  uint16_t moved[kRegChunks];
+  uint16_t moved[NCH];
 #pragma unroll
-  for (uint32_t c = 0; c < kRegChunks; ++c) moved[c] = (c * 64u + l) < r ? list[L.keys[c * 64u + l]] : (uint16_t)0;
+  for (uint32_t c = 0; c < NCH; ++c) moved[c] = (c * 64u + l) < r ? list[L.keys[c * 64u + l]] : (uint16_t)0;
   __syncthreads();
 #pragma unroll
-  for (uint32_t c = 0; c < kRegChunks; ++c)
+  for (uint32_t c = 0; c < NCH; ++c)
     if ((c * 64u + l) < r) list[c * 64u + l] = moved[c];
   __syncthreads();
 }
@@ -638,8 +638,32 @@ __device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, ui
     __syncthreads();
     return;
   }
+  if (r <= 2u) {
+    // one or two vertices (about half of all calls deep in the tree): the order cannot change; the second vertex opens
+    // class 2 iff it is adjacent to the first
+    if (l == 0) {
+      L.C[0] = 1u;
+      if (r == 2u) {
+        const uint32_t a = list[0], b = list[1];
+        L.C[1] = ((L.adjc[(size_t)a * MW + (b >> 6)] >> (b & 63u)) & 1ull) ? 2u : 1u;
+      }
+    }
+    __syncthreads();
+    return;
+  }
   if (r <= 64u) { colour_sort_regs<1>(L, list, r, MW); return; }
-  if (r <= 512u && L.aprime) { colour_sort_rows(L, list, r, MW); return; }
+  if (r <= 512u && L.aprime) {
+    switch ((r + 63u) / 64u) {                            // wave-uniform
+      case 2: colour_sort_rows<2>(L, list, r, MW); break;
+      case 3: colour_sort_rows<3>(L, list, r, MW); break;
+      case 4: colour_sort_rows<4>(L, list, r, MW); break;
+      case 5: colour_sort_rows<5>(L, list, r, MW); break;
+      case 6: colour_sort_rows<6>(L, list, r, MW); break;
+      case 7: colour_sort_rows<7>(L, list, r, MW); break;
+      default: colour_sort_rows<8>(L, list, r, MW); break;
+    }
+    return;
+  }
   if (r <= 256u) { colour_sort_regs<4>(L, list, r, MW); return; }
   if (r <= 512u) { colour_sort_regs<8>(L, list, r, MW); return; }
   const uint32_t nchunks = (r + 63u) / 64u;
