@@ -384,34 +384,47 @@ constexpr uint32_t kRegChunks = 8;                         // register paths cov
 
 // DegreeSort (maximum_clique.cpp:263-284): (degree inside the list, vertex) ascending, then reversed.
 // deg[] must hold the degree of list[i] at position i. Rank by counting; keys are unique.
+// keys stay in registers (lane l: positions l, l + 64, ...); every key is broadcast once with v_readlane. NCH = chunks of 64
+// positions, a template parameter so that the per-key work is straight-line code over exactly NCH registers.
+template <uint32_t NCH>
+__device__ __forceinline__ void rank_sort_regs(uint16_t* list, const uint32_t* deg, uint32_t r) {
+  const uint32_t l = lane_id();
+  uint32_t kreg[NCH], rank[NCH];
+#pragma unroll
+  for (uint32_t c = 0; c < NCH; ++c) {
+    const uint32_t i = c * 64u + l;
+    kreg[c] = i < r ? ((deg[i] << 16) | list[i]) : 0u;
+    rank[c] = 0u;
+  }
+#pragma unroll
+  for (uint32_t cj = 0; cj < NCH; ++cj) {
+    const uint32_t cnt = min(64u, r - cj * 64u);           // r > 64 (NCH - 1): every chunk has members
+    for (uint32_t lj = 0; lj < cnt; ++lj) {
+      const uint32_t kj = rdlane(kreg[cj], lj);
+#pragma unroll
+      for (uint32_t c = 0; c < NCH; ++c) rank[c] += (kj > kreg[c]) ? 1u : 0u;
+    }
+  }
+  __syncthreads();                                         // every lane holds its keys: the list can be overwritten
+#pragma unroll
+  for (uint32_t c = 0; c < NCH; ++c)
+    if (c * 64u + l < r) list[rank[c]] = (uint16_t)(kreg[c] & 0xFFFFu);
+  __syncthreads();
+}
+
 __device__ __forceinline__ void rank_sort_desc(uint16_t* list, uint16_t* tmp, const uint32_t* deg, uint32_t r, uint32_t* keys) {
   const uint32_t l = lane_id();
   if (r <= kRegChunks * 64u) {
-    // keys stay in registers (lane l: positions l, l + 64, ...); every key is broadcast once with v_readlane
-    const uint32_t nch = (r + 63u) / 64u;
-    uint32_t kreg[kRegChunks], rank[kRegChunks];
-#pragma unroll
-    for (uint32_t c = 0; c < kRegChunks; ++c) {
-      const uint32_t i = c * 64u + l;
-      kreg[c] = i < r ? ((deg[i] << 16) | list[i]) : 0u;
-      rank[c] = 0u;
+    switch ((r + 63u) / 64u) {                             // wave-uniform
+      case 0: case 1: rank_sort_regs<1>(list, deg, r); break;
+      case 2: rank_sort_regs<2>(list, deg, r); break;
+      case 3: rank_sort_regs<3>(list, deg, r); break;
+      case 4: rank_sort_regs<4>(list, deg, r); break;
+      case 5: rank_sort_regs<5>(list, deg, r); break;
+      case 6: rank_sort_regs<6>(list, deg, r); break;
+      case 7: rank_sort_regs<7>(list, deg, r); break;
+      default: rank_sort_regs<8>(list, deg, r); break;
     }
-#pragma unroll
-    for (uint32_t cj = 0; cj < kRegChunks; ++cj) {
-      if (cj < nch) {                                      // wave-uniform
-        const uint32_t cnt = min(64u, r - cj * 64u);
-        for (uint32_t lj = 0; lj < cnt; ++lj) {
-          const uint32_t kj = rdlane(kreg[cj], lj);
-#pragma unroll
-          for (uint32_t c = 0; c < kRegChunks; ++c) rank[c] += (kj > kreg[c]) ? 1u : 0u;
-        }
-      }
-    }
-    __syncthreads();                                       // every lane holds its keys: the list can be overwritten
-#pragma unroll
-    for (uint32_t c = 0; c < kRegChunks; ++c)
-      if (c * 64u + l < r) list[rank[c]] = (uint16_t)(kreg[c] & 0xFFFFu);
-    __syncthreads();
     return;
   }
   for (uint32_t i = l; i < r; i += 64u) keys[i] = (deg[i] << 16) | list[i];
