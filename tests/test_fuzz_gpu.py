@@ -207,3 +207,37 @@ def test_l2_random_configurations(ctx, seed):
     ctx.db_load(desc, pts, off)
     radius = float(rng.choice([0.3, 0.6, 1.5, 1e9])) * scale
     l2_same(ctx, desc, pts, off, q, k, radius)
+
+
+@pytest.mark.parametrize("mode", ["duplicate_model_points", "collinear_model", "huge_coordinates", "tiny_coordinates",
+                                  "nan_inf_model_points", "coplanar_cloud", "zero_span", "all_same_keypoint_pixel"])
+@pytest.mark.parametrize("seed", _seeds(3))
+def test_verifier_degenerate_geometry(ctx, mode, seed):
+    """Inputs the arithmetic was not designed for -- duplicate or collinear model points, coordinates at 1e3 / 1e-3 scale,
+    NaN / Inf among the model points, a planar cloud, zero spans, every keypoint on one pixel: whatever the reference
+    arithmetic makes of them, the GPU makes the same (comparisons with NaN, distances of 0, singular covariance)."""
+    rng = np.random.Generator(np.random.PCG64(38000 + seed))
+    sc = synth.make_verify_scene(int(rng.integers(120, 400)), n_objects=3, per_object=300, visible=((1, 0.4),), matches_per_kp=3,
+                                 seed=800 + seed, nan_frac=0.05)
+    mx, cloud, kp, spans = sc["matches_xyz"].copy(), sc["cloud"].copy(), sc["kp_xy"].copy(), sc["spans"].copy()
+    if mode == "duplicate_model_points":
+        mx[rng.random(len(mx)) < 0.4] = mx[0]
+    elif mode == "collinear_model":
+        mx[:, 1] = mx[:, 0] * np.float32(0.5); mx[:, 2] = mx[:, 0] * np.float32(-0.25)
+    elif mode == "huge_coordinates":
+        mx *= np.float32(1e3); cloud *= np.float32(1e3); spans = spans * np.float32(1e3)
+    elif mode == "tiny_coordinates":
+        mx *= np.float32(1e-3); cloud *= np.float32(1e-3); spans = spans * np.float32(1e-3)
+    elif mode == "nan_inf_model_points":
+        bad = rng.random(len(mx)) < 0.15
+        mx[bad, rng.integers(0, 3, bad.sum())] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), bad.sum())
+    elif mode == "coplanar_cloud":
+        cloud[:, :, 2] = np.where(np.isnan(cloud[:, :, 2]), np.nan, np.float32(0.9))
+    elif mode == "zero_span":
+        spans = np.zeros_like(spans)
+    elif mode == "all_same_keypoint_pixel":
+        p = cloud[int(kp[0, 1]), int(kp[0, 0])].copy()
+        kp[:] = kp[0]
+        cloud[int(kp[0, 1]), int(kp[0, 0])] = np.where(np.isnan(p), np.float32(0.5), p)
+    sc2 = dict(sc, matches_xyz=mx, cloud=cloud, kp_xy=kp, spans=spans)
+    _compare_frame(ctx, sc2, 6, 150, err=[0.01, 10.0, 1e-5][seed % 3], seed=1 + seed, max_poses=512)
