@@ -241,3 +241,30 @@ def test_verifier_degenerate_geometry(ctx, mode, seed):
         cloud[int(kp[0, 1]), int(kp[0, 0])] = np.where(np.isnan(p), np.float32(0.5), p)
     sc2 = dict(sc, matches_xyz=mx, cloud=cloud, kp_xy=kp, spans=spans)
     _compare_frame(ctx, sc2, 6, 150, err=[0.01, 10.0, 1e-5][seed % 3], seed=1 + seed, max_poses=512)
+
+
+@pytest.mark.parametrize("pattern", ["checkerboard8", "checkerboard3", "stripes", "dots", "two_level_noise", "saturated_blocks",
+                                     "periodic_texture"])
+def test_orb_on_images_full_of_ties(ctx, pattern):
+    """Periodic and piecewise-constant images: thousands of corners with EQUAL FAST scores and EQUAL Harris responses,
+    so every selection (threshold by histogram, ties in (y, x) order, top-n by response) is decided by the tie rules."""
+    H, W = 240, 320
+    y, x = np.mgrid[0:H, 0:W]
+    rng = np.random.Generator(np.random.PCG64(39000))
+    if pattern == "checkerboard8":
+        img = (((y // 8) + (x // 8)) % 2 * 200 + 20)
+    elif pattern == "checkerboard3":
+        img = (((y // 3) + (x // 3)) % 2 * 255)
+    elif pattern == "stripes":
+        img = ((x // 5) % 2 * 180 + (y // 40) % 2 * 40)
+    elif pattern == "dots":
+        img = np.full((H, W), 30); img[4::9, 4::9] = 250
+    elif pattern == "two_level_noise":
+        img = rng.integers(0, 2, (H, W)) * 255
+    elif pattern == "saturated_blocks":
+        img = np.where(((y // 16) % 2 == 0) & ((x // 16) % 3 == 0), 255, 0)
+    else:
+        img = (128 + 100 * np.sin(x * 0.7) * np.sin(y * 0.9)).astype(np.int64)
+    img = np.ascontiguousarray(img, np.uint8)
+    for nf, nl in ((300, 3), (1500, 1), (50, 5)):
+        orb_same(ctx, img, nf, nl, 1.2)
