@@ -130,6 +130,10 @@ __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restr
   // issued as asm: the compiler would otherwise drain vmcnt to 0 before every LDS read (it cannot know which
   // slot a read touches), which is exactly the prefetch depth this ring exists for
   typedef __attribute__((address_space(3))) void* lptr_t;
+  // m0 is named in the clobber list on purpose (the asm writes it; the compiler must not keep a value there across it);
+  // clang flags every reserved register in a clobber list, hence the pragma
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 #define L2_LOAD_LDS(width_, gaddr_, lds_)                                                                      \
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_" width_ " %0, off"                             \
                :: "v"(gaddr_), "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(lptr_t)(lds_))) : "memory", "m0")
