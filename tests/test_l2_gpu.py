@@ -106,3 +106,23 @@ def test_c4_full_size_properties(ctx):
     sel = (pick[:, None] * 2 + np.arange(2)).ravel()
     for f in ("trainIdx", "imgIdx", "distance"):
         assert np.array_equal(m[f][sel], o_m[f]), f
+
+
+def test_one_gemm_path_with_overflowing_candidate_lists(ctx):
+    """A DB large enough for the one-GEMM path (>= 64k rows: the seed of an evenly spaced sample IS the candidate threshold)
+    that holds 1500 near-copies of one vector: queries next to it collect more candidates than a list holds and are redone
+    by the exact scan; the other queries take the fast path. All of them equal the oracle."""
+    rng = np.random.Generator(np.random.PCG64(123))
+    n = 70000
+    desc = (rng.random((n, 128)) * 200).astype(np.float32)
+    base = (rng.random(128) * 200).astype(np.float32)
+    where = rng.choice(n, 1500, replace=False)
+    desc[where] = base[None, :] + rng.normal(0, 0.02, (1500, 128)).astype(np.float32)
+    pts = rng.random((n, 3)).astype(np.float32)
+    off = np.array([0, 20000, 20000, 70000], np.uint32)
+    q = np.concatenate([base[None, :] + rng.normal(0, 0.02, (12, 128)).astype(np.float32),      # overflow -> exact scan
+                        desc[rng.integers(0, n, 40)] + rng.normal(0, 3.0, (40, 128)).astype(np.float32),
+                        (rng.random((30, 128)) * 200).astype(np.float32)]).astype(np.float32)
+    ctx.db_load(desc, pts, off)
+    for k in (1, 4, 8):
+        _assert_same(ctx, desc, pts, off, q, k, 1.0e9)

@@ -10,11 +10,14 @@
 //   (bf16 rounding moves each vector by <= 2^-9 of its norm, Cauchy-Schwarz on the two error terms, the f32
 //   accumulation of 128 products and of the norms is below 2^-16 of |q||r|; the second term covers the rounding
 //   of the sequential f32 sum that DEFINES d2, see include/todhip.h).
-//   pass 0  seed(q) = k-th smallest score over the first rows only   (an upper bound of A_k: a subset's k-th smallest)
+//   pass 0  seed(q) = k-th smallest score over a sample of the DB    (an upper bound of A_k: a subset's k-th smallest)
 //   pass 1  A_k(q) = k-th smallest score over the DB                (GEMM + per-lane top-8 in registers; only scores
 //                                                                    below the seed are ever inserted)
 //   pass 2  candidates = { r : score <= A_k + 2 eps }                (same GEMM, atomic append, <= kCandCap per query)
 //           every row of the true top-k is a candidate: its d2 <= T_k <= A_k + |q|^2 + eps
+//   DBs of >= 64k rows skip pass 1: the sample is an evenly spaced quarter of the DB (at most 64k rows) and seed + 2 eps
+//   is used as the threshold of pass 2 -- seed >= A_k, so the candidates are a superset (rows of rank <= ~k N / n_sample
+//   plus the eps band) and pass 3 returns the same result from it
 //   pass 3  exact d2 of the candidates in the defining order (sequential f32, no fma), k smallest by (d2, row);
 //           a query whose candidate list overflowed is redone by an exact scan of the whole DB
 // L2G  l2_gemm_kernel<PASS>    block = 4 waves x 4 query tiles of 32 = 512 queries; DB tiles of 32 rows x 128 bf16
@@ -39,7 +42,7 @@ constexpr uint32_t kQTilesPerWave = 4;
 constexpr uint32_t kWaves = 4;
 constexpr uint32_t kBlockQueries = kWaves * kQTilesPerWave * 32u;   // 256
 constexpr uint32_t kTop = 8;                              // per-lane list length of pass 1 (k <= 8)
-constexpr uint32_t kCandCap = 256;                        // candidates per query before the exact-scan fallback
+constexpr uint32_t kCandCap = 1024;                        // candidates per query before the exact-scan fallback
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 = 4 VGPRs: one MFMA A/B fragment
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -91,10 +94,11 @@ __global__ __launch_bounds__(256) void l2_eps_kernel(const float* __restrict__ q
 // KT: per-lane list length of pass 1 (4 when k <= 4: 16 VGPRs less), unused in pass 2
 template <int PASS, uint32_t KT>
 __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restrict__ db, const float* __restrict__ dbn,
-                                                         uint32_t n_tiles, uint32_t tiles_per_chunk,
+                                                         uint32_t n_tiles, uint32_t tiles_per_chunk, uint32_t tile_stride,
                                                          const uint16_t* __restrict__ qh, uint32_t nq_pad,
                                                          float* __restrict__ part, const float* __restrict__ thr,
                                                          uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
+  // tile_stride: tile t of the launch is DB tile t * tile_stride (the seed pass samples the DB evenly; 1 otherwise)
   // thr: PASS 1 -- optional per-query seed (only scores below it can matter), PASS 2 -- the candidate threshold
   // LDS ring of DB tiles, written by global_load_lds (no VGPR staging): a wave-load drops 64 x 16 B = 4 rows
   // contiguously, so rows are unpadded and the 16-byte chunk c of row r is stored at chunk c ^ (r & 15) instead
@@ -146,10 +150,10 @@ __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restr
 #define L2_ISSUE(tile_)                                                                                        \
   {                                                                                                            \
     const uint32_t slot_ = ((tile_) - t_begin) % kRing;                                                        \
-    const uint4* src_ = reinterpret_cast<const uint4*>(db + (size_t)(tile_) * kTileRows * kDim);               \
+    const uint4* src_ = reinterpret_cast<const uint4*>(db + (size_t)(tile_) * tile_stride * kTileRows * kDim); \
     L2_LOAD_LDS("dwordx4", src_ + src_chunk[0], &s_tile[slot_][(2u * wave) * 1024u]);                          \
     L2_LOAD_LDS("dwordx4", src_ + src_chunk[1], &s_tile[slot_][(2u * wave + 1u) * 1024u]);                     \
-    L2_LOAD_LDS("dword", dbn + (size_t)(tile_) * kTileRows + r, &s_norm[slot_][0]);                            \
+    L2_LOAD_LDS("dword", dbn + (size_t)(tile_) * tile_stride * kTileRows + r, &s_norm[slot_][0]);              \
   }
   // s_waitcnt vmcnt(N), nothing else: N = loads that may stay in flight (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8)
 #define L2_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
@@ -431,7 +435,7 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
   const uint32_t n_parts = 2u * n_chunks;
   TOD_HIP(ws->q_bf16.reserve((size_t)nq_pad * kDim * 2));
   TOD_HIP(ws->q_eps.reserve((size_t)nq_pad * 4 * 2));
-  TOD_HIP(ws->part.reserve((size_t)n_parts * nq_pad * kTop * 4));
+  TOD_HIP(ws->part.reserve((size_t)std::max(n_parts, 64u) * nq_pad * kTop * 4));   // the seed pass writes up to 2 x 32 partitions
   TOD_HIP(ws->thr.reserve((size_t)nq_pad * 4 * 2));
   TOD_HIP(ws->cand.reserve((size_t)nq_pad * kCandCap * 4));
   float* qnorm = ws->q_eps.as<float>() + nq_pad;
@@ -442,31 +446,51 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
                      ws->q_eps.as<float>());
   TOD_HIP(hipMemsetAsync(ws->cand_cnt.p, 0, (size_t)nq_pad * 4, st));
   const uint32_t k_eff = std::min(k, std::max(1u, n));
-  // pass 0: the k-th smallest score over a sample (the first rows) bounds A_k from above; with it as the initial
-  // limit of pass 1 only ~k N / n_sample scores per query ever reach the insertion path
+  auto gemm1 = k_eff <= 4u ? l2_gemm_kernel<1, 4> : l2_gemm_kernel<1, 8>;
+  float* const d_seed = ws->thr.as<float>() + nq_pad;
+  // pass 0: the k-th smallest score over a sample of the DB bounds A_k from above.
+  //  * one-GEMM path (DBs of >= 64k rows): the sample is every (n_tiles / sample)-th tile, a quarter of the DB at most
+  //    2048 tiles, so it is representative whatever the object order; seed + 2 eps IS the candidate threshold of pass 2 --
+  //    a superset of what the exact A_k would admit (rows of rank <= ~k N / n_sample plus the eps band) -- and the pass
+  //    that computes A_k over the whole DB is skipped.
+  //  * classic path (smaller DBs): the sample is the first rows and the seed only limits what enters pass 1's lists.
+  const bool fast = n_tiles >= 2048u;
+  const uint32_t sample_tiles = fast ? std::min(2048u, n_tiles / 4u) : std::min(n_tiles, 256u);
+  const uint32_t sample_stride = fast ? n_tiles / sample_tiles : 1u;
   const float* seed = nullptr;
-  const uint32_t sample_tiles = std::min(n_tiles, 256u);
-  if (n_tiles >= 8u * sample_tiles && sample_tiles * kTileRows >= k_eff) {
-    const uint32_t s_chunks = std::min(sample_tiles, 32u), s_tpc = (sample_tiles + s_chunks - 1u) / s_chunks;
-    float* d_seed = ws->thr.as<float>() + nq_pad;
-    hipLaunchKernelGGL((k_eff <= 4u ? l2_gemm_kernel<1, 4> : l2_gemm_kernel<1, 8>), dim3(s_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
-                       ws->db_norm.as<float>(), sample_tiles, s_tpc, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
+  bool one_gemm = false;
+  if ((fast || n_tiles >= 8u * sample_tiles) && sample_tiles * kTileRows >= k_eff) {
+    const uint32_t s_chunks = std::min(sample_tiles, fast ? n_chunks : 32u), s_tpc = (sample_tiles + s_chunks - 1u) / s_chunks;
+    const uint32_t s_used = (sample_tiles + s_tpc - 1u) / s_tpc;
+    hipLaunchKernelGGL(gemm1, dim3(s_used, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(), ws->db_norm.as<float>(),
+                       sample_tiles, s_tpc, sample_stride, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
                        (const float*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), 2u * s_chunks, nq_pad,
-                       nq_pad, k_eff, (const float*)nullptr, ws->q_eps.as<float>(), 0.f, d_seed);
-    seed = d_seed;
+    if (fast) {
+      hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), 2u * s_used, nq,
+                         nq_pad, k_eff, (const float*)nullptr, ws->q_eps.as<float>(), 2.f, ws->thr.as<float>());
+      one_gemm = true;
+    } else {
+      hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), 2u * s_used, nq_pad,
+                         nq_pad, k_eff, (const float*)nullptr, ws->q_eps.as<float>(), 0.f, d_seed);
+      seed = d_seed;
+    }
   }
   int slot = -1;
-  if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
-  hipLaunchKernelGGL((k_eff <= 4u ? l2_gemm_kernel<1, 4> : l2_gemm_kernel<1, 8>), dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
-                     ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
-                     seed, (uint32_t*)nullptr, (uint32_t*)nullptr);
-  if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
-  hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), n_parts, nq, nq_pad,
-                     k_eff, seed, ws->q_eps.as<float>(), 2.f, ws->thr.as<float>());
+  if (!one_gemm) {
+    if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
+    hipLaunchKernelGGL(gemm1, dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(), ws->db_norm.as<float>(), n_tiles,
+                       tiles_per_chunk, 1u, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(), seed, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr);
+    if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; slot = -1; }
+    hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), n_parts, nq, nq_pad,
+                       k_eff, seed, ws->q_eps.as<float>(), 2.f, ws->thr.as<float>());
+  } else if (ctx->time_kernels) {
+    int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc;
+  }
   hipLaunchKernelGGL((l2_gemm_kernel<2, 4>), dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
-                     ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, ws->q_bf16.as<uint16_t>(), nq_pad, (float*)nullptr,
+                     ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, 1u, ws->q_bf16.as<uint16_t>(), nq_pad, (float*)nullptr,
                      ws->thr.as<float>(), ws->cand.as<uint32_t>(), ws->cand_cnt.as<uint32_t>());
+  if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(l2_rerank_kernel, dim3((nq + 3u) / 4u), dim3(256), 0, st, d_q, nq, ctx->db_desc.as<float>(),
                      ws->cand.as<uint32_t>(), ws->cand_cnt.as<uint32_t>(), k, ws->keys.as<uint64_t>(), overflow);
   hipLaunchKernelGGL(l2_exact_scan_kernel, dim3(nq), dim3(256), 0, st, d_q, nq, ctx->db_desc.as<float>(), n, k,
