@@ -455,12 +455,14 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
   //    that computes A_k over the whole DB is skipped.
   //  * classic path (smaller DBs): the sample is the first rows and the seed only limits what enters pass 1's lists.
   const bool fast = n_tiles >= 2048u;
-  const uint32_t sample_tiles = fast ? std::min(2048u, n_tiles / 4u) : std::min(n_tiles, 256u);
+  static const uint32_t env_st = getenv("TODHIP_L2_SAMPLE_TILES") ? (uint32_t)atoi(getenv("TODHIP_L2_SAMPLE_TILES")) : 0u;   // tuning knob
+  const uint32_t sample_tiles = fast ? std::min(env_st ? env_st : 2048u, n_tiles / 4u) : std::min(n_tiles, 256u);
   const uint32_t sample_stride = fast ? n_tiles / sample_tiles : 1u;
   const float* seed = nullptr;
   bool one_gemm = false;
   if ((fast || n_tiles >= 8u * sample_tiles) && sample_tiles * kTileRows >= k_eff) {
-    const uint32_t s_chunks = std::min(sample_tiles, fast ? n_chunks : 32u), s_tpc = (sample_tiles + s_chunks - 1u) / s_chunks;
+    static const uint32_t env_sc = getenv("TODHIP_L2_SEED_CHUNKS") ? (uint32_t)atoi(getenv("TODHIP_L2_SEED_CHUNKS")) : 0u;   // tuning knob
+    const uint32_t s_chunks = std::min(sample_tiles, fast ? (env_sc ? std::min(env_sc, n_chunks) : n_chunks) : 32u), s_tpc = (sample_tiles + s_chunks - 1u) / s_chunks;
     const uint32_t s_used = (sample_tiles + s_tpc - 1u) / s_tpc;
     hipLaunchKernelGGL(gemm1, dim3(s_used, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(), ws->db_norm.as<float>(),
                        sample_tiles, s_tpc, sample_stride, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
