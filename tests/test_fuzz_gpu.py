@@ -268,3 +268,29 @@ def test_orb_on_images_full_of_ties(ctx, pattern):
     img = np.ascontiguousarray(img, np.uint8)
     for nf, nl in ((300, 3), (1500, 1), (50, 5)):
         orb_same(ctx, img, nf, nl, 1.2)
+
+
+@pytest.mark.parametrize("seed", _seeds(4))
+def test_l2_random_large_databases(ctx, seed):
+    """Float-descriptor matcher on DBs above 64k rows, where the seed of an evenly spaced sample is used as the candidate
+    threshold and the A_k pass is skipped: clustered rows (the sample sees few members of a query's cluster), duplicates,
+    integer values, several k."""
+    from test_l2_gpu import _assert_same as l2_same
+    rng = np.random.Generator(np.random.PCG64(40000 + seed))
+    n_obj = int(rng.integers(3, 9))
+    sizes = [int(rng.integers(8000, 30000)) for _ in range(n_obj)]
+    while sum(sizes) < 66000:
+        sizes.append(int(rng.integers(8000, 30000)))
+    n, nq, k = sum(sizes), int(rng.integers(8, 50)), int(rng.integers(1, 9))
+    centres = (rng.random((len(sizes), 128)) * 200).astype(np.float32)
+    spread = float(rng.choice([2.0, 20.0, 200.0]))
+    desc = np.concatenate([c[None, :] + rng.normal(0, spread, (m, 128)).astype(np.float32) for c, m in zip(centres, sizes)])
+    if seed % 2:
+        desc = np.rint(desc).astype(np.float32)
+    desc[rng.integers(0, n, 50)] = desc[0]                                    # 50 duplicates of one row
+    q = (desc[rng.integers(0, n, nq)] + rng.normal(0, 0.3 * spread, (nq, 128))).astype(np.float32)
+    q[0] = desc[0]
+    pts = rng.random((n, 3)).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    ctx.db_load(np.ascontiguousarray(desc, np.float32), pts, off)
+    l2_same(ctx, desc, pts, off, q, k, float(rng.choice([0.5, 3.0, 1e9])) * spread * 11.3)
