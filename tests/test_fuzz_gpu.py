@@ -38,7 +38,7 @@ def test_matcher_random_configurations(ctx, seed):
         sizes[0] = 1
     nq = int(rng.integers(1, 700))
     k = int(rng.integers(1, 9))
-    radius = int(rng.choice([1, 2, 20, 35, 38, 39, 46, 47, 64, 100, 128, 256, 257, 1000]))
+    radius = int(rng.choice([1, 2, 20, 35, 37, 38, 47, 48, 55, 64, 79, 80, 100, 128, 256, 257, 1000]))
     n = sum(sizes)
     style = seed % 4
     if style == 0:                                             # iid bits

@@ -77,7 +77,7 @@ def test_ties_resolve_by_ascending_row(ctx):
 def test_radius_truncation_edges(ctx):
     desc, pts, off = synth.make_db(2, per_object=3000)
     fr = synth.make_frame(desc, pts, off, 200, frame=9, visible_object=1, flip_p=0.12)
-    for radius in (1, 20, 30, 31, 35, 37, 38, 40, 45, 46, 55, 100, 128, 255, 256, 1000):   # 37|38 and 45|46: elimination schedules
+    for radius in (1, 20, 30, 31, 35, 37, 38, 40, 45, 47, 48, 55, 70, 79, 80, 100, 128, 255, 256, 1000):   # 37|38, 47|48, 79|80: schedule changes
         _assert_same(ctx, desc, pts, off, fr["q_desc"], 5, radius)
 
 

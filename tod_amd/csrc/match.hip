@@ -91,28 +91,31 @@ __device__ __forceinline__ uint32_t hamming256_mem(const uint32_t (&q)[kWords], 
 // query): a row at or above it cannot be among the k nearest of the whole DB (ties with a foreign bound are kept
 // because a smaller row index could still win them), so skipping it keeps the merged result exact.
 // MODE picks the elimination schedule by how tight the initial bound (radius + 1) is; every schedule is exact.
-//   2: test after 96 bits per row, then the 4th word, then the rest   (pays for cut <= 38: a row passes the first test
+//   2: test after 96 bits per row, then after 128, after 192, then the rest   (pays for cut <= 38: a row passes the first test
 //      in some lane with probability ~0.3 on independent bits at cut 36, ~0.9 at cut 40)
-//   1: test after 128 bits per 4 rows, then the rest                  (38 < cut <= 46)
+//   1: test after 128 bits per 4 rows, then the rest                  (38 < cut <= 48)
+//   3: test after 192 bits per 4 rows, then the rest                  (48 < cut <= 80, e.g. radius 55 of conf/detection.ros.ork:60)
 //   0: full distances, one test per 4 rows                            (larger radii: no lower bound prunes anything)
 template <int K, int MODE>
 __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], const RowGroup& g, uint32_t r,
                                               uint32_t (&best)[K], uint32_t& worst_d, uint32_t& limit, uint32_t foreign) {
-  if (MODE < 2) {
+  if (MODE != 2) {
     // the four rows' accumulate chains are interleaved word by word: no instruction depends on its predecessor
+    constexpr int kFirst = MODE == 1 ? 4 : (MODE == 3 ? 6 : kWords);   // words before the group test
     uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
 #pragma unroll
-    for (int w = 0; w < (MODE == 1 ? 4 : kWords); ++w) {
+    for (int w = 0; w < kFirst; ++w) {
       const uint32_t x0 = qd[w] ^ g.lo[w], x1 = qd[w] ^ g.lo[kWords + w], x2 = qd[w] ^ g.hi[w], x3 = qd[w] ^ g.hi[kWords + w];
       d0 = bcnt_acc(x0, d0); d1 = bcnt_acc(x1, d1); d2 = bcnt_acc(x2, d2); d3 = bcnt_acc(x3, d3);
     }
     uint32_t dmin = min(min(d0, d1), min(d2, d3));
-    if (MODE == 1) {
-      if (__builtin_amdgcn_ballot_w64(dmin < limit) == 0ull) return;    // lower bounds already out: skip the second half
-      d0 = hamming128<0, 4>(qd, g.lo, d0);
-      d1 = hamming128<1, 4>(qd, g.lo, d1);
-      d2 = hamming128<0, 4>(qd, g.hi, d2);
-      d3 = hamming128<1, 4>(qd, g.hi, d3);
+    if (kFirst < kWords) {
+      if (__builtin_amdgcn_ballot_w64(dmin < limit) == 0ull) return;    // lower bounds already out: skip the rest
+#pragma unroll
+      for (int w = kFirst; w < kWords; ++w) {
+        const uint32_t x0 = qd[w] ^ g.lo[w], x1 = qd[w] ^ g.lo[kWords + w], x2 = qd[w] ^ g.hi[w], x3 = qd[w] ^ g.hi[kWords + w];
+        d0 = bcnt_acc(x0, d0); d1 = bcnt_acc(x1, d1); d2 = bcnt_acc(x2, d2); d3 = bcnt_acc(x3, d3);
+      }
       dmin = min(min(d0, d1), min(d2, d3));
     }
     if (__builtin_amdgcn_ballot_w64(dmin < limit) != 0ull) {
@@ -130,7 +133,8 @@ __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], cons
   // Three-stage partial-distance elimination. Stage A: 96 bits of each of the four rows (chains interleaved word by
   // word: no instruction depends on its predecessor) and one ballot per row; a row whose lower bound reaches the limit
   // in all 64 queries is finished. Stage B, per surviving row (~29 % of the rows on independent bits at radius 35):
-  // the 4th word, test again; stage C (rare): the other 128 bits, test, insert.
+  // the 4th word, test again; stage C (rare on independent bits, common on correlated ones): words 5-6, test; stage D: the
+  // last 64 bits, test, insert.
   uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;
 #pragma unroll
   for (int w = 0; w < 3; ++w) {
@@ -146,11 +150,16 @@ __device__ __forceinline__ void consume_group(const uint32_t (&qd)[kWords], cons
   if ((bal_) != 0ull) {                                                                                            \
     d_ = bcnt_acc(qd[3] ^ rows_[half_ * kWords + 3], d_);                                                         \
     if (__builtin_amdgcn_ballot_w64(d_ < limit) != 0ull) {                                                         \
-      d_ = hamming128<half_, 4>(qd, rows_, d_);                                                                   \
+      d_ = bcnt_acc(qd[4] ^ rows_[half_ * kWords + 4], d_);                                                       \
+      d_ = bcnt_acc(qd[5] ^ rows_[half_ * kWords + 5], d_);                                                       \
       if (__builtin_amdgcn_ballot_w64(d_ < limit) != 0ull) {                                                       \
-        topk_insert<K>(best, (d_ << kLocalBits) | (r + idx_));                                                    \
-        worst_d = best[K - 1] >> kLocalBits;                                                                      \
-        limit = min(worst_d, foreign);                                                                            \
+        d_ = bcnt_acc(qd[6] ^ rows_[half_ * kWords + 6], d_);                                                     \
+        d_ = bcnt_acc(qd[7] ^ rows_[half_ * kWords + 7], d_);                                                     \
+        if (__builtin_amdgcn_ballot_w64(d_ < limit) != 0ull) {                                                     \
+          topk_insert<K>(best, (d_ << kLocalBits) | (r + idx_));                                                  \
+          worst_d = best[K - 1] >> kLocalBits;                                                                    \
+          limit = min(worst_d, foreign);                                                                          \
+        }                                                                                                         \
       }                                                                                                           \
     }                                                                                                             \
   }
@@ -412,10 +421,12 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radi
   TOD_HIP(hipMemsetAsync(ctx->m_bound.p, 0xFF, (size_t)nq_pad * sizeof(uint32_t), ctx->stream));
   int slot = -1;
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
-  // every schedule is exact; TODHIP_K4_MODE=0/1/2 overrides the choice (diagnostics: tools/k4_on_correlated_descriptors.py)
+  // every schedule is exact; TODHIP_K4_MODE=0/1/2/3 overrides the choice (diagnostics: tools/k4_on_correlated_descriptors.py)
   static const int env_mode = getenv("TODHIP_K4_MODE") ? atoi(getenv("TODHIP_K4_MODE")) : -1;
-  const int mode = (env_mode >= 0 && env_mode <= 2 && cut <= 256u) ? env_mode : (cut <= 38u ? 2 : (cut <= 46u ? 1 : 0));
-  auto kern = mode == 2 ? hamming_topk_tiles<K, 2> : (mode == 1 ? hamming_topk_tiles<K, 1> : hamming_topk_tiles<K, 0>);
+  const int mode = (env_mode >= 0 && env_mode <= 3 && cut <= 256u) ? env_mode
+                                                                   : (cut <= 38u ? 2 : (cut <= 48u ? 1 : (cut <= 80u ? 3 : 0)));
+  auto kern = mode == 2 ? hamming_topk_tiles<K, 2>
+                        : (mode == 1 ? hamming_topk_tiles<K, 1> : (mode == 3 ? hamming_topk_tiles<K, 3> : hamming_topk_tiles<K, 0>));
   hipLaunchKernelGGL(kern, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw,
                      blocks_per_xcd, tiles_per_xcd, cut, ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>());

@@ -3,7 +3,7 @@ import csv, glob, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 out = os.path.join(root, "gpurun_out")
-KERNEL = "hamming_topk_tiles"
+KERNEL = "hamming_topk_tiles<2, 2>"   # k = 2, three-stage schedule: the timed launches (bench.py also runs 3 dense ones afterwards)
 
 stats = glob.glob(os.path.join(out, "prof_k4_trace", "**", "*kernel_stats.csv"), recursive=True)
 assert stats, "no kernel_stats.csv"
