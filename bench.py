@@ -422,7 +422,7 @@ def main():
                        "stages": stages, "db_rows_per_gpu": info["shard_rows"],
                        "matcher_input": "SURVEY 8(d) synthetic descriptors (iid bits, planted matches at 8 % flips): the "
                                         "partial-distance elimination halves the DB pass on them; it is data dependent -- 0.27 ms per "
-                                        "frame at rBRIEF-like correlation, the dense 0.42 ms on strongly biased descriptors (DESIGN.md 6, "
+                                        "frame at rBRIEF-like correlation, 0.36 ms on strongly biased descriptors, 0.43 ms dense (DESIGN.md 6, "
                                         "tools/k4_on_correlated_descriptors.py, tools/k4_on_orb_descriptors.py)",
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
                        "poses_per_frame_rank0": n_pose_total[0] / max(n_steps_done[0] * B, 1),
