@@ -3,9 +3,9 @@ import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import numpy as np, torch
 from tod_amd import capi, synth
-desc, pts, off = synth.make_db(200)
+desc, pts, off = synth.make_db(int(os.environ.get("OBJECTS", "200")))
 B, nq, k = int(os.environ.get("B", "16")), 1000, 2
-q = np.concatenate([synth.make_frame(desc, pts, off, nq, frame=f, visible_object=(17 * f + 3) % 200)["q_desc"] for f in range(B)])
+q = np.concatenate([synth.make_frame(desc, pts, off, nq, frame=f, visible_object=(17 * f + 3) % 200 % int(os.environ.get("OBJECTS", "200")))["q_desc"] for f in range(B)])
 ctx = capi.Context(0)
 ctx.db_load(desc, pts, off)
 d_q = torch.from_numpy(q).cuda(); n = B * nq
