@@ -389,16 +389,17 @@ int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radi
   const uint32_t n_qw = (nq + 63u) / 64u;
   const uint32_t nq_pad = n_qw * 64u;
   // Tiling (measured, tools/time_k4.py): about three times more waves than fit the chip at once and tiles of at most
-  // ~4096 rows. An exactly-resident grid of long-running waves (the first design) lost 15-20 %: the hardware does not
-  // spread blocks evenly over the CUs, and the query waves of a large tile drift apart in it (scalar-cache and L2
-  // misses); short blocks rebalance by themselves and keep a tile's readers together.
+  // ~2048 rows (16 000 queries x 1M rows: 3.27 ms with 4096-row tiles, 3.20 ms with 2048; 10M rows: 35.6 -> 34.3 ms).
+  // An exactly-resident grid of long-running waves (the first design) lost 15-20 %: the hardware does not spread
+  // blocks evenly over the CUs, and the query waves of a large tile drift apart in it (scalar-cache and L2 misses);
+  // short blocks rebalance by themselves and keep a tile's readers together.
   static const int env_wpc = getenv("TODHIP_K4_WAVES_PER_CU") ? atoi(getenv("TODHIP_K4_WAVES_PER_CU")) : 0;   // tuning knob
   uint32_t n_tiles;
   if (env_wpc > 0) {
     n_tiles = (uint32_t)ctx->n_cu * (uint32_t)env_wpc / n_qw;
   } else {
-    n_tiles = std::max(3u * (uint32_t)ctx->n_cu * (uint32_t)kWavesPerCU / n_qw, (n_rows + 4095u) / 4096u);
-    n_tiles = std::min(n_tiles, 4096u);
+    n_tiles = std::max(3u * (uint32_t)ctx->n_cu * (uint32_t)kWavesPerCU / n_qw, (n_rows + 2047u) / 2048u);
+    n_tiles = std::min(n_tiles, 8192u);
   }
   if (n_tiles < 1) n_tiles = 1;
   if (n_tiles >= 8) n_tiles = (n_tiles + 7u) & ~7u;      // whole tiles per XCD (8 XCDs)
