@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--exchange", choices=("all_to_all", "all_gather"), default="all_to_all",
                     help="several ranks: how the per-shard candidates travel. A rank only merges its own frames, so an "
                          "all-to-all moves 1/world of an all-gather's bytes over the point-to-point xGMI links")
+    ap.add_argument("--replicas", action="store_true",
+                    help="several ranks: every rank holds the WHOLE DB and matches only its own frames -- no data-path collective "
+                         "(SURVEY 8(e)'s comparison point for DBs that fit one GPU; the default shards the DB rows)")
     ap.add_argument("--serial-exchange", action="store_true",
                     help="several ranks: issue the collectives on the matcher's stream, in program order (gather -> match -> "
                          "exchange -> merge), instead of on their own stream where they overlap the neighbouring DB passes")
@@ -137,7 +140,8 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx = capi.Context(local_rank, stream.cuda_stream)
-    db_spans = ctx.db_load(desc, pts, off, shard_rank=rank, shard_count=world)
+    sharded = world > 1 and not args.replicas
+    db_spans = ctx.db_load(desc, pts, off, shard_rank=rank if sharded else 0, shard_count=world if sharded else 1)
     info = ctx.db_info()
     # single device: steps alternate between two matcher contexts (own stream, own workspaces, own copy of the 32 MB
     # DB), so the merge/finalize tail and the launch ramp of one step overlap with the DB pass of the next; with
@@ -240,7 +244,7 @@ def main():
     # q_all / keys / km; the events below are the only cross-stream edges:
     #   gathered(i) -> match(i);  matched(i) -> exchange(i);  exchanged(i - 2) -> match(i) (keys buffer reuse);
     #   gather(i + 2) overwrites q_all[i % 2] after exchange(i), which itself waited for match(i)  (stream order).
-    overlap = use_dist and not args.serial_exchange
+    overlap = use_dist and not args.serial_exchange and not args.replicas
     if overlap:
         cstream = torch.cuda.Stream(priority=-1)
         cctx = capi.Context(local_rank, cstream.cuda_stream)
@@ -292,8 +296,8 @@ def main():
             return match_step_overlapped(i, n_steps)
         o = outs[i % D]
         q = Q_B[i % period]
-        if not use_dist:
-            # single device: no key exchange; the B frames' descriptors share one pass over the DB
+        if not use_dist or args.replicas:
+            # single device (or a replica of the whole DB): no key exchange; the B frames' descriptors share one pass over the DB
             mctx[i % len(mctx)].match_device(q.data_ptr(), B * nq, k, args.radius, o["counts"].data_ptr(),
                                              o["matches"].data_ptr(), o["xyz"].data_ptr())
             return mstreams[i % len(mstreams)]
@@ -383,9 +387,13 @@ def main():
     n_launch = sum(b.n_match_kernel_launches - a.n_match_kernel_launches for a, b in zip(c0, c1))
     k4_ms = sum(b.sum_match_kernel_ms - a.sum_match_kernel_ms for a, b in zip(c0, c1)) / max(n_launch, 1)
     frames_per_launch = B                                          # one launch matches the world*B frames of a step
-    alg_bytes = info["shard_rows"] * 32 + world * frames_per_launch * nq * (32 + k * 8)   # N*32 + F*Q*(32 + k*8)
+    if args.replicas:
+        world_q = 1                                                # ... or, with replicas, this rank's own B frames
+    else:
+        world_q = world
+    alg_bytes = info["shard_rows"] * 32 + world_q * frames_per_launch * nq * (32 + k * 8)   # N*32 + F*Q*(32 + k*8)
     achieved = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
-    distances = float(nq) * world * frames_per_launch * info["shard_rows"]
+    distances = float(nq) * world_q * frames_per_launch * info["shard_rows"]
 
     # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, collected in their own
     # rocprofv3 runs by tools/profile_k4.sh and committed as profiles/r01_k4_pmc.json); only quoted for the
@@ -434,7 +442,9 @@ def main():
                               (args.nq, n_kp_total[0] / max(n_steps_done[0] * B, 1)) if do_orb else None,
                        "frames_per_step": world * B,
                        "parallelism": ("DB rows sharded x%d (object aligned), %d frames per rank per step, RCCL all-gather of "
-                                       "descriptors, %s of per-shard candidates" % (world, B, args.exchange)) if world > 1 else "1 GPU"},
+                                       "descriptors, %s of per-shard candidates" % (world, B, args.exchange)) if sharded else
+                                      ("%d replicas of the whole DB, %d frames per rank per step, no data-path collective" % (world, B)
+                                       if world > 1 else "1 GPU")},
             "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,
@@ -442,11 +452,11 @@ def main():
                          "dense_launch_ms": dense_ms,
                          "dense_launch_note": "same launch without the radius bound (no partial-distance elimination possible), "
                                               "measured after the timed region, alone",
-                         "queries_per_launch": world * B * nq,
+                         "queries_per_launch": world_q * B * nq,
                          "concurrent_matcher_contexts": len(mctx),
                          "note": "at %d queries per DB pass this kernel is bound by integer VALU issue, not HBM "
                                  "(SURVEY F11): see valu_roofline; launch_ms is a launch's own duration (%s)"
-                                 % (world * B * nq, "one matcher context: launches do not overlap" if len(mctx) == 1 else
+                                 % (world_q * B * nq, "one matcher context: launches do not overlap" if len(mctx) == 1 else
                                     "%d matcher contexts: consecutive launches overlap" % len(mctx))},
             "valu_roofline": {"bound": "valu", "achieved": valu_rate / 1e12, "peak": VALU_PEAK_LANEOPS / 1e12,
                               "unit": "T lane-op/s", "frac": valu_frac,
