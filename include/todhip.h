@@ -73,6 +73,11 @@ int  todhip_last_hip_error(const todhip_ctx*);
 int  todhip_synchronize(todhip_ctx*);
 int  todhip_get_counters(todhip_ctx*, todhip_counters* out);
 int  todhip_set_kernel_timing(todhip_ctx*, int enable);   /* bracket the matcher kernel with HIP events */
+/* The exact Hamming search of todhip_match* exists twice, with identical results: on the vector ALU (xor + popcount,
+ * partial-distance elimination: data dependent) and on the matrix cores (bits as +-1 MX-fp4 values, dot = 256 - 2 d:
+ * data independent). AUTO picks by launch shape. */
+enum { TODHIP_ENGINE_AUTO = 0, TODHIP_ENGINE_VALU = 1, TODHIP_ENGINE_MFMA = 2 };
+int  todhip_set_matcher_engine(todhip_ctx*, int engine);
 
 /* ---- stage B: DescriptorMatcher ---------------------------------------------------------------- */
 /* Replaces DescriptorMatcher::parameter_callback (DescriptorMatcher.cpp:60-129): ingest every object,

@@ -52,7 +52,7 @@ class Counters(C.Structure):
 # every symbol include/todhip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "todhip_version", "todhip_create", "todhip_destroy", "todhip_stream", "todhip_last_hip_error",
-    "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_db_load", "todhip_db_info",
+    "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_db_load", "todhip_db_info",
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device",
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
@@ -138,6 +138,11 @@ class Context:
         c = Counters()
         _check(lib().todhip_get_counters(self._h, C.byref(c)), "todhip_get_counters")
         return c
+
+    def set_matcher_engine(self, engine):
+        """0 auto, 1 vector ALU (K4), 2 matrix cores (K4x): identical results"""
+        _check(lib().todhip_set_matcher_engine(self._h, C.c_int({"auto": 0, "valu": 1, "mfma": 2}.get(engine, engine))),
+               "todhip_set_matcher_engine")
 
     def set_kernel_timing(self, enable):
         _check(lib().todhip_set_kernel_timing(self._h, C.c_int(1 if enable else 0)), "todhip_set_kernel_timing")

@@ -83,6 +83,12 @@ int todhip_set_kernel_timing(todhip_ctx* ctx, int enable) {
   return TODHIP_OK;
 }
 
+int todhip_set_matcher_engine(todhip_ctx* ctx, int engine) {
+  if (!ctx || engine < TODHIP_ENGINE_AUTO || engine > TODHIP_ENGINE_MFMA) return TODHIP_EINVAL;
+  ctx->matcher_engine = engine;
+  return TODHIP_OK;
+}
+
 // Object-aligned contiguous shards: object o belongs to the shard whose row range contains its first row
 // when the rows are cut into shard_count equal pieces (an object never straddles two devices).
 static void shard_bounds(const std::vector<uint32_t>& off, uint32_t n_objs, uint32_t rank, uint32_t count,

@@ -96,6 +96,7 @@ struct todhip_ctx {
   hipEvent_t evp[2 * kEvPairs] = {};
   uint64_t ev_head = 0, ev_tail = 0;   // pairs [ev_tail, ev_head) are recorded and not yet read
   todhip_counters counters = {};
+  int matcher_engine = TODHIP_ENGINE_AUTO;   // todhip_set_matcher_engine
 
   std::vector<todhip_round_trace> traces;
 

@@ -266,6 +266,228 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_tiles(const uint32_t* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K4x  hamming_topk_mfma   the same exact search on the matrix cores. With every descriptor bit b written as the
+//                          MX-fp4 (E2M1) value 1 - 2b, the dot product of two descriptors is 256 - 2 * hamming: products
+//                          are +-1, the f32 accumulator holds integers <= 256, so the result is EXACT.
+//                          v_mfma_f32_32x32x64_f8f6f4 (fp4 x fp4, unit scales) takes 64 bit positions of 32 DB rows x 32
+//                          queries per issue: 4 MFMAs = 1024 complete distances in 128 matrix-pipe cycles (8 pairs per
+//                          clock and SIMD; the VALU form above peaks at 1, or ~2 when its elimination fires) and the
+//                          rate does not depend on the data.
+//                          One WAVE = (DB tile, 32 QT queries). The query fragments stay in registers (16 VGPRs per
+//                          32 queries); every lane loads 16 packed bytes of one DB row per 32-row step (a wave load = 32
+//                          rows = 1 KB contiguous, served by L2: all query waves of a tile read the same lines), expands
+//                          them to fp4 with 7 VALU ops per 32 bits, no LDS, no barrier. A and B use the same
+//                          (lane, register, nibble) -> bit assignment, so the sum runs over matching bit positions whatever
+//                          the hardware's internal k order is.
+//                          Accumulator layout (dtype independent): lane = query column (l & 31), 16 registers = 16 DB
+//                          rows (i & 3) + 8 (i >> 2) + 4 (l >> 5). A lane keeps its k best keys in registers exactly as
+//                          K4 does; the test per 32 x 32 block is max over the 16 registers > threshold (8 v_max3 + 1
+//                          compare, in the shadow of the next block's MFMAs) and only a block with a hit walks its registers.
+//                          Bounds are exchanged between tiles through the same per-query word as K4 (loaded one period
+//                          ahead, so the latency of the load is never waited for). Output = K4's partial-key layout.
+typedef int mfma_i32x8 __attribute__((ext_vector_type(8)));
+typedef float mfma_f32x16 __attribute__((ext_vector_type(16)));
+
+// 32 descriptor bits -> 32 fp4 values (4 dwords): nibble i of out[j] = 0x2 | (bit (4 i + j) << 3)  (+1.0 / -1.0 in E2M1).
+// The two constants live in registers (gfx9 VOP3 takes no literal), so each dword is one shift + one v_and_or_b32.
+struct Fp4Consts { uint32_t sign, one; };
+__device__ __forceinline__ Fp4Consts fp4_consts() {
+  Fp4Consts k;
+  asm volatile("s_mov_b32 %0, 0x88888888" : "=s"(k.sign));
+  asm volatile("v_mov_b32 %0, 0x22222222" : "=v"(k.one));
+  return k;
+}
+__device__ __forceinline__ mfma_i32x8 expand_word(uint32_t x, const Fp4Consts& k) {
+  const int a = (int)(((x << 3) & k.sign) | k.one), b = (int)(((x << 2) & k.sign) | k.one),
+            c = (int)(((x << 1) & k.sign) | k.one), d = (int)((x & k.sign) | k.one);
+  return mfma_i32x8{a, b, c, d, 0, 0, 0, 0};
+}
+
+struct Fp4Row { mfma_i32x8 s[4]; };   // the lane's 128 bits of one row: 4 MFMA steps x 4 dwords (upper halves unused by fp4)
+
+__device__ __forceinline__ void expand_row(const uint4& p, Fp4Row& f, const Fp4Consts& k) {
+  f.s[0] = expand_word(p.x, k); f.s[1] = expand_word(p.y, k); f.s[2] = expand_word(p.z, k); f.s[3] = expand_word(p.w, k);
+}
+
+__device__ __forceinline__ float thr_of_limit(uint32_t limit) { return 256.f - 2.f * (float)limit; }   // dot > thr <=> d < limit
+
+// 256 bit positions of 32 DB rows (A) x 32 queries (B): acc[i] of lane l = dot(row (i & 3) + 8 (i >> 2) + 4 (l >> 5), query l & 31)
+__device__ __forceinline__ mfma_f32x16 dot_block(const Fp4Row& a, const Fp4Row& b) {
+  mfma_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a.s[s], b.s[s], acc, 4, 4, 0, 0, 0, 0);
+  return acc;
+}
+
+// The test of one accumulator block: nothing to do unless some lane's best dot product beats its threshold (rare: the
+// thresholds follow the k-th best distance found so far, anywhere in the DB); then walk the block's 16 rows. MASK: rows at
+// or beyond n_lim do not exist (the last, partial step of the DB).
+template <int K, bool MASK>
+__device__ __forceinline__ void mfma_block_test(const mfma_f32x16& acc, float& thr, uint32_t r_lane, uint32_t n_lim,
+                                                uint32_t (&best)[K]) {
+  if (!MASK) {
+    float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, acc[i]), acc[i + 1]);
+    m = fmaxf(m, acc[15]);
+    if (__builtin_amdgcn_ballot_w64(m > thr) == 0ull) return;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    // the block's row i = r_lane | ((i & 3) + 8 (i >> 2)): r_lane = 32 step + 4 (lane >> 5) leaves bits 0, 1, 3, 4 free
+    const uint32_t ri = (uint32_t)((i & 3) + 8 * (i >> 2));
+    const bool hit = MASK ? (acc[i] > thr && (r_lane | ri) < n_lim) : (acc[i] > thr);
+    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+      // key = distance << 22 | row: (256 - dot) * 2^21 is an exact integer below 2^31. A stale (looser) threshold only
+      // lets more rows try: the list keeps its k smallest keys whatever is offered
+      const uint32_t key = (uint32_t)((256.f - acc[i]) * 2097152.f) | r_lane | ri;
+      topk_insert<K>(best, hit ? key : 0xFFFFFFFFu);
+    }
+  }
+  thr = fmaxf(thr, thr_of_limit(best[K - 1] >> kLocalBits));       // thresholds only ever tighten
+}
+
+// One 32-row step: QT x 4 MFMAs against the resident query fragments. The test of block t-1 (and, in the first four
+// blocks, the fp4 expansion of the NEXT step's packed rows) sits in the same basic block as the MFMAs of block t, so the
+// vector ALU works in the matrix pipe's shadow; the last block's test is carried into the next step (accP / rP).
+template <int K, int QT, bool MASK>
+__device__ __forceinline__ void mfma_step(const Fp4Row& a, Fp4Row& a_next, const uint4& p_next, const Fp4Row (&qb)[QT],
+                                          float (&thr)[QT], uint32_t (&best)[QT][K], mfma_f32x16& accP, uint32_t& rP,
+                                          uint32_t r_lane, uint32_t n_lim, const Fp4Consts& kc) {
+  mfma_f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    acc[t & 1] = dot_block(a, qb[t]);
+    if (t == 0) a_next.s[0] = expand_word(p_next.x, kc);
+    if (t == 1) a_next.s[1] = expand_word(p_next.y, kc);
+    if (t == 2) a_next.s[2] = expand_word(p_next.z, kc);
+    if (t == 3) a_next.s[3] = expand_word(p_next.w, kc);
+    if (t == 0) mfma_block_test<K, false>(accP, thr[QT - 1], rP, n_lim, best[QT - 1]);   // the previous step is never partial
+    else mfma_block_test<K, MASK>(acc[(t - 1) & 1], thr[t - 1], r_lane, n_lim, best[t - 1]);
+  }
+  accP = acc[(QT - 1) & 1];
+  rP = r_lane;
+}
+
+template <int K, int QT>
+__global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* __restrict__ db,
+                                                               const uint32_t* __restrict__ q, uint32_t n_rows,
+                                                               uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
+                                                               uint32_t n_tiles, uint32_t n_qw, uint32_t n_qw64,
+                                                               uint32_t blocks_per_xcd, uint32_t tiles_per_xcd, uint32_t cut,
+                                                               uint32_t share_period,
+                                                               uint32_t* __restrict__ part, uint32_t* bound,
+                                                               uint8_t* __restrict__ stored) {
+  static_assert(QT % 2 == 0 && QT >= 4, "two query blocks share a 64-query flag byte; the expansion uses four blocks");
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  uint32_t tile, qw;
+  if (tiles_per_xcd) {
+    const uint32_t local = __builtin_amdgcn_readfirstlane(slot * kWavesPerBlock + (threadIdx.x >> 6));
+    if (local >= tiles_per_xcd * n_qw) return;
+    tile = xcd * tiles_per_xcd + local / n_qw; qw = local % n_qw;
+  } else {
+    const uint32_t vblock = xcd * blocks_per_xcd + slot;
+    const uint32_t item = __builtin_amdgcn_readfirstlane(vblock * kWavesPerBlock + (threadIdx.x >> 6));
+    tile = item / n_qw; qw = item % n_qw;
+  }
+  if (tile >= n_tiles) return;
+  const uint32_t lane = threadIdx.x & 63u, c = lane & 31u, h = lane >> 5;
+  const uint32_t q0 = qw * (32u * QT);
+
+  const Fp4Consts kc = fp4_consts();
+  // query blocks beyond nq repeat the last query: their results are never stored
+  Fp4Row qb[QT];
+  uint32_t best[QT][K];
+  float thr[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const uint32_t qi = q0 + 32u * t + c;
+    const uint4 p = *reinterpret_cast<const uint4*>(q + (size_t)(qi < nq ? qi : nq - 1u) * kWords + 4u * h);
+    expand_row(p, qb[t], kc);
+#pragma unroll
+    for (int j = 0; j < K; ++j) best[t][j] = 0xFFFFFFFFu;
+    // cut = radius + 1: a row beyond the radius is dropped by the truncation (DescriptorMatcher.cpp:212-220) whatever its rank
+    thr[t] = thr_of_limit(cut);
+  }
+
+  const uint32_t row0 = tile * rows_per_tile;
+  const uint32_t row_end = min(n_rows, row0 + rows_per_tile);
+  const uint32_t n_local = row_end - row0;                          // > 0: tile < n_tiles
+  const uint32_t n_full = n_local / 32u, n_steps = (n_local + 31u) / 32u;   // the DB's last step may be partial
+  const uint32_t last_row = n_rows - 1u;
+  // this lane's 16 bytes of DB row (row0 + 32 step + c), clamped into the DB (rows past the end are masked, not used)
+  auto load_step = [&](uint32_t step) -> uint4 {
+    const uint32_t r = min(row0 + 32u * step + c, last_row);
+    return *reinterpret_cast<const uint4*>(db + (size_t)r * kWords + 4u * h);
+  };
+  Fp4Row a, a_next;
+  {
+    const uint4 p = load_step(0);
+    expand_row(p, a, kc);
+  }
+  uint4 pa = load_step(1u < n_steps ? 1u : 0u);                    // packed rows of step + 1 (expanded during step)
+  mfma_f32x16 accP;                                                 // pending block of the previous step: none yet
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accP[i] = -1024.f;
+  uint32_t rP = 0;
+  uint32_t seen[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) seen[t] = 0xFFFFFFFFu;              // "nothing published"
+  uint32_t next_share = 2u;                                         // first exchange after 64 rows, as K4
+
+  for (uint32_t step = 0; step < n_full; ++step) {
+    const uint4 pb = load_step(step + 2u < n_steps ? step + 2u : n_steps - 1u);   // in flight for a whole step
+    mfma_step<K, QT, false>(a, a_next, pa, qb, thr, best, accP, rP, 32u * step + 4u * h, n_local, kc);
+    a = a_next;
+    pa = pb;
+    if (step + 1u == next_share) {                                  // wave-uniform
+      next_share += share_period;
+      // take the bounds loaded one period ago (a published bound stays valid: bounds only fall), publish a full list's
+      // bound if it improves on what was seen, start the loads of the next period
+#pragma unroll
+      for (int t = 0; t < QT; ++t) {
+        const uint32_t qi = q0 + 32u * t + c;
+        uint32_t* my_bound = bound + (qi < nq ? qi : nq - 1u);
+        const uint32_t worst_d = best[t][K - 1] >> kLocalBits;
+        if (worst_d < (0xFFFFFFFFu >> kLocalBits) && worst_d < seen[t]) atomicMin(my_bound, worst_d);
+        // a foreign bound is applied with <=: a smaller row index elsewhere may still win a tie
+        if (seen[t] != 0xFFFFFFFFu) thr[t] = fmaxf(thr[t], thr_of_limit(seen[t] + 1u));
+        seen[t] = __hip_atomic_load(my_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  if (n_full < n_steps) mfma_step<K, QT, true>(a, a_next, pa, qb, thr, best, accP, rP, 32u * n_full + 4u * h, n_local, kc);
+  mfma_block_test<K, true>(accP, thr[QT - 1], rP, n_local, best[QT - 1]);   // drain the last pending block
+
+  // lanes l and l + 32 hold the two halves of a query's rows: merge the partner's list, then K4's output format
+  // (partial keys + one flag byte per (tile, 64 queries); two query blocks share a flag, so both are stored when
+  // either kept something)
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    uint32_t other[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) other[j] = __shfl_xor(best[t][j], 32);
+#pragma unroll
+    for (int j = 0; j < K; ++j) topk_insert<K>(best[t], other[j]);
+  }
+#pragma unroll
+  for (int u = 0; u < QT / 2; ++u) {
+    const uint32_t qa = q0 + 64u * u + c, qb2 = qa + 32u;
+    const bool any_a = qa < nq && best[2 * u][0] != 0xFFFFFFFFu, any_b = qb2 < nq && best[2 * u + 1][0] != 0xFFFFFFFFu;
+    if (__builtin_amdgcn_ballot_w64(any_a || any_b) != 0ull) {
+      if (h == 0u) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          if (qa < nq) part[((size_t)tile * K + j) * nq_pad + qa] = best[2 * u][j];
+          if (qb2 < nq) part[((size_t)tile * K + j) * nq_pad + qb2] = best[2 * u + 1][j];
+        }
+      }
+      if (lane == 0) stored[(size_t)tile * n_qw64 + (q0 >> 6) + u] = 0;
+    }
+  }
+}
+
 // K4m: thread (query, group) merges the tiles t = group, group + G, ... ; keys become
 // (distance << 32 | global_row), unique per row, so any merge order gives the same k smallest.
 // Output layout [group][nq][K] == the [shard][nq][k] layout finalize_kernel consumes.
@@ -390,8 +612,68 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __rest
   counts[qi] = kept;
 }
 
+// 0: K4 on the VALU, 1: K4x on the matrix cores. todhip_set_matcher_engine() decides; while it says "auto" the
+// environment variable TODHIP_K4_ENGINE=valu|mfma does (whole test suites can be run on either engine that way).
+int k4_engine(const todhip_ctx* ctx, uint32_t nq) {
+  if (ctx->matcher_engine == TODHIP_ENGINE_VALU) return 0;
+  if (ctx->matcher_engine == TODHIP_ENGINE_MFMA) return 1;
+  static const char* env = getenv("TODHIP_K4_ENGINE");
+  if (env && env[0] == 'v') return 0;
+  if (env && env[0] == 'm') return 1;
+  (void)nq;
+  return 0;
+}
+
+template <int K>
+int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radius, uint64_t* d_lists, uint32_t* n_lists) {
+  constexpr int QT = K <= 2 ? 6 : 4;                                  // query blocks of 32 per wave (register budget)
+  const uint32_t cut = radius >= 256u ? 0xFFFFFFFFu >> kLocalBits : radius + 1u;   // distances are <= 256: no cut beyond that
+  const uint32_t n_rows = (uint32_t)ctx->shard_rows;
+  const uint32_t n_qw = (nq + 32u * QT - 1u) / (32u * QT), n_qw64 = (nq + 63u) / 64u;
+  const uint32_t nq_pad = n_qw64 * 64u;
+  // about three times more waves than the chip holds at once (2 per SIMD), tiles of whole 32-row steps, >= 256 rows
+  static const int env_wpc = getenv("TODHIP_K4X_WAVES_PER_CU") ? atoi(getenv("TODHIP_K4X_WAVES_PER_CU")) : 24;
+  uint32_t n_tiles = std::max(1u, (uint32_t)ctx->n_cu * (uint32_t)env_wpc / n_qw);
+  n_tiles = std::min(n_tiles, std::max(1u, n_rows / 256u));
+  n_tiles = std::min(n_tiles, 8192u);
+  if (n_tiles >= 8) n_tiles = (n_tiles + 7u) & ~7u;
+  uint32_t rows_per_tile = (n_rows + n_tiles - 1) / n_tiles;
+  rows_per_tile = (rows_per_tile + 31u) & ~31u;
+  if (rows_per_tile > kLocalMask) return TODHIP_EINVAL;
+  n_tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
+  const uint32_t items = n_tiles * n_qw;
+  const uint32_t blocks = (items + kWavesPerBlock - 1) / kWavesPerBlock;
+  uint32_t blocks_per_xcd = (blocks + 7u) / 8u;
+  uint32_t tiles_per_xcd = 0;
+  if (n_tiles >= 8 && n_tiles % 8u == 0) {
+    tiles_per_xcd = n_tiles / 8u;
+    blocks_per_xcd = (tiles_per_xcd * n_qw + kWavesPerBlock - 1) / kWavesPerBlock;
+  }
+  static const int env_share = getenv("TODHIP_K4X_SHARE") ? atoi(getenv("TODHIP_K4X_SHARE")) : 16;
+  const uint32_t groups = n_tiles < (uint32_t)kMergeGroups ? n_tiles : (uint32_t)kMergeGroups;
+  TOD_HIP(ctx->m_part.reserve((size_t)n_tiles * K * nq_pad * sizeof(uint32_t)));
+  const size_t bound_bytes = (size_t)nq_pad * sizeof(uint32_t), flag_bytes = (size_t)n_tiles * n_qw64;
+  TOD_HIP(ctx->m_bound.reserve(bound_bytes + flag_bytes));
+  TOD_HIP(hipMemsetAsync(ctx->m_bound.p, 0xFF, bound_bytes + flag_bytes, ctx->stream));
+  uint8_t* const d_stored = ctx->m_bound.as<uint8_t>() + bound_bytes;
+  int slot = -1;
+  if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
+  hipLaunchKernelGGL((hamming_topk_mfma<K, QT>), dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
+                     ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw, n_qw64,
+                     blocks_per_xcd, tiles_per_xcd, cut, (uint32_t)std::max(1, env_share), ctx->m_part.as<uint32_t>(),
+                     ctx->m_bound.as<uint32_t>(), d_stored);
+  if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
+  hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
+                     ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
+                     d_stored, n_qw64, d_lists);
+  TOD_HIP(hipGetLastError());
+  *n_lists = groups;
+  return TODHIP_OK;
+}
+
 template <int K>
 int launch_topk(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radius, uint64_t* d_lists, uint32_t* n_lists) {
+  if (k4_engine(ctx, nq) == 1) return launch_topk_mfma<K>(ctx, d_q, nq, radius, d_lists, n_lists);
   const uint32_t cut = radius >= 256u ? 0xFFFFFFFFu : radius + 1u;   // distances are <= 256: no cut beyond that
   const uint32_t n_rows = (uint32_t)ctx->shard_rows;
   const uint32_t n_qw = (nq + 63u) / 64u;
