@@ -123,6 +123,13 @@ int todhip_match_shard_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, ui
 int todhip_merge_shards_device(todhip_ctx*, const void* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
                                uint32_t radius, void* d_counts, void* d_matches, void* d_matches_xyz);
 
+/* The same merge launched on a stream of the caller's instead of the context's: it only READS the context's immutable
+ * object table and model points, so it may run beside a todhip_match_shard_device call that is in flight on the context's
+ * own stream (the multi-GPU step puts collectives + merge on a second stream, tod_amd/sharded.py). The caller orders the
+ * stream against the producer of d_keys_all and the consumers of the outputs. */
+int todhip_merge_shards_device_on(todhip_ctx*, void* hip_stream, const void* d_keys_all, uint32_t n_shards, uint32_t nq,
+                                  uint32_t k, uint32_t radius, void* d_counts, void* d_matches, void* d_matches_xyz);
+
 /* ---- stage C: GuessGenerator ------------------------------------------------------------------- */
 void todhip_rng_seed(todhip_rng*, uint32_t seed);   /* srand(seed); the reference never seeds => seed 1 */
 /* Replaces GuessGenerator::process (GuessGenerator.cpp:127-250) and everything under src/common.

@@ -9,9 +9,25 @@ from tod_amd import capi, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+ENGINE = {"name": "auto"}     # the engine of the context under test; the sharded helper's own contexts follow it
+
+
+@pytest.fixture(scope="module", params=["valu", "mfma"])
+def ctx(request):
+    """Every test of this module runs on both engines of the exact search: K4 (vector ALU) and K4x (matrix cores)."""
     c = capi.Context(0)
+    c.set_matcher_engine(request.param)
+    ENGINE["name"] = request.param
+    yield c
+    c.close()
+    ENGINE["name"] = "auto"
+
+
+@pytest.fixture(scope="module")
+def ctx_auto():
+    """The engine the library picks by launch shape (the big, oracle-bound tests run once, on that)."""
+    c = capi.Context(0)
+    ENGINE["name"] = "auto"
     yield c
     c.close()
 
@@ -117,6 +133,7 @@ def _shard_merge(desc, pts, off, q, k, radius, n_shards):
     ctxs = []
     for s in range(n_shards):
         c = capi.Context(0)
+        c.set_matcher_engine(ENGINE["name"])
         c.db_load(desc, pts, off, shard_rank=s, shard_count=n_shards)
         c.match_shard_device(d_q.data_ptr(), nq, k, radius, keys_all[s].data_ptr())
         c.synchronize()
@@ -199,7 +216,8 @@ def test_shard_layout_matches_python_mirror(ctx):
             c.close()
 
 
-def test_c5_shape_1080p_orb2000_2m_rows(ctx):
+def test_c5_shape_1080p_orb2000_2m_rows(ctx_auto):
+    ctx = ctx_auto
     """BASELINE configs[4] on one GPU: ORB-2000 frame vs a 2M-descriptor DB (400 objects x 5000), k=5, radius 35.
     Size-independent properties for all queries, the oracle for a subset."""
     desc, pts, off = synth.make_db(400)
@@ -256,7 +274,8 @@ def test_batch_of_frames_in_one_launch_equals_frame_by_frame(ctx):
         assert np.array_equal(cb[f * nq:(f + 1) * nq].cpu().numpy(), np.diff(row_ptr.astype(np.int64)))
 
 
-def test_ten_million_row_database_properties(ctx):
+def test_ten_million_row_database_properties(ctx_auto):
+    ctx = ctx_auto
     """Beyond the benchmark's size: 10M rows (2000 objects x 5000, 320 MB of descriptors) in one shard -- row indices past
     2^23, the tile count at its cap. Planted rows are found first, every distance is the pair's true distance, lists
     ascend, and 16 queries equal the oracle bit for bit. Then the same DB cut into 3 shards and merged."""
@@ -284,3 +303,60 @@ def test_ten_million_row_database_properties(ctx):
     counts, ms, xyzs, infos = _shard_merge(desc, pts, off, fr["q_desc"], 3, 255, 3)
     assert np.array_equal(ms["trainIdx"], m["trainIdx"]) and np.array_equal(ms["imgIdx"], m["imgIdx"])
     assert np.array_equal(ms["distance"], m["distance"]) and sum(i["shard_rows"] for i in infos) == 10_000_000
+
+
+def test_bench_launch_shape_16000_queries_1m_rows(ctx):
+    """The exact launch bench.py times: 16 frames x 1000 descriptors in one pass over the 1M-row DB, k = 2, radius 35
+    (BASELINE configs[2] on one GPU). Size-independent properties for all 16 000 queries, the oracle bit for bit on 64."""
+    import torch
+    desc, pts, off = synth.make_db(200)
+    ctx.db_load(desc, pts, off)
+    F, nq, k, radius = 16, 1000, 2, 35
+    frames = [synth.make_frame(desc, pts, off, nq, frame=f, visible_object=(17 * f + 3) % 200) for f in range(F)]
+    q = np.concatenate([fr["q_desc"] for fr in frames])
+    truth = np.concatenate([fr["truth_rows"] for fr in frames])
+    n = F * nq
+    d_q = torch.from_numpy(q).cuda()
+    cnt = torch.zeros(n, dtype=torch.int32, device="cuda"); mm = torch.zeros((n * k, 4), dtype=torch.int32, device="cuda")
+    xx = torch.zeros((n * k, 3), dtype=torch.float32, device="cuda")     # zeroed: slots beyond a query's count are not written
+    ctx.match_device(d_q.data_ptr(), n, k, radius, cnt.data_ptr(), mm.data_ptr(), xx.data_ptr())
+    ctx.synchronize()
+    cnt = cnt.cpu().numpy(); m = mm.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(n, k); xyz = xx.cpu().numpy().reshape(n, k, 3)
+    keep = np.arange(k)[None, :] < cnt[:, None]
+    rows = off[m["imgIdx"]].astype(np.int64) + m["trainIdx"]
+    lut = np.array([bin(i).count("1") for i in range(256)], np.uint32)
+    qq = np.broadcast_to(np.arange(n)[:, None], (n, k))
+    assert np.array_equal(m["queryIdx"][keep], qq[keep])
+    true_d = lut[np.bitwise_xor(desc[rows[keep]], q[qq[keep]])].sum(axis=1)
+    assert np.array_equal(true_d.astype(np.float32), m["distance"][keep]) and (true_d <= radius).all()
+    both = cnt == 2
+    assert ((m["distance"][both, 0] < m["distance"][both, 1]) |
+            ((m["distance"][both, 0] == m["distance"][both, 1]) & (rows[both, 0] < rows[both, 1]))).all()
+    planted = np.flatnonzero(truth >= 0)
+    found = cnt[planted] >= 1
+    assert found.mean() > 0.99 and np.array_equal(rows[planted[found], 0], truth[planted[found]])
+    assert np.array_equal(xyz[keep], pts[rows[keep]])
+    sub = np.arange(7, n, 250)                                         # 64 queries against all 1M rows on the CPU
+    keys = O.knn_keys(desc, q[sub], k)
+    for i, qi in enumerate(sub):
+        want = [int(kk) for kk in keys[i] if (int(kk) >> 32) <= radius]
+        got = [(int(d) << 32) | int(r) for d, r in zip(m["distance"][qi, :cnt[qi]], rows[qi, :cnt[qi]])]
+        assert got == want
+
+
+def test_c3_partition_1m_rows_8_shards_equals_unsharded(ctx):
+    """BASELINE configs[2]'s own partition: the 1M-row DB cut into 8 object-aligned shards (125k rows each), every shard
+    searched on its own, keys merged -- equal to the single-device result for a whole frame."""
+    import torch
+    desc, pts, off = synth.make_db(200)
+    fr = synth.make_frame(desc, pts, off, 1000, frame=11, visible_object=42)
+    q = fr["q_desc"]
+    q[5] = desc[124_999]; q[6] = desc[125_000]                         # rows either side of a shard boundary
+    counts, ms, xyzs, infos = _shard_merge(desc, pts, off, q, 2, 35, 8)
+    assert [i["shard_rows"] for i in infos] == [125_000] * 8
+    ctx.db_load(desc, pts, off)
+    row_ptr, m, xyz = ctx.match(q, 2, 35)
+    assert np.array_equal(np.diff(row_ptr.astype(np.int64)), counts)
+    for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
+        assert np.array_equal(ms[f], m[f]), f
+    assert np.array_equal(xyzs, xyz)

@@ -53,7 +53,7 @@ class Counters(C.Structure):
 EXPORTS = [
     "todhip_version", "todhip_create", "todhip_destroy", "todhip_stream", "todhip_last_hip_error",
     "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_db_load", "todhip_db_info",
-    "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device",
+    "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device", "todhip_merge_shards_device_on",
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
     "todhip_orb_device", "todhip_verify_device_depth", "todhip_orb_batch_device",
@@ -221,6 +221,13 @@ class Context:
                                               C.c_uint32(k), C.c_uint32(radius), C.c_void_p(d_counts),
                                               C.c_void_p(d_matches), C.c_void_p(d_xyz))
         _check(rc, "todhip_merge_shards_device")
+
+    def merge_shards_device_on(self, stream, d_keys_all, n_shards, nq, k, radius, d_counts, d_matches, d_xyz):
+        """The merge on a stream of the caller's (it only reads the context's immutable tables)."""
+        rc = lib().todhip_merge_shards_device_on(self._h, C.c_void_p(stream), C.c_void_p(d_keys_all), C.c_uint32(n_shards),
+                                                 C.c_uint32(nq), C.c_uint32(k), C.c_uint32(radius), C.c_void_p(d_counts),
+                                                 C.c_void_p(d_matches), C.c_void_p(d_xyz))
+        _check(rc, "todhip_merge_shards_device_on")
 
     # ---------------------------------------------------------------- stage C
     def verify(self, kp_xy, cloud, row_ptr, matches, matches_xyz, spans, min_inliers, n_iter, err, rng,

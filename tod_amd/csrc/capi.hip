@@ -199,6 +199,16 @@ int todhip_merge_shards_device(todhip_ctx* ctx, const void* d_keys_all, uint32_t
                             reinterpret_cast<float*>(d_matches_xyz));
 }
 
+int todhip_merge_shards_device_on(todhip_ctx* ctx, void* hip_stream, const void* d_keys_all, uint32_t n_shards, uint32_t nq,
+                                  uint32_t k, uint32_t radius, void* d_counts, void* d_matches, void* d_matches_xyz) {
+  if (!ctx || !hip_stream || !d_keys_all || !d_counts || !d_matches || !d_matches_xyz) return TODHIP_EINVAL;
+  if (k == 0 || k > 8 || radius == 0 || n_shards == 0) return TODHIP_EINVAL;
+  if (ctx->total_rows == 0) return TODHIP_ENODB;
+  return tod_match_finalize(ctx, reinterpret_cast<const uint64_t*>(d_keys_all), n_shards, nq, k, radius,
+                            reinterpret_cast<uint32_t*>(d_counts), reinterpret_cast<todhip_dmatch*>(d_matches),
+                            reinterpret_cast<float*>(d_matches_xyz), reinterpret_cast<hipStream_t>(hip_stream));
+}
+
 int todhip_match_device(todhip_ctx* ctx, const void* d_q_desc, uint32_t nq, uint32_t k, uint32_t radius,
                         void* d_counts, void* d_matches, void* d_matches_xyz) {
   if (!ctx || !d_q_desc || !d_counts || !d_matches || !d_matches_xyz) return TODHIP_EINVAL;

@@ -115,7 +115,8 @@ int tod_match_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, u
 size_t tod_match_lists_bytes(uint32_t nq, uint32_t k);
 int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint32_t radius, uint64_t* d_keys);
 int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
-                       uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz);
+                       uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz,
+                       hipStream_t stream = nullptr);   // nullptr: the context's stream
 // verify.hip / orb.hip
 void tod_verify_ws_free(todhip_ctx* ctx);
 void tod_l2_ws_free(todhip_ctx* ctx);

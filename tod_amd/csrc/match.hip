@@ -322,16 +322,28 @@ __device__ __forceinline__ mfma_f32x16 dot_block(const Fp4Row& a, const Fp4Row& 
 
 // The test of one accumulator block: nothing to do unless some lane's best dot product beats its threshold (rare: the
 // thresholds follow the k-th best distance found so far, anywhere in the DB); then walk the block's 16 rows. MASK: rows at
-// or beyond n_lim do not exist (the last, partial step of the DB).
-template <int K, bool MASK>
+// or beyond n_lim do not exist (the last, partial step of the DB). IMAX: thresholds are >= 0 (radius < 128; they only rise),
+// so the 16-way maximum may be taken on the raw bits as integers -- among non-negative floats the order is the same, and a
+// negative dot product can never beat a non-negative threshold -- which spares the float maximum's NaN-quieting moves.
+template <int K, bool MASK, bool IMAX>
 __device__ __forceinline__ void mfma_block_test(const mfma_f32x16& acc, float& thr, uint32_t r_lane, uint32_t n_lim,
                                                 uint32_t (&best)[K]) {
   if (!MASK) {
-    float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+    bool any;
+    if (IMAX) {
+      int m = max(max(__float_as_int(acc[0]), __float_as_int(acc[1])), __float_as_int(acc[2]));
 #pragma unroll
-    for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, acc[i]), acc[i + 1]);
-    m = fmaxf(m, acc[15]);
-    if (__builtin_amdgcn_ballot_w64(m > thr) == 0ull) return;
+      for (int i = 3; i < 15; i += 2) m = max(max(m, __float_as_int(acc[i])), __float_as_int(acc[i + 1]));
+      m = max(m, __float_as_int(acc[15]));
+      any = m > __float_as_int(thr);
+    } else {
+      float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+      for (int i = 3; i < 15; i += 2) m = fmaxf(fmaxf(m, acc[i]), acc[i + 1]);
+      m = fmaxf(m, acc[15]);
+      any = m > thr;
+    }
+    if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -350,27 +362,25 @@ __device__ __forceinline__ void mfma_block_test(const mfma_f32x16& acc, float& t
 
 // One 32-row step: QT x 4 MFMAs against the resident query fragments. The test of block t-1 (and, in the first four
 // blocks, the fp4 expansion of the NEXT step's packed rows) sits in the same basic block as the MFMAs of block t, so the
-// vector ALU works in the matrix pipe's shadow; the last block's test is carried into the next step (accP / rP).
-template <int K, int QT, bool MASK>
+// vector ALU works in the matrix pipe's shadow; the last block's test is carried into the next step: QT is even, so it
+// waits in acc_odd while block 0 of the next step fills acc_even.
+template <int K, int QT, bool MASK, bool IMAX>
 __device__ __forceinline__ void mfma_step(const Fp4Row& a, Fp4Row& a_next, const uint4& p_next, const Fp4Row (&qb)[QT],
-                                          float (&thr)[QT], uint32_t (&best)[QT][K], mfma_f32x16& accP, uint32_t& rP,
-                                          uint32_t r_lane, uint32_t n_lim, const Fp4Consts& kc) {
-  mfma_f32x16 acc[2];
+                                          float (&thr)[QT], uint32_t (&best)[QT][K], mfma_f32x16& acc_even,
+                                          mfma_f32x16& acc_odd, uint32_t r_lane, uint32_t n_lim, const Fp4Consts& kc) {
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    acc[t & 1] = dot_block(a, qb[t]);
+    if (t & 1) acc_odd = dot_block(a, qb[t]); else acc_even = dot_block(a, qb[t]);
     if (t == 0) a_next.s[0] = expand_word(p_next.x, kc);
     if (t == 1) a_next.s[1] = expand_word(p_next.y, kc);
     if (t == 2) a_next.s[2] = expand_word(p_next.z, kc);
     if (t == 3) a_next.s[3] = expand_word(p_next.w, kc);
-    if (t == 0) mfma_block_test<K, false>(accP, thr[QT - 1], rP, n_lim, best[QT - 1]);   // the previous step is never partial
-    else mfma_block_test<K, MASK>(acc[(t - 1) & 1], thr[t - 1], r_lane, n_lim, best[t - 1]);
+    if (t == 0) mfma_block_test<K, MASK, IMAX>(acc_odd, thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]);   // previous step's last block
+    else mfma_block_test<K, MASK, IMAX>((t & 1) ? acc_even : acc_odd, thr[t - 1], r_lane, n_lim, best[t - 1]);
   }
-  accP = acc[(QT - 1) & 1];
-  rP = r_lane;
 }
 
-template <int K, int QT>
+template <int K, int QT, bool IMAX, bool PF2>
 __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* __restrict__ db,
                                                                const uint32_t* __restrict__ q, uint32_t n_rows,
                                                                uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
@@ -418,30 +428,38 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   const uint32_t last_row = n_rows - 1u;
   // this lane's 16 bytes of DB row (row0 + 32 step + c), clamped into the DB (rows past the end are masked, not used)
   auto load_step = [&](uint32_t step) -> uint4 {
-    const uint32_t r = min(row0 + 32u * step + c, last_row);
+    const uint32_t r = min(row0 + 32u * min(step, n_steps - 1u) + c, last_row);
     return *reinterpret_cast<const uint4*>(db + (size_t)r * kWords + 4u * h);
   };
-  Fp4Row a, a_next;
+  Fp4Row a0, a1;
   {
     const uint4 p = load_step(0);
-    expand_row(p, a, kc);
+    expand_row(p, a0, kc);
   }
-  uint4 pa = load_step(1u < n_steps ? 1u : 0u);                    // packed rows of step + 1 (expanded during step)
-  mfma_f32x16 accP;                                                 // pending block of the previous step: none yet
+  // packed rows in flight: of steps + 1 and + 2 (PF2), or of step + 1 only (4 registers less: what lets QT = 8 fit)
+  uint4 pa = load_step(1), pb = PF2 ? load_step(2) : pa;
+  mfma_f32x16 acc_even, acc_odd;                                    // acc_odd: pending block of the previous step -- none yet
 #pragma unroll
-  for (int i = 0; i < 16; ++i) accP[i] = -1024.f;
-  uint32_t rP = 0;
+  for (int i = 0; i < 16; ++i) acc_odd[i] = -1024.f;
   uint32_t seen[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) seen[t] = 0xFFFFFFFFu;              // "nothing published"
   uint32_t next_share = 2u;                                         // first exchange after 64 rows, as K4
 
-  for (uint32_t step = 0; step < n_full; ++step) {
-    const uint4 pb = load_step(step + 2u < n_steps ? step + 2u : n_steps - 1u);   // in flight for a whole step
-    mfma_step<K, QT, false>(a, a_next, pa, qb, thr, best, accP, rP, 32u * step + 4u * h, n_local, kc);
-    a = a_next;
-    pa = pb;
-    if (step + 1u == next_share) {                                  // wave-uniform
+  uint32_t step = 0;
+  for (; step + 2u <= n_full; step += 2u) {
+    // two steps per trip: the expanded rows ping-pong between a0 and a1, the packed ones between pa and pb
+    mfma_step<K, QT, false, IMAX>(a0, a1, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 4u * h, n_local, kc);
+    if (PF2) {
+      pa = load_step(step + 3u);
+      mfma_step<K, QT, false, IMAX>(a1, a0, pb, qb, thr, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
+      pb = load_step(step + 4u);
+    } else {
+      pa = load_step(step + 2u);
+      mfma_step<K, QT, false, IMAX>(a1, a0, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
+      pa = load_step(step + 3u);
+    }
+    if (step + 2u >= next_share) {                                  // wave-uniform
       next_share += share_period;
       // take the bounds loaded one period ago (a published bound stays valid: bounds only fall), publish a full list's
       // bound if it improves on what was seen, start the loads of the next period
@@ -457,8 +475,13 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
       }
     }
   }
-  if (n_full < n_steps) mfma_step<K, QT, true>(a, a_next, pa, qb, thr, best, accP, rP, 32u * n_full + 4u * h, n_local, kc);
-  mfma_block_test<K, true>(accP, thr[QT - 1], rP, n_local, best[QT - 1]);   // drain the last pending block
+  // at most one full and one partial step are left: the masked form serves both
+  for (; step < n_steps; ++step) {
+    mfma_step<K, QT, true, IMAX>(a0, a1, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 4u * h, n_local, kc);
+    a0 = a1;
+    pa = PF2 ? pb : load_step(step + 2u);
+  }
+  mfma_block_test<K, true, IMAX>(acc_odd, thr[QT - 1], 32u * (n_steps - 1u) + 4u * h, n_local, best[QT - 1]);   // drain
 
   // lanes l and l + 32 hold the two halves of a query's rows: merge the partner's list, then K4's output format
   // (partial keys + one flag byte per (tile, 64 queries); two query blocks share a flag, so both are stored when
@@ -620,23 +643,31 @@ int k4_engine(const todhip_ctx* ctx, uint32_t nq) {
   static const char* env = getenv("TODHIP_K4_ENGINE");
   if (env && env[0] == 'v') return 0;
   if (env && env[0] == 'm') return 1;
-  (void)nq;
-  return 0;
+  // Measured (tools/k4_engines.py, ms per launch K4 | K4x): 16 000 x 1M 3.2 | 1.1 on independent bits and 5.7 | 1.35 on this
+  // repo's ORB descriptors; 1000 x 1M 0.25 | 0.085; 1000 x 100k 0.035 | 0.021; 500 x 5000 0.008 | 0.013. The matrix form
+  // pays from ~2^24 pairs on; below, a wave's 128-256 query columns and its fixed start-up cost more than they save.
+  return nq >= 64u && (uint64_t)nq * ctx->shard_rows >= (1ull << 24) ? 1 : 0;
 }
 
-template <int K>
-int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radius, uint64_t* d_lists, uint32_t* n_lists) {
-  constexpr int QT = K <= 2 ? 6 : 4;                                  // query blocks of 32 per wave (register budget)
+template <int K, int QT>
+int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radius, uint64_t* d_lists, uint32_t* n_lists) {
+  constexpr bool PF2 = QT < 8;                                        // register budget: see hamming_topk_mfma
   const uint32_t cut = radius >= 256u ? 0xFFFFFFFFu >> kLocalBits : radius + 1u;   // distances are <= 256: no cut beyond that
   const uint32_t n_rows = (uint32_t)ctx->shard_rows;
   const uint32_t n_qw = (nq + 32u * QT - 1u) / (32u * QT), n_qw64 = (nq + 63u) / 64u;
   const uint32_t nq_pad = n_qw64 * 64u;
-  // about three times more waves than the chip holds at once (2 per SIMD), tiles of whole 32-row steps, >= 256 rows
-  static const int env_wpc = getenv("TODHIP_K4X_WAVES_PER_CU") ? atoi(getenv("TODHIP_K4X_WAVES_PER_CU")) : 24;
-  uint32_t n_tiles = std::max(1u, (uint32_t)ctx->n_cu * (uint32_t)env_wpc / n_qw);
+  // Rounds of waves: the chip holds 8 of these waves per CU (2 per SIMD, by registers). A launch whose wave count is just
+  // under a whole number of rounds has no straggling last round (measured, tools/k4x_sweep.py, 16 000 x 1M: 16 waves per
+  // CU = 2 rounds 1.13 ms, 14 = 1.6 rounds 1.37 ms, 8 = all resident 1.36 ms, 32 .. 128 1.11 ms); four rounds while a tile
+  // then still has >= 48 steps (a tile starts with empty lists), two otherwise. Tiles are whole 32-row steps.
+  const int env_wpc = getenv("TODHIP_K4X_WAVES_PER_CU") ? atoi(getenv("TODHIP_K4X_WAVES_PER_CU")) : 0;   // tuning knobs, read per launch
+  uint32_t wpc = 32;
+  if ((uint64_t)n_rows * n_qw < (uint64_t)ctx->n_cu * wpc * 1536u) wpc = 16;
+  if (env_wpc > 0) wpc = (uint32_t)env_wpc;
+  uint32_t n_tiles = std::max(1u, (uint32_t)ctx->n_cu * wpc / n_qw);
   n_tiles = std::min(n_tiles, std::max(1u, n_rows / 256u));
   n_tiles = std::min(n_tiles, 8192u);
-  if (n_tiles >= 8) n_tiles = (n_tiles + 7u) & ~7u;
+  if (n_tiles >= 16) n_tiles &= ~7u;                                  // whole tiles per XCD, never more waves than asked for
   uint32_t rows_per_tile = (n_rows + n_tiles - 1) / n_tiles;
   rows_per_tile = (rows_per_tile + 31u) & ~31u;
   if (rows_per_tile > kLocalMask) return TODHIP_EINVAL;
@@ -649,7 +680,7 @@ int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t
     tiles_per_xcd = n_tiles / 8u;
     blocks_per_xcd = (tiles_per_xcd * n_qw + kWavesPerBlock - 1) / kWavesPerBlock;
   }
-  static const int env_share = getenv("TODHIP_K4X_SHARE") ? atoi(getenv("TODHIP_K4X_SHARE")) : 16;
+  const int env_share = getenv("TODHIP_K4X_SHARE") ? atoi(getenv("TODHIP_K4X_SHARE")) : 16;
   const uint32_t groups = n_tiles < (uint32_t)kMergeGroups ? n_tiles : (uint32_t)kMergeGroups;
   TOD_HIP(ctx->m_part.reserve((size_t)n_tiles * K * nq_pad * sizeof(uint32_t)));
   const size_t bound_bytes = (size_t)nq_pad * sizeof(uint32_t), flag_bytes = (size_t)n_tiles * n_qw64;
@@ -658,9 +689,11 @@ int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t
   uint8_t* const d_stored = ctx->m_bound.as<uint8_t>() + bound_bytes;
   int slot = -1;
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
-  hipLaunchKernelGGL((hamming_topk_mfma<K, QT>), dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
+  // radius < 128: every threshold is >= 0 and the block test may compare raw bits (see mfma_block_test)
+  auto kern = cut <= 128u ? hamming_topk_mfma<K, QT, true, PF2> : hamming_topk_mfma<K, QT, false, PF2>;
+  hipLaunchKernelGGL(kern, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw, n_qw64,
-                     blocks_per_xcd, tiles_per_xcd, cut, (uint32_t)std::max(1, env_share), ctx->m_part.as<uint32_t>(),
+                     blocks_per_xcd, tiles_per_xcd, cut, (uint32_t)std::max(2, env_share), ctx->m_part.as<uint32_t>(),
                      ctx->m_bound.as<uint32_t>(), d_stored);
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
@@ -669,6 +702,23 @@ int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t
   TOD_HIP(hipGetLastError());
   *n_lists = groups;
   return TODHIP_OK;
+}
+
+template <int K>
+int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radius, uint64_t* d_lists, uint32_t* n_lists) {
+  // Query blocks of 32 per wave (QT): as many as the registers hold beside the k-entry lists -- 8 for k <= 2, 6 for k <= 5
+  // (the reference's k, DescriptorMatcher.cpp:211), 4 beyond -- and among those the one that pads nq the least (a wave
+  // computes all its blocks; 1000 queries are 4 x 256 but 6 x 192). TODHIP_K4X_QT forces one (experiments).
+  constexpr int kMaxQT = K <= 2 ? 8 : (K <= 5 ? 6 : 4);
+  const int env_qt = getenv("TODHIP_K4X_QT") ? atoi(getenv("TODHIP_K4X_QT")) : 0;
+  auto padded = [&](uint32_t qt) { return (nq + 32u * qt - 1u) / (32u * qt) * (32u * qt); };
+  int qt = kMaxQT;
+  if (kMaxQT >= 8 && padded(6) < padded((uint32_t)qt)) qt = 6;
+  if (kMaxQT >= 6 && padded(4) < padded((uint32_t)qt)) qt = 4;
+  if ((env_qt == 4 || env_qt == 6 || env_qt == 8) && env_qt <= kMaxQT) qt = env_qt;
+  if (qt == 8) return launch_topk_mfma_qt<K, (kMaxQT >= 8 ? 8 : 4)>(ctx, d_q, nq, radius, d_lists, n_lists);
+  if (qt == 6) return launch_topk_mfma_qt<K, (kMaxQT >= 6 ? 6 : 4)>(ctx, d_q, nq, radius, d_lists, n_lists);
+  return launch_topk_mfma_qt<K, 4>(ctx, d_q, nq, radius, d_lists, n_lists);
 }
 
 template <int K>
@@ -798,10 +848,10 @@ int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t
 }
 
 int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
-                       uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz) {
+                       uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz, hipStream_t stream) {
   if (nq == 0) return TODHIP_OK;
   const uint32_t blocks = (nq + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, d_keys_all, n_shards, nq, k, radius,
+  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(kBlock), 0, stream ? stream : ctx->stream, d_keys_all, n_shards, nq, k, radius,
                      ctx->db_obj_off.as<uint32_t>(), ctx->n_objs, ctx->db_pts.as<float>(), d_counts, d_matches,
                      d_xyz);
   TOD_HIP(hipGetLastError());
