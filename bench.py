@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the detection hot path on MI355X (BASELINE.json metric).
 
-Workload (config C3 of BASELINE.json, also run at N=1 because the 1M-descriptor DB fits one GPU):
-one 640x480 synthetic frame = 1000 ORB descriptors matched against the 1M-descriptor object DB
-(200 objects x 5000), Hamming brute force k=2, radius 35, then geometric verification.
-With N GPUs (tod_amd/sharded.py) the descriptor rows are split into N object-aligned shards and a step
-processes 16 frames per rank: descriptors are all-gathered, every rank matches all N x 16 frames against
-its shard, the per-shard candidates are exchanged with one RCCL collective (all-to-all by default: a rank only needs
-the candidates of its own frames; --exchange all_gather for the literal all-gather), and every rank merges (order:
-distance asc, global row asc) and verifies its own frames. Per-GPU work is constant as N grows. The collectives and
-the merge run on their own stream, double buffered, so that they overlap the DB passes of the neighbouring steps
-(--serial-exchange puts them back on the matcher's stream in program order).
+Headline workload (config C3 of BASELINE.json, also run at N=1 because the 1M-descriptor DB fits one GPU): one 640x480
+synthetic frame = 1000 ORB descriptors matched against the 1M-descriptor object DB (200 objects x 5000), Hamming brute
+force k=2, radius 35, then geometric verification; stages ORB | matcher | verifier, each one batched call per step of 16
+frames, on three streams (tod_amd/pipeline.py). The three stages are sized and scheduled as in production but, in the
+headline, NOT data-chained: SURVEY 8(d)'s synthetic DB (independent bits) cannot be matched by descriptors of a synthetic
+image, so ORB runs on the 8(d) image while the matcher and verifier consume the frame's planted descriptors / keypoints.
+The `chained` block (N=1) times the real dataflow: DB trained by todhip_model_* on rendered views, ORB -> match -> verify
+consuming each other's device buffers (tod_amd/scenes.py).
 
-One JSON line on rank 0; see the task contract for the fields. `roofline` is for the dominant kernel
-(hamming_topk_tiles); `cpu_baseline` times the CPU oracle on a bounded sample of the same workload.
+With N GPUs (tod_amd/sharded.py::ShardedMatcher) the descriptor rows are split into N object-aligned shards and a step
+processes 16 frames per rank: descriptors are all-gathered, every rank matches all N x 16 frames against its shard, the
+per-shard candidates are exchanged with one RCCL collective (all-to-all by default: a rank only needs the candidates of
+its own frames; --exchange all_gather for the literal all-gather), and every rank merges (order: distance asc, global
+row asc) and verifies its own frames. Per-GPU work is constant as N grows (weak scaling). Launch: the driver's
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N`; a bare `python bench.py --gpus N`
+starts exactly that as a child process (before anything touches the GPU) and exits with its code.
+
+One JSON line on rank 0. `roofline` is for the dominant kernel (the matcher's DB pass); `cpu_baseline` times the CPU
+oracle on a bounded sample of the same workload; `repeats` = the timed region run several times (value = the median);
+`chained`, `configs` (C1, C2, C4, C5 single-GPU share) and `adapter_path` (one frame at a time through the host-buffer
+calls the ecto cells make) are measured after the timed region, at N=1 only.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -26,17 +36,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The HIP runtime maps a process's streams onto 4 hardware queues unless told otherwise, so at most ~4 of the
-# per-frame ORB/verifier streams would overlap (tools/stream_concurrency.py: 4 by default, 8 with more queues;
-# beyond 8 busy queues the driver time-slices them and every launch stalls, so 8 it is).
+# The HIP runtime maps a process's streams onto 4 hardware queues unless told otherwise (tools/stream_concurrency.py: 4 by
+# default, 8 with more queues; beyond 8 busy queues the driver time-slices them and every launch stalls, so 8 it is).
 # Must be in the environment before the runtime is loaded (i.e. before torch is imported).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) issue at 16 lanes/clk/SIMD on gfx950: 4 cycles per
-# wave64 instruction, measured with tools/valu_peak.hip (profiles/r01_valu_peak_microbench.txt: 38-40 T lane-op/s).
-# Only f32 FMA is dual-rate, so SURVEY F11's 78.6 T figure does not apply to this kernel.
-VALU_PEAK_LANEOPS = 39.81e12                        # measured: xor->bcnt mix at 8 waves/SIMD (256 CU x 4 SIMD x 16 lanes x ~2.43 GHz)
+MFMA_FP4_PEAK_TFLOPS = 10000.0                      # MI355X_MICROARCH.md: FP6/FP4 MFMA ~10 PF dense
+MFMA_BF16_PEAK_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: BF16 MFMA ~2.5 PF dense
+FLOP_PER_PAIR = 512.0                               # a 256-bit Hamming distance on the matrix cores = 256 multiply-adds
+# 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) issue at 16 lanes/clk/SIMD on gfx950 (tools/valu_peak.hip,
+# profiles/r01_valu_peak_microbench.txt: 38-40 T lane-op/s): the roof of the vector-ALU engine (--engine valu)
+VALU_PEAK_LANEOPS = 39.81e12
 LANEOPS_DENSE = 16                                  # 8 v_xor_b32 + 8 accumulating v_bcnt_u32_b32 per full 256-bit pair
 
 
@@ -45,6 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=3, help="the timed region of --steps steps is run this many times; value = median")
     ap.add_argument("--objects", type=int, default=200, help="objects of 5000 descriptors (200 -> 1M rows)")
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--k", type=int, default=2)
@@ -52,6 +64,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
     ap.add_argument("--stages", default="orb,match,verify", help="comma list of: orb,match,verify")
     ap.add_argument("--batch", type=int, default=16, help="frames per rank per step")
+    ap.add_argument("--engine", choices=("auto", "valu", "mfma"), default="auto",
+                    help="the exact Hamming search's engine: vector ALU (K4) or matrix cores (K4x); identical results")
     ap.add_argument("--exchange", choices=("all_to_all", "all_gather"), default="all_to_all",
                     help="several ranks: how the per-shard candidates travel. A rank only merges its own frames, so an "
                          "all-to-all moves 1/world of an all-gather's bytes over the point-to-point xGMI links")
@@ -61,15 +75,23 @@ def parse():
     ap.add_argument("--serial-exchange", action="store_true",
                     help="several ranks: issue the collectives on the matcher's stream, in program order (gather -> match -> "
                          "exchange -> merge), instead of on their own stream where they overlap the neighbouring DB passes")
-    ap.add_argument("--matcher-contexts", type=int, default=1,
-                    help="single device only: 2 alternates steps between two matcher contexts so that consecutive DB passes "
-                         "overlap (+4 %% frames/s); off by default because a launch's own duration then no longer says what "
-                         "it costs, and a kernel-trace profile (which serializes launches) no longer agrees with it")
     ap.add_argument("--iterations", type=int, default=2500, help="n_ransac_iterations (conf/detection.ork:38)")
     ap.add_argument("--min-inliers", type=int, default=8, help="min_inliers (conf/detection.ork:39)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras", default="chained,configs,adapter", help="N=1 only, after the timed region: comma list of "
+                    "chained,configs,adapter ('' = none)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver does, as a child, and leave with
+    its exit code. Nothing has touched the GPU yet (torch is not imported), so this is a plain child process."""
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: --gpus %d without WORLD_SIZE: launching %s\n" % (args.gpus, " ".join(cmd)))
+    raise SystemExit(subprocess.call(cmd))
 
 
 def cpu_baseline(desc, pts, off, frames, k, radius, budget_s, stages, iterations=2500, min_inliers=8):
@@ -114,18 +136,355 @@ def cpu_baseline(desc, pts, off, frames, k, radius, budget_s, stages, iterations
     return out
 
 
+def spread(values):
+    v = sorted(values)
+    return dict(values=values, median=statistics.median(v), min=v[0], max=v[-1])
+
+
+class SyntheticPipeline:
+    """The three stages on the SURVEY 8(d) synthetic workload with device-resident inputs (the headline's structure, also
+    used for the C1 / C2 / C5 blocks): ORB on the 8(d) image, matcher + verifier on the frame's planted descriptors."""
+
+    def __init__(self, torch, capi, device, desc, pts, off, frames, nq, k, radius, B, stages, iterations, min_inliers,
+                 engine="auto", H=480, W=640, shard=None, n_levels=3, match_fn=None, main_stream=None, verify_workers=2):
+        from tod_amd.pipeline import StagePipeline
+        self.torch, self.capi = torch, capi
+        self.nq, self.k, self.radius, self.B, self.H, self.W = nq, k, radius, B, H, W
+        self.iterations, self.min_inliers = iterations, min_inliers
+        do_orb, do_verify = "orb" in stages, "verify" in stages
+        self.stream = main_stream or torch.cuda.Stream()
+        self.ctx = capi.Context(device, self.stream.cuda_stream)
+        self.ctx.set_matcher_engine(engine)
+        self.shard = shard                                               # (rank, count): this device holds one shard of the rows
+        self.spans = self.ctx.db_load(desc, pts, off, *(shard or (0, 1)))
+        self.info = self.ctx.db_info()
+        from math import gcd
+        n = len(frames)
+        self.period = n // gcd(B, n)
+
+        def batch_of(v, key, dtype=None):
+            arrs = [frames[(v * B + b) % n][key] for b in range(B)]
+            return torch.from_numpy(np.ascontiguousarray(np.stack(arrs), dtype=dtype)).cuda()
+
+        self.Q_B = [batch_of(v, "q_desc") for v in range(self.period)]                          # [B, Q, 32]
+        self.KP_B = [batch_of(v, "kp_xy", np.float32) for v in range(self.period)]              # [B, Q, 2]
+        self.CLOUD_B = [batch_of(v, "cloud", np.float32) for v in range(self.period)] if do_verify else []
+        self.IMG_B = [batch_of(v, "image") for v in range(self.period)] if do_orb else []       # [B, H, W]
+        self.D = 3
+        self.outs = [dict(counts=torch.zeros(B * nq, dtype=torch.int32, device="cuda"),
+                          matches=torch.zeros((B * nq * k, 4), dtype=torch.int32, device="cuda"),
+                          xyz=torch.zeros((B * nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(self.D)]
+        self.ostream = torch.cuda.Stream(priority=-1)
+        self.octx = capi.Context(device, self.ostream.cuda_stream) if do_orb else None
+        # two verifier workers (context + stream each) take alternate steps: the verifier is latency bound (host round trips,
+        # single-wave clique searches), so two batches in flight fill each other's gaps
+        self.vstreams = [torch.cuda.Stream(priority=-1) for _ in range(verify_workers)] if do_verify else []
+        self.vctxs = [capi.Context(device, s.cuda_stream) for s in self.vstreams]
+        self.orb_out = (torch.empty((B, nq, 2), device="cuda"), torch.empty((B, nq, 4), device="cuda"),
+                        torch.empty((B, nq, 32), dtype=torch.uint8, device="cuda")) if do_orb else None
+        self.n_levels = n_levels
+        self.match_fn = match_fn or self._match_local
+        self.pipe = StagePipeline(torch, orb=self._orb if do_orb else None, match=lambda i, n_steps: self.match_fn(self, i, n_steps),
+                                  verify=self._verify if do_verify else None,
+                                  wait_for=lambda i, ev: self.vstreams[i % len(self.vstreams)].wait_event(ev), depth=self.D,
+                                  verify_workers=max(verify_workers, 1))
+
+    def _orb(self, i):
+        o = self.orb_out
+        n = self.octx.orb_batch_device(self.IMG_B[i % self.period].data_ptr(), self.B, self.H * self.W, self.H, self.W, self.W,
+                                       self.nq, self.n_levels, 1.2, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), self.nq)
+        return sum(n)
+
+    @staticmethod
+    def _match_local(self, i, n_steps):
+        o = self.outs[i % self.D]
+        q = self.Q_B[i % self.period]
+        self.ctx.match_device(q.data_ptr(), self.B * self.nq, self.k, self.radius, o["counts"].data_ptr(),
+                              o["matches"].data_ptr(), o["xyz"].data_ptr())
+        return self.stream
+
+    def _verify(self, i):
+        o = self.outs[i % self.D]
+        rngs = (self.capi.Rng * self.B)(*[self.capi.rng_new(1) for _ in range(self.B)])   # rand() restarts per frame (decision D4)
+        poses = self.vctxs[i % len(self.vctxs)].verify_batch_device(self.B, self.KP_B[i % self.period].data_ptr(), self.nq,
+                                              self.CLOUD_B[i % self.period].data_ptr(), self.H, self.W, o["counts"].data_ptr(),
+                                              o["matches"].data_ptr(), o["xyz"].data_ptr(), self.k, self.spans, self.min_inliers,
+                                              self.iterations, 0.01, rngs)
+        return sum(len(p) for p in poses)
+
+    def close(self):
+        self.pipe.close()
+        for c in [self.octx, self.ctx] + self.vctxs:
+            if c is not None:
+                c.close()
+
+
+def timed_regions(torch, run, fence, steps, repeats, reduce_max=None):
+    """`repeats` timed regions of exactly `steps` steps, each bracketed by fence() on both sides; seconds per region."""
+    out = []
+    for _ in range(repeats):
+        fence()
+        t0 = time.perf_counter()
+        run(steps)
+        fence()
+        dt = time.perf_counter() - t0
+        out.append(reduce_max(dt) if reduce_max else dt)
+    return out
+
+
+def launch_ms(c0, c1):
+    n = c1.n_match_kernel_launches - c0.n_match_kernel_launches
+    return (c1.sum_match_kernel_ms - c0.sum_match_kernel_ms) / max(n, 1), n
+
+
+# ------------------------------------------------------------------------------------------------------------ extras (N = 1)
+def run_chained(torch, capi, device, args):
+    """Real dataflow: DB trained by todhip_model_* on rendered views of 200 textured planes (this library's own ORB
+    descriptors: real rBRIEF statistics), then per step ORB -> matcher -> verifier on 16 rendered detection views, each stage
+    consuming the previous one's device buffers (keypoints + descriptors -> matches -> poses from the depth image)."""
+    from tod_amd import scenes
+    from tod_amd.pipeline import StagePipeline
+    t_setup = time.perf_counter()
+    B, nq, k, radius = args.batch, args.nq, args.k, args.radius
+    n_obj = args.objects
+    textures = scenes.make_textures(n_obj)
+    tctx = capi.Context(device)
+    desc, pts, off = scenes.train_db(tctx, textures, rows_per_object=5000)
+    tctx.close()
+    batches = scenes.make_detection_batches(textures, 4, B)
+    H, W = scenes.H, scenes.W
+    mstream, ostream = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+    vstreams = [torch.cuda.Stream(priority=-1) for _ in range(2)]
+    mctx, octx = capi.Context(device, mstream.cuda_stream), capi.Context(device, ostream.cuda_stream)
+    vctxs = [capi.Context(device, s.cuda_stream) for s in vstreams]
+    mctx.set_matcher_engine(args.engine)
+    spans = mctx.db_load(desc, pts, off)
+    D, P = 3, len(batches)
+    R = 2 * D                                                             # ORB output ring: ORB runs D ahead of the matcher, the verifier D behind
+    orb_ring = [dict(kp=torch.zeros((B, nq, 2), device="cuda"), aux=torch.zeros((B, nq, 4), device="cuda"),
+                     desc=torch.zeros((B, nq, 32), dtype=torch.uint8, device="cuda"), n=[nq] * B) for _ in range(R)]
+    outs = [dict(counts=torch.zeros(B * nq, dtype=torch.int32, device="cuda"),
+                 matches=torch.zeros((B * nq * k, 4), dtype=torch.int32, device="cuda"),
+                 xyz=torch.zeros((B * nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(D)]
+    stats = dict(frames=0, right_object=0, pose_ok=0, poses=0, kp_short=0)
+
+    def orb(i):
+        s = orb_ring[i % R]
+        s["n"] = octx.orb_batch_device(batches[i % P]["images"].data_ptr(), B, H * W, H, W, W, nq, 3, 1.2, s["kp"].data_ptr(),
+                                       s["aux"].data_ptr(), s["desc"].data_ptr(), nq)
+        return sum(s["n"])
+
+    def match(i, n_steps):
+        s, o = orb_ring[i % R], outs[i % D]
+        mctx.match_device(s["desc"].data_ptr(), B * nq, k, radius, o["counts"].data_ptr(), o["matches"].data_ptr(), o["xyz"].data_ptr())
+        if min(s["n"]) < nq:                                             # a frame with fewer keypoints pads with counts 0 (todhip.h)
+            with torch.cuda.stream(mstream):
+                c2 = o["counts"].view(B, nq)
+                for b, nb in enumerate(s["n"]):
+                    if nb < nq:
+                        c2[b, nb:] = 0
+            stats["kp_short"] += 1
+        return mstream
+
+    def verify(i):
+        s, o, bt = orb_ring[i % R], outs[i % D], batches[i % P]
+        rngs = (capi.Rng * B)(*[capi.rng_new(1) for _ in range(B)])
+        poses = vctxs[i % 2].verify_batch_device(B, s["kp"].data_ptr(), nq, 0, H, W, o["counts"].data_ptr(), o["matches"].data_ptr(),
+                                         o["xyz"].data_ptr(), k, spans, args.min_inliers, args.iterations, 0.01, rngs,
+                                         depth=(bt["depth"].data_ptr(), False, scenes.K))
+        for f, pl in enumerate(poses):
+            stats["frames"] += 1
+            stats["poses"] += len(pl)
+            hit = [p for p in pl if p["object"] == bt["objects"][f]]
+            if hit:
+                stats["right_object"] += 1
+                Rt, tt = bt["poses"][f]
+                if np.abs(hit[0]["R"] - Rt).max() < 0.03 and np.abs(hit[0]["t"] - tt).max() < 0.006:
+                    stats["pose_ok"] += 1
+        return sum(len(p) for p in poses)
+
+    pipe = StagePipeline(torch, orb=orb, match=match, verify=verify, wait_for=lambda i, ev: vstreams[i % 2].wait_event(ev), depth=D,
+                         verify_workers=2)
+    setup_s = time.perf_counter() - t_setup
+    pipe.run(3)
+    torch.cuda.synchronize()
+    for key in stats:
+        stats[key] = 0
+    pipe.reset_stats()
+    mctx.set_kernel_timing(True)
+    c0 = mctx.counters()
+    steps = max(args.steps // 2, 5)
+    secs = timed_regions(torch, pipe.run, torch.cuda.synchronize, steps, args.repeats)
+    c1 = mctx.counters()
+    k_ms, n_l = launch_ms(c0, c1)
+    fps = [steps * B / s for s in secs]
+    n_f = max(stats["frames"], 1)
+    out = {"what": "data-chained pipeline: DB trained by todhip_model_* on %d rendered views per object (ORB descriptors of this "
+                   "library), per step todhip_orb_batch_device -> todhip_match_device -> todhip_verify_batch_device_depth on %d rendered "
+                   "detection views, every stage reading the previous stage's device buffers" % (len(scenes.TRAIN_VIEWS), B),
+           "db_rows": int(off[-1]), "db_objects": n_obj, "k": k, "radius": radius, "frames_per_step": B, "steps": steps,
+           "frames_per_s": spread(fps), "ms_per_step": statistics.median(secs) / steps * 1e3,
+           "matcher_launch_ms": k_ms, "matcher_launches": n_l,
+           "stage_ms_per_step": {key: 1e3 * v / (steps * args.repeats) for key, v in pipe.stage_s.items()},
+           "keypoints_per_frame": pipe.n_kp / max(pipe.n_steps * B, 1),
+           "poses_per_frame": stats["poses"] / n_f, "frames_with_the_right_object": stats["right_object"] / n_f,
+           "frames_with_the_rendering_pose": stats["pose_ok"] / n_f,
+           "pose_tolerance": "max |dR| < 0.03, max |dt| < 6 mm against the pose the view was rendered from",
+           "setup_s": setup_s}
+    pipe.close()
+    for c in [mctx, octx] + vctxs:
+        c.close()
+    return out
+
+
+def run_adapter_path(torch, capi, device, desc, pts, off, frames, args):
+    """What adapter/ecto_cells.hpp can reach: one frame at a time through the host-buffer calls, every call synchronous
+    (todhip_orb = FeatureDescriptor, todhip_match = DescriptorMatcher::process, todhip_verify = GuessGenerator::process)."""
+    ctx = capi.Context(device)
+    ctx.set_matcher_engine(args.engine)
+    spans = ctx.db_load(desc, pts, off)
+    t_stage = {"orb": [], "match": [], "verify": []}
+    n_poses = 0
+    reps = 4
+    for r in range(reps + 1):
+        for fr in frames:
+            t0 = time.perf_counter()
+            ctx.orb(fr["image"], args.nq, 3, 1.2)
+            t1 = time.perf_counter()
+            row_ptr, m, xyz = ctx.match(fr["q_desc"], args.k, args.radius)
+            t2 = time.perf_counter()
+            poses = ctx.verify(fr["kp_xy"], fr["cloud"], row_ptr, m, xyz, spans, args.min_inliers, args.iterations, 0.01, capi.rng_new(1))
+            t3 = time.perf_counter()
+            if r > 0:                                                     # first pass = warm-up
+                t_stage["orb"].append(t1 - t0); t_stage["match"].append(t2 - t1); t_stage["verify"].append(t3 - t2)
+                n_poses += len(poses)
+    ctx.close()
+    med = {key: statistics.median(v) for key, v in t_stage.items()}
+    per_frame = [a + b + c for a, b, c in zip(t_stage["orb"], t_stage["match"], t_stage["verify"])]
+    return {"what": "one frame at a time through todhip_orb + todhip_match + todhip_verify with host buffers (PCIe inclusive, one "
+                    "synchronous call per cell) -- the only forms adapter/ecto_cells.hpp calls; C3 workload",
+            "frames": len(per_frame), "frames_per_s": 1.0 / statistics.median(per_frame),
+            "frames_per_s_match_verify_only": 1.0 / (med["match"] + med["verify"]),
+            "ms_per_call": {key: 1e3 * v for key, v in med.items()},
+            "ms_per_frame_spread": spread([1e3 * v for v in sorted(per_frame)[::max(len(per_frame) // 8, 1)]]),
+            "poses_per_frame": n_poses / max(len(per_frame), 1)}
+
+
+def run_configs(torch, capi, synth, device, args):
+    """BASELINE.json configs other than the headline's (C3), each on one GPU: frames/s + the dominant kernel's time."""
+    out = {}
+
+    def pipeline_block(name, desc, pts, off, frames, nq, k, radius, B, stages, steps, H=480, W=640, shard=None, match_fn=None, note=""):
+        sp = SyntheticPipeline(torch, capi, device, desc, pts, off, frames, nq, k, radius, B, stages, args.iterations, args.min_inliers,
+                               engine=args.engine, H=H, W=W, shard=shard, match_fn=match_fn)
+        sp.pipe.run(2)
+        torch.cuda.synchronize()
+        sp.pipe.reset_stats()
+        sp.ctx.set_kernel_timing(True)
+        c0 = sp.ctx.counters()
+        secs = timed_regions(torch, sp.pipe.run, torch.cuda.synchronize, steps, args.repeats)
+        k_ms, n_l = launch_ms(c0, sp.ctx.counters())
+        blk = {"workload": name, "frames_per_step": B, "steps": steps, "frames_per_s": spread([steps * B / s for s in secs]),
+               "ms_per_step": statistics.median(secs) / steps * 1e3, "matcher_launch_ms": k_ms,
+               "stage_ms_per_step": {key: 1e3 * v / (steps * args.repeats) for key, v in sp.pipe.stage_s.items()},
+               "poses_per_frame": sp.pipe.n_poses / max(sp.pipe.n_steps * B, 1)}
+        if note:
+            blk["note"] = note
+        sp.close()
+        return blk
+
+    # ---- C1: the reference's own case -- one frame, ORB-500, a 1-object DB, k = 5 (DescriptorMatcher.cpp:211), radius 35
+    d1, p1, o1 = synth.make_db(1)
+    f1 = [synth.make_frame(d1, p1, o1, 500, frame=f, visible_object=0) for f in range(4)]
+    for f, fr in enumerate(f1):
+        fr["image"] = synth.make_image(f)
+    out["C1"] = pipeline_block("C1: single 640x480 frame, ORB-500 vs a 1-object DB (5000 descriptors), k=5, radius 35, full verifier; "
+                               "a step = ONE frame (the reference's frame-at-a-time regime)", d1, p1, o1, f1, 500, 5, 35, 1,
+                               ["orb", "match", "verify"], 40)
+    out["C1"]["batched"] = pipeline_block("the same frames, 16 per step", d1, p1, o1, f1, 500, 5, 35, 16, ["orb", "match", "verify"], 10)
+    # ---- C2: ORB-1000 vs 100k descriptors, k = 2
+    d2, p2, o2 = synth.make_db(20)
+    f2 = [synth.make_frame(d2, p2, o2, 1000, frame=f, visible_object=(17 * f + 3) % 20) for f in range(8)]
+    for f, fr in enumerate(f2):
+        fr["image"] = synth.make_image(f)
+    out["C2"] = pipeline_block("C2: ORB-1000 per frame vs 100k-descriptor DB (20 objects x 5000), Hamming BF k=2, radius 35, 16 frames per step",
+                               d2, p2, o2, f2, 1000, 2, 35, 16, ["orb", "match", "verify"], 15)
+    del d2, p2, f2
+    # ---- C5, one GPU's share of the 8-GPU job: 4 of the 32 1080p frames (ORB-2000 + verifier), all 32 frames' descriptors
+    # against this rank's 250k-row shard of the 2M-row DB, merge of its own 4 frames (no peers here: the other ranks' candidate
+    # lists are absent, the visible objects are chosen inside this shard)
+    d5, p5, o5 = synth.make_db(400)
+    B5, nq5, world5 = 4, 2000, 8
+    f5 = [synth.make_frame(d5, p5, o5, nq5, frame=f, visible_object=(7 * f + 3) % 50, H=1080, W=1920, f=1400.0) for f in range(B5)]
+    for f, fr in enumerate(f5):
+        fr["image"] = synth.make_image(f, H=1080, W=1920, n_rect=8000)
+    keys5 = {}
+
+    def match_c5(sp, i, n_steps):
+        if "q_all" not in keys5:
+            keys5["q_all"] = sp.Q_B[0].repeat(world5, 1, 1).contiguous()                # what the all-gather delivers: 32 frames
+            keys5["keys"] = torch.empty((world5 * B5 * nq5, 2), dtype=torch.int64, device="cuda")
+        o = sp.outs[i % sp.D]
+        sp.ctx.match_shard_device(keys5["q_all"].data_ptr(), world5 * B5 * nq5, 2, 35, keys5["keys"].data_ptr())
+        sp.ctx.merge_shards_device(keys5["keys"].data_ptr(), 1, B5 * nq5, 2, 35, o["counts"].data_ptr(), o["matches"].data_ptr(),
+                                   o["xyz"].data_ptr())
+        return sp.stream
+
+    out["C5_single_gpu_share"] = pipeline_block(
+        "C5, one rank's share of the 8-GPU job: per step ORB-2000 on 4 of the 32 1080p frames, the 32 x 2000 descriptors against this "
+        "rank's 250k-row shard of the 2M-row DB (k=2, radius 35), merge + full verifier for its own 4 frames", d5, p5, o5, f5, nq5, 2, 35,
+        B5, ["orb", "match", "verify"], 10, H=1080, W=1920, shard=(0, world5), match_fn=match_c5,
+        note="no collectives on one GPU: the candidate exchange (32 x 2000 x 2 keys x 8 B per rank) is missing from this figure")
+    del d5, p5, f5, keys5
+    # ---- C4: float descriptors, L2 brute force as a bf16 MFMA GEMM + exact refinement (matcher only: not a reference feature)
+    d4, p4, o4 = synth.make_sift_db(100)
+    q4, _ = synth.make_sift_queries(d4, 1000, frame=0)
+    c4 = capi.Context(device)
+    c4.db_load(d4, p4, o4)
+    dq = torch.from_numpy(q4).cuda()
+    cnt = torch.zeros(1000, dtype=torch.int32, device="cuda"); mm = torch.zeros((2000, 4), dtype=torch.int32, device="cuda")
+    xx = torch.zeros((2000, 3), dtype=torch.float32, device="cuda")
+    call = lambda: c4.match_l2_device(dq.data_ptr(), 1000, 2, 400.0, cnt.data_ptr(), mm.data_ptr(), xx.data_ptr())
+    for _ in range(3):
+        call()
+    c4.synchronize()
+    secs = []
+    for _ in range(args.repeats):
+        t0 = time.perf_counter()
+        for _ in range(20):
+            call()
+        c4.synchronize()
+        secs.append((time.perf_counter() - t0) / 20)
+    flops = 2.0 * 1000 * d4.shape[0] * 128
+    med = statistics.median(secs)
+    out["C4"] = {"workload": "C4: 1000 SIFT-128 float descriptors vs 500k-row DB, L2 brute force k=2 as a bf16 MFMA GEMM with exact f32 "
+                             "refinement (todhip_match_l2_device; matcher only)",
+                 "frames_per_s": spread([1.0 / s for s in secs]), "ms_per_call": med * 1e3,
+                 "roofline": {"bound": "mfma", "achieved": flops / med / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": flops / med / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                              "note": "2 Q N 128 flop of the distance table / the whole call (seed pass + GEMM pass + exact re-ranking)"},
+                 "queries_with_a_match": int((cnt > 0).sum().item())}
+    c4.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------- main
 def main():
     args = parse()
     stages = [s for s in args.stages.split(",") if s]
+    extras = [s for s in args.extras.split(",") if s]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("TOD_BENCH_FORCE_DIST") != "1":
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, world, args.gpus, args.gpus))
 
     import torch
     import torch.distributed as dist
-    from tod_amd import capi, synth
+    from tod_amd import capi, sharded, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -151,219 +510,58 @@ def main():
               for f in range(args.frames)]
     for f, fr in enumerate(frames):
         fr["image"] = synth.make_image(f)
+    # frame f belongs to rank (f % world); every rank keeps its own frames resident in HBM
+    my_frames = [frames[f] for f in range(len(frames)) if f % world == rank] or [frames[rank % len(frames)]]
 
-    # one explicit stream for everything: libtodhip kernels, torch copies and the RCCL collectives (which order
-    # themselves against torch's current stream). The default stream's handle is 0 == "create your own" for
-    # todhip_create, which would put the kernels on a different stream than the collectives.
+    # one explicit stream for the matcher: libtodhip kernels, torch copies and (serial form) the RCCL collectives, which order
+    # themselves against torch's current stream. The default stream's handle is 0 == "create your own" for todhip_create.
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    ctx = capi.Context(local_rank, stream.cuda_stream)
-    sharded = world > 1 and not args.replicas
-    db_spans = ctx.db_load(desc, pts, off, shard_rank=rank if sharded else 0, shard_count=world if sharded else 1)
-    info = ctx.db_info()
-    # single device: steps alternate between two matcher contexts (own stream, own workspaces, own copy of the 32 MB
-    # DB), so the merge/finalize tail and the launch ramp of one step overlap with the DB pass of the next; with
-    # several ranks the collectives keep everything on the one stream
-    mctx, mstreams = [ctx], [stream]
-    if world == 1 and args.matcher_contexts > 1:
-        s2 = torch.cuda.Stream()
-        c2 = capi.Context(local_rank, s2.cuda_stream)
-        c2.db_load(desc, pts, off)
-        mctx.append(c2); mstreams.append(s2)
+    nq, k, B = args.nq, args.k, args.batch
+    sharded_db = use_dist and not args.replicas
+    overlap = sharded_db and not args.serial_exchange
+    sm_box = {}
 
-    nq, k = args.nq, args.k
-    do_verify = "verify" in stages
-    do_orb = "orb" in stages
-    B = args.batch                                   # frames per rank per step
-    from concurrent.futures import ThreadPoolExecutor
-    from math import gcd
-    # frame f belongs to rank (f % world); every rank keeps its own frames resident in HBM
-    my_ids = [f for f in range(len(frames)) if f % world == rank] or [rank % len(frames)]
-    n_my = len(my_ids)
-    H, W = frames[0]["cloud"].shape[:2]
-    # A step is a batch of B frames: frame (i * B + b) % n_my of this rank's frames, b = 0..B-1. The batches repeat
-    # with a short period, so each distinct batch is laid out once as contiguous [B, ...] arrays (what a camera
-    # driver handing over B frames would provide).
-    period = n_my // gcd(B, n_my)
-
-    def batch_of(v, key, dtype=None):
-        arrs = [frames[my_ids[(v * B + b) % n_my]][key] for b in range(B)]
-        return torch.from_numpy(np.ascontiguousarray(np.stack(arrs), dtype=dtype)).cuda()
-
-    Q_B = [batch_of(v, "q_desc") for v in range(period)]                            # [B, Q, 32]
-    KP_B = [batch_of(v, "kp_xy", np.float32) for v in range(period)]                # [B, Q, 2]
-    CLOUD_B = [batch_of(v, "cloud", np.float32) for v in range(period)] if do_verify else []   # [B, H, W, 3]
-    # stage A runs on the SURVEY 8(d) synthetic grey image of the frame. Its descriptors are not the matcher's input
-    # (random-image ORB descriptors cannot match a synthetic DB; the frame's planted descriptors do that), but its
-    # work is part of every frame and the matcher of a step starts only when that step's ORB batch is done.
-    IMG_B = [batch_of(v, "image") for v in range(period)] if do_orb else []         # [B, H, W]
-    # matcher outputs, ring of D step buffers: the verifier of step s reads set (s % D) while later steps fill the others
-    D = 3
-    outs = [dict(counts=torch.empty(B * nq, dtype=torch.int32, device="cuda"),
-                 matches=torch.empty((B * nq * k, 4), dtype=torch.int32, device="cuda"),
-                 xyz=torch.empty((B * nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(D)]
-    d_keys = torch.empty((world * B * nq, k), dtype=torch.int64, device="cuda")
-    # Three stages, three streams, three host threads: ORB batch (step s+1..s+2) | matcher (step s, this thread: it owns
-    # torch's current stream and the collectives) | verifier batch (step s-1). Every stage call covers the B frames of
-    # a step in the launches of one frame (todhip_orb_batch_device, todhip_verify_batch_device).
-    ostream, vstream = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1)
-    octx = capi.Context(local_rank, ostream.cuda_stream) if do_orb else None
-    vctx = capi.Context(local_rank, vstream.cuda_stream) if do_verify else None
-    orb_out = (torch.empty((B, nq, 2), device="cuda"), torch.empty((B, nq, 4), device="cuda"),
-               torch.empty((B, nq, 32), dtype=torch.uint8, device="cuda")) if do_orb else None
-    opool = ThreadPoolExecutor(1) if do_orb else None
-    vpool = ThreadPoolExecutor(1) if do_verify else None
-    stage_s = {"orb": 0.0, "match_issue": 0.0, "verify": 0.0}
-    n_kp_total = [0]
-    n_pose_total = [0]
-    n_steps_done = [0]
-
-    def alloc(shape, dtype_name):
-        return torch.empty(shape, dtype=getattr(torch, dtype_name), device="cuda")
-
-    def all_gather(out, inp):
-        if backend == "nccl":
-            dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1))
-        else:                                           # gloo rehearsal: stage through the host
-            parts = [torch.empty(inp.numel(), dtype=inp.dtype) for _ in range(world)]
-            dist.all_gather(parts, inp.contiguous().view(-1).cpu())
-            out.view(-1).copy_(torch.cat(parts).to(out.device))
-
-    def all_to_all(out, inp):
-        if backend == "nccl":
-            dist.all_to_all_single(out.view(-1), inp.contiguous().view(-1))
-        else:                                           # gloo rehearsal: stage through the host
-            o = torch.empty(out.numel(), dtype=out.dtype)
-            dist.all_to_all_single(o, inp.contiguous().view(-1).cpu())
-            out.view(-1).copy_(o.to(out.device))
-
-    def orb_task(i):
-        t = time.perf_counter()
-        n = octx.orb_batch_device(IMG_B[i % period].data_ptr(), B, H * W, H, W, W, nq, 3, 1.2, orb_out[0].data_ptr(),
-                                  orb_out[1].data_ptr(), orb_out[2].data_ptr(), nq)
-        stage_s["orb"] += time.perf_counter() - t
-        return sum(n)
-
-    def verify_task(i, ev):
-        vstream.wait_event(ev)                          # this step's matcher outputs (recorded on the matcher's stream)
-        ev.synchronize()                                # (host side too, so that the stage time below is the verifier's own)
-        t = time.perf_counter()
-        o = outs[i % D]
-        rngs = (capi.Rng * B)(*[capi.rng_new(1) for _ in range(B)])   # rand() restarts per frame (decision D4)
-        poses = vctx.verify_batch_device(B, KP_B[i % period].data_ptr(), nq, CLOUD_B[i % period].data_ptr(), H, W,
-                                         o["counts"].data_ptr(), o["matches"].data_ptr(), o["xyz"].data_ptr(), k, db_spans,
-                                         args.min_inliers, args.iterations, 0.01, rngs)
-        stage_s["verify"] += time.perf_counter() - t
-        return sum(len(p) for p in poses)
-
-    # Several ranks: the collectives and the merge run on their own stream (cstream), so that the DB pass of step i + 1
-    # follows that of step i without a gap. Order on cstream, identical on every rank: gather(0), gather(1), exchange(0),
-    # merge(0), gather(2), exchange(1), merge(1), ... -- one communicator, one stream, one order. Double-buffered
-    # q_all / keys / km; the events below are the only cross-stream edges:
-    #   gathered(i) -> match(i);  matched(i) -> exchange(i);  exchanged(i - 2) -> match(i) (keys buffer reuse);
-    #   gather(i + 2) overwrites q_all[i % 2] after exchange(i), which itself waited for match(i)  (stream order).
-    overlap = use_dist and not args.serial_exchange and not args.replicas
-    if overlap:
-        cstream = torch.cuda.Stream(priority=-1)
-        cctx = capi.Context(local_rank, cstream.cuda_stream)
-        cctx.db_load(desc, pts, off, shard_rank=rank, shard_count=world)
-        q_all2 = [torch.empty((world, B, nq, 32), dtype=torch.uint8, device="cuda") for _ in range(2)]
-        keys2 = [torch.empty((world * B * nq, k), dtype=torch.int64, device="cuda") for _ in range(2)]
-        km2 = [torch.empty((world, B * nq, k), dtype=torch.int64, device="cuda") for _ in range(2)]
-        keys_all2 = ([torch.empty((world, world, B * nq, k), dtype=torch.int64, device="cuda") for _ in range(2)]
-                     if args.exchange == "all_gather" else None)
-        ev_gathered, ev_exchanged = {}, {}
-
-    def issue_gather(i):
-        with torch.cuda.stream(cstream):
-            all_gather(q_all2[i % 2], Q_B[i % period])
-            ev_gathered[i] = torch.cuda.Event()
-            ev_gathered[i].record(cstream)
-
-    def match_step_overlapped(i, n_steps):
-        o = outs[i % D]
+    def match_sharded(sp, i, n_steps):
+        sm = sm_box["sm"]
         if i == 0:
-            ev_gathered.clear(); ev_exchanged.clear()
-            issue_gather(0)
-        if i + 1 < n_steps:
-            issue_gather(i + 1)
-        stream.wait_event(ev_gathered.pop(i))
-        if i - 2 in ev_exchanged:
-            stream.wait_event(ev_exchanged.pop(i - 2))
-        ctx.match_shard_device(q_all2[i % 2].data_ptr(), world * B * nq, k, args.radius, keys2[i % 2].data_ptr())
-        matched = torch.cuda.Event()
-        matched.record(stream)
-        with torch.cuda.stream(cstream):
-            cstream.wait_event(matched)
-            if args.exchange == "all_to_all":
-                all_to_all(km2[i % 2], keys2[i % 2])                               # keys is [frame owner][B*Q][k]
-                mine = km2[i % 2]
-            else:
-                all_gather(keys_all2[i % 2], keys2[i % 2])                         # [shard][rank][B*Q][k]
-                mine = km2[i % 2]
-                mine.copy_(keys_all2[i % 2][:, rank])
-            ev_exchanged[i] = torch.cuda.Event()
-            ev_exchanged[i].record(cstream)
-            cctx.merge_shards_device(mine.data_ptr(), world, B * nq, k, args.radius, o["counts"].data_ptr(),
-                                     o["matches"].data_ptr(), o["xyz"].data_ptr())
-        return cstream
+            sm.begin(n_steps, lambda j: (sp.Q_B[j % sp.period], None))
+        return sm.step(i, sp.outs[i % sp.D])
 
-    def match_step(i, n_steps):
-        """Returns the stream on which this step's matcher outputs become complete."""
-        if overlap:
-            return match_step_overlapped(i, n_steps)
-        o = outs[i % D]
-        q = Q_B[i % period]
-        if not use_dist or args.replicas:
-            # single device (or a replica of the whole DB): no key exchange; the B frames' descriptors share one pass over the DB
-            mctx[i % len(mctx)].match_device(q.data_ptr(), B * nq, k, args.radius, o["counts"].data_ptr(),
-                                             o["matches"].data_ptr(), o["xyz"].data_ptr())
-            return mstreams[i % len(mstreams)]
-        # tod_amd/sharded.py with B frames per rank, in program order on the matcher's stream: gather descriptors, match
-        # all world*B frames against this rank's shard, exchange the candidates, merge this rank's B frames
-        q_all = alloc((world, B, nq, 32), "uint8")
-        all_gather(q_all, q)
-        ctx.match_shard_device(q_all.data_ptr(), world * B * nq, k, args.radius, d_keys.data_ptr())
-        if args.exchange == "all_to_all":
-            km = alloc((world, B * nq, k), "int64")                             # chunk j <- shard j's keys of MY frames
-            all_to_all(km, d_keys)                                              # d_keys is [frame owner][B*Q][k]
-        else:
-            keys_all = alloc((world, world, B, nq, k), "int64")                 # [shard][rank][b][Q][k]
-            all_gather(keys_all, d_keys)
-            km = keys_all[:, rank].contiguous()                                 # [shard][B*Q][k]
-        ctx.merge_shards_device(km.data_ptr(), world, B * nq, k, args.radius, o["counts"].data_ptr(),
-                                o["matches"].data_ptr(), o["xyz"].data_ptr())
-        return stream
-
-    def run_steps(n_steps):
-        """ORB(i) -> match(i) -> verify(i); ORB runs up to D steps ahead, the matcher up to D - 1 steps ahead of the verifier."""
-        ofut, vfut = {}, {}
-        for j in range(min(D, n_steps)):
-            if do_orb:
-                ofut[j] = opool.submit(orb_task, j)
-        def orb_done(j):                                              # wait for ORB batch j, keep ORB D batches ahead
-            if do_orb and j in ofut:
-                n_kp_total[0] += ofut.pop(j).result()
-                if j + D < n_steps:
-                    ofut[j + D] = opool.submit(orb_task, j + D)
-
-        for i in range(n_steps):
-            if do_verify and i - D in vfut:
-                n_pose_total[0] += vfut.pop(i - D).result()          # buffer set i % D is free again
-            orb_done(i)
-            if overlap:
-                orb_done(i + 1)                                       # the gather of step i + 1 is issued in step i
-            t = time.perf_counter()
-            out_stream = match_step(i, n_steps)
-            stage_s["match_issue"] += time.perf_counter() - t
-            if do_verify:
-                ev = torch.cuda.Event()
-                ev.record(out_stream)                    # the matcher outputs of this step are complete after this
-                vfut[i] = vpool.submit(verify_task, i, ev)
-        for i in sorted(vfut):
-            n_pose_total[0] += vfut[i].result()
-        n_steps_done[0] += n_steps
+    sp = SyntheticPipeline(torch, capi, local_rank, desc, pts, off, my_frames, nq, k, args.radius, B, stages, args.iterations,
+                           args.min_inliers, engine=args.engine, shard=(rank, world) if sharded_db else None,
+                           match_fn=match_sharded if sharded_db else None, main_stream=stream)
+    sp.pipe.next_orb = overlap
+    info = sp.info
+    check = None
+    if sharded_db:
+        cstream = torch.cuda.Stream(priority=-1) if overlap else stream
+        ops = sharded.GpuOps(sp.ctx, stream, cstream, backend, k, args.radius)
+        sm_box["sm"] = sharded.ShardedMatcher(ops, world, rank, B, nq, k, exchange=args.exchange, overlap=overlap)
+        # self-check before anything is timed: step 0's merged matches of THIS rank's frames == the result of a replica that
+        # holds the whole DB (every rank checks its own frames; the verdict is reduced over the ranks)
+        sm = sm_box["sm"]
+        sm.begin(1, lambda j: (sp.Q_B[0], None))
+        done_on = sm.step(0, sp.outs[0])
+        done_on.synchronize()
+        rctx = capi.Context(local_rank, stream.cuda_stream)
+        rctx.set_matcher_engine(args.engine)
+        rctx.db_load(desc, pts, off)
+        ref = dict(counts=torch.zeros_like(sp.outs[0]["counts"]), matches=torch.zeros_like(sp.outs[0]["matches"]),
+                   xyz=torch.zeros_like(sp.outs[0]["xyz"]))
+        rctx.match_device(sp.Q_B[0].data_ptr(), B * nq, k, args.radius, ref["counts"].data_ptr(), ref["matches"].data_ptr(),
+                          ref["xyz"].data_ptr())
+        stream.synchronize()
+        keep = (torch.arange(k, device="cuda").view(1, k) < ref["counts"].view(-1, 1)).view(-1)
+        same = (torch.equal(ref["counts"], sp.outs[0]["counts"]) and torch.equal(ref["matches"][keep], sp.outs[0]["matches"][keep]) and
+                torch.equal(ref["xyz"][keep], sp.outs[0]["xyz"][keep]))
+        rctx.close()
+        flag = torch.tensor([1 if same else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        check = bool(flag.item())
+        if not check:
+            raise SystemExit("sharded step 0 differs from the unsharded result on some rank")
 
     def fence():
         torch.cuda.synchronize()
@@ -371,131 +569,140 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(args.warmup)
-    fence()
-    for key in stage_s:
-        stage_s[key] = 0.0
-    for c in mctx:
-        c.set_kernel_timing(True)
-    c0 = [c.counters() for c in mctx]
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    dt_local = dt
-    c1 = [c.counters() for c in mctx]
-    # outside the timed region, single device only: the same launch with the radius cut switched off (radius 256) --
-    # what the DB pass costs when no lower bound can prune (correlated descriptors); reported beside the roofline
-    dense_ms = None
-    if world == 1:
-        o = outs[0]
-        d0 = ctx.counters()
-        for _ in range(3):
-            ctx.match_device(Q_B[0].data_ptr(), B * nq, k, 256, o["counts"].data_ptr(), o["matches"].data_ptr(), o["xyz"].data_ptr())
-        torch.cuda.synchronize()
-        d1 = ctx.counters()
-        dense_ms = (d1.sum_match_kernel_ms - d0.sum_match_kernel_ms) / max(d1.n_match_kernel_launches - d0.n_match_kernel_launches, 1)
-    for c in mctx:
-        c.set_kernel_timing(False)
-
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if use_dist:
+    def reduce_max(dt):
+        if not use_dist:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        return float(t.item())
 
-    n_launch = sum(b.n_match_kernel_launches - a.n_match_kernel_launches for a, b in zip(c0, c1))
-    k4_ms = sum(b.sum_match_kernel_ms - a.sum_match_kernel_ms for a, b in zip(c0, c1)) / max(n_launch, 1)
-    frames_per_launch = B                                          # one launch matches the world*B frames of a step
-    if args.replicas:
-        world_q = 1                                                # ... or, with replicas, this rank's own B frames
-    else:
-        world_q = world
-    alg_bytes = info["shard_rows"] * 32 + world_q * frames_per_launch * nq * (32 + k * 8)   # N*32 + F*Q*(32 + k*8)
-    achieved = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
-    distances = float(nq) * world_q * frames_per_launch * info["shard_rows"]
+    sp.pipe.run(args.warmup)
+    fence()
+    sp.pipe.reset_stats()
+    sp.ctx.set_kernel_timing(True)
+    c0 = sp.ctx.counters()
+    kp0, poses0, steps0 = sp.pipe.n_kp, sp.pipe.n_poses, sp.pipe.n_steps
+    t_local0 = time.perf_counter()
+    secs = timed_regions(torch, sp.pipe.run, fence, args.steps, args.repeats, reduce_max)
+    dt_local = time.perf_counter() - t_local0
+    c1 = sp.ctx.counters()
+    k4_ms, n_launch = launch_ms(c0, c1)
+    n_timed_steps = sp.pipe.n_steps - steps0
+    dt = statistics.median(secs)
+    engine_used = args.engine
+    if engine_used == "auto":
+        world_q0 = 1 if (args.replicas or not use_dist) else world
+        engine_used = "mfma" if (world_q0 * B * nq >= 64 and world_q0 * B * nq * info["shard_rows"] >= (1 << 24)) else "valu"
 
-    # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, collected in their own
-    # rocprofv3 runs by tools/profile_k4.sh and committed as profiles/r01_k4_pmc.json); only quoted for the
-    # workload it was measured on
-    traffic, traffic_src = None, None
-    # VALU instructions the kernel EXECUTES per (row, query) pair: 16 for a full distance, about half of that when the
-    # 128-bit lower bound prunes the row (data dependent). Taken from the same PMC passes (SQ_INSTS_VALU) when the
-    # workload is the profiled one, else the dense count is used and the figure is an upper bound.
-    laneops, laneops_src = float(LANEOPS_DENSE), "dense instruction count (upper bound)"
-    pmc_path = os.path.join(ROOT, "profiles", "r01_k4_pmc.json")
-    pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
-    if (world == 1 and k == 2 and info["shard_rows"] == 1000000 and args.radius == 35 and
-            pmc.get("queries_per_launch") == B * nq):
+    # outside the timed region, single device only: the other engine on the same launch, and (vector engine) the dense schedule
+    other = {}
+    if world == 1 and not use_dist:
+        o = sp.outs[0]
+        for eng, radius in (("valu", args.radius), ("valu_dense", 256), ("mfma", args.radius)):
+            sp.ctx.set_matcher_engine(eng.split("_")[0])
+            d0 = sp.ctx.counters()
+            for _ in range(3):
+                sp.ctx.match_device(sp.Q_B[0].data_ptr(), B * nq, k, radius, o["counts"].data_ptr(), o["matches"].data_ptr(), o["xyz"].data_ptr())
+            torch.cuda.synchronize()
+            other[eng], _ = launch_ms(d0, sp.ctx.counters())
+        sp.ctx.set_matcher_engine(args.engine)
+    sp.ctx.set_kernel_timing(False)
+
+    world_q = 1 if (args.replicas or not use_dist) else world          # frames' worth of queries one launch matches: world * B or B
+    q_launch = world_q * B * nq
+    alg_bytes = info["shard_rows"] * 32 + q_launch * (32 + k * 8)      # N*32 + F*Q*(32 + k*8)
+    pairs = float(q_launch) * info["shard_rows"]
+    hbm_gbs = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
+    # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, each in its own rocprofv3 run,
+    # tools/profile_k4.sh -> profiles/r02_k4x_pmc.json); only quoted for the workload it was measured on
+    traffic, traffic_src, pmc = None, None, {}
+    pmc_path = os.path.join(ROOT, "profiles", "r02_k4x_pmc.json" if engine_used == "mfma" else "r01_k4_pmc.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+    if (world == 1 and k == 2 and info["shard_rows"] == 1000000 and args.radius == 35 and pmc.get("queries_per_launch") == q_launch):
         traffic = pmc["hbm_traffic_bytes_per_launch"]
-        traffic_src = "profiles/r01_k4_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        if "valu_insts_per_row_and_wave" in pmc:
-            laneops = float(pmc["valu_insts_per_row_and_wave"])
-            laneops_src = "profiles/r01_k4_pmc.json (SQ_INSTS_VALU per row and 64-query wave)"
-    # Single device: consecutive steps' launches overlap (two matcher contexts), so a launch's own duration overstates
-    # its cost; the VALU rate is therefore taken chip-wide over the timed region (all launches' executed lane-ops / wall
-    # time), and the per-launch figure is given beside it.
-    valu_rate_launch = laneops * distances / (k4_ms * 1e-3) if k4_ms > 0 else 0.0
-    valu_rate = laneops * distances * n_launch / dt_local if dt_local > 0 else 0.0
-    valu_frac = valu_rate / VALU_PEAK_LANEOPS
+        traffic_src = os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+
     if rank == 0:
+        if engine_used == "mfma":
+            tflops = pairs * FLOP_PER_PAIR / (k4_ms * 1e-3) / 1e12 if k4_ms > 0 else 0.0
+            roofline = {"kernel": "hamming_topk_mfma", "bound": "mfma", "achieved": tflops, "peak": MFMA_FP4_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": tflops / MFMA_FP4_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                        "launch_ms": k4_ms, "launches": n_launch, "queries_per_launch": q_launch, "db_rows": info["shard_rows"],
+                        "algorithmic_flops": pairs * FLOP_PER_PAIR, "algorithmic_bytes": alg_bytes,
+                        "pairs_per_s": pairs / (k4_ms * 1e-3) if k4_ms > 0 else 0.0,
+                        "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                                "note": "BASELINE.json's 'achieved HBM GB/s on BF-matcher': every 32-byte row is reused by all %d queries "
+                                        "of the pass, so the pass is three orders of magnitude on the compute side of the HBM roof; "
+                                        "tools/k4_small_q.py measures the memory-bound regime (a few queries per pass)" % q_launch},
+                        "measured_mfma_roof": pmc.get("measured_mfma_roof"),
+                        "note": "exact 256-bit Hamming distances as fp4 (+-1) dot products on the matrix cores: 512 flop per (query, row) "
+                                "pair, v_mfma_f32_32x32x64_f8f6f4; data independent. launch_ms = HIP events around the launch on its "
+                                "own stream, averaged over the timed regions"}
+        else:
+            laneops = float(pmc.get("valu_insts_per_row_and_wave", LANEOPS_DENSE)) if traffic is not None else float(LANEOPS_DENSE)
+            valu_rate = laneops * pairs / (k4_ms * 1e-3) if k4_ms > 0 else 0.0
+            roofline = {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "launch_ms": k4_ms,
+                        "launches": n_launch, "queries_per_launch": q_launch, "db_rows": info["shard_rows"], "algorithmic_bytes": alg_bytes,
+                        "binding_roof": "integer VALU", "valu": {"achieved": valu_rate / 1e12, "peak": VALU_PEAK_LANEOPS / 1e12,
+                                                                 "unit": "T lane-op/s", "frac": valu_rate / VALU_PEAK_LANEOPS,
+                                                                 "valu_ops_per_distance": laneops},
+                        "note": "vector-ALU engine (xor + popcount with partial-distance elimination): bound by integer VALU issue, data dependent"}
+        if other:
+            roofline["same_launch_other_engines_ms"] = {
+                "vector ALU (K4), radius %d" % args.radius: other["valu"], "vector ALU, no radius bound (dense schedule)": other["valu_dense"],
+                "matrix cores (K4x)": other["mfma"],
+                "note": "measured after the timed region, alone on the GPU; the vector engine's elimination is data dependent (independent "
+                        "bits here: its best case), the matrix engine's time is not"}
+        n_fr = max(n_timed_steps * B, 1)
         out = {
             "metric": "frames/sec @ 640x480, 1M-descriptor DB; achieved HBM GB/s on BF-matcher",
             "value": args.steps * world * B / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (xor + popcount), f32 in the verifier",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": ("fp4 (+-1) x fp4 -> f32 on the matrix cores (exact integers)" if engine_used == "mfma" else "u32 (xor + popcount)") +
+                     ", f32 in the verifier",
             "data": "synthetic",
+            "repeats": {"timed_regions": args.repeats, "steps_each": args.steps, "value_is": "median region",
+                        "frames_per_s": spread([args.steps * world * B / s for s in secs])},
             "config": {"workload": "C3: one 640x480 frame = %d ORB descriptors vs %d-descriptor DB (%d objects x 5000), "
                                    "Hamming BF k=%d, radius %d" % (nq, desc.shape[0], args.objects, k, args.radius),
-                       "stages": stages, "db_rows_per_gpu": info["shard_rows"],
-                       "matcher_input": "SURVEY 8(d) synthetic descriptors (iid bits, planted matches at 8 % flips): the "
-                                        "partial-distance elimination halves the DB pass on them; it is data dependent -- 0.27 ms per "
-                                        "frame at rBRIEF-like correlation, 0.36 ms on strongly biased descriptors, 0.43 ms dense (DESIGN.md 6, "
-                                        "tools/k4_on_correlated_descriptors.py, tools/k4_on_orb_descriptors.py)",
+                       "stages": stages, "db_rows_per_gpu": info["shard_rows"], "matcher_engine": engine_used,
+                       "dataflow": "stages run concurrently on three streams and are sized as in production but are NOT data-chained in this "
+                                   "figure (8(d)'s synthetic DB cannot be matched by descriptors of a synthetic image): ORB runs on the 8(d) "
+                                   "image, matcher and verifier consume the frame's planted descriptors; `chained` times the real dataflow",
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
-                       "poses_per_frame_rank0": n_pose_total[0] / max(n_steps_done[0] * B, 1),
+                       "poses_per_frame_rank0": (sp.pipe.n_poses - poses0) / n_fr,
                        "frames_per_rank_per_step": B,
-                       "pipeline": "3 stages on 3 streams, each one batched call per step: ORB | matcher | verifier" +
+                       "pipeline": "3 stages, each one batched call per step: ORB | matcher | verifier (two verifier workers on alternate steps)" +
                                    ("; collectives + merge on a 4th stream, overlapping the neighbouring DB passes" if overlap else ""),
-                       "stage_ms_per_step": {key: 1e3 * v / max(args.steps, 1) for key, v in stage_s.items()},
+                       "stage_ms_per_step": {key: 1e3 * v / max(n_timed_steps, 1) for key, v in sp.pipe.stage_s.items()},
                        "orb": "ORB-%d, 3 levels, scale 1.2 on the 8(d) synthetic image; %.0f keypoints/frame" %
-                              (args.nq, n_kp_total[0] / max(n_steps_done[0] * B, 1)) if do_orb else None,
+                              (args.nq, (sp.pipe.n_kp - kp0) / n_fr) if "orb" in stages else None,
                        "frames_per_step": world * B,
-                       "parallelism": ("DB rows sharded x%d (object aligned), %d frames per rank per step, RCCL all-gather of "
-                                       "descriptors, %s of per-shard candidates" % (world, B, args.exchange)) if sharded else
+                       "parallelism": ("DB rows sharded x%d (object aligned), %d frames per rank per step, RCCL all_gather of descriptors, "
+                                       "RCCL %s of per-shard candidates, %s" % (world, B, args.exchange, "collectives + merge overlapped "
+                                       "on their own stream" if overlap else "collectives in program order on the matcher's stream")) if sharded_db else
                                       ("%d replicas of the whole DB, %d frames per rank per step, no data-path collective" % (world, B)
-                                       if world > 1 else "1 GPU")},
-            "roofline": {"kernel": "hamming_topk_tiles", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launch_ms": k4_ms, "algorithmic_bytes": alg_bytes,
-                         "binding_roof": "integer VALU (see valu_roofline)", "valu_frac": valu_frac,
-                         "dense_launch_ms": dense_ms,
-                         "dense_launch_note": "same launch without the radius bound (no partial-distance elimination possible), "
-                                              "measured after the timed region, alone",
-                         "queries_per_launch": world_q * B * nq,
-                         "concurrent_matcher_contexts": len(mctx),
-                         "note": "at %d queries per DB pass this kernel is bound by integer VALU issue, not HBM "
-                                 "(SURVEY F11): see valu_roofline; launch_ms is a launch's own duration (%s)"
-                                 % (world_q * B * nq, "one matcher context: launches do not overlap" if len(mctx) == 1 else
-                                    "%d matcher contexts: consecutive launches overlap" % len(mctx))},
-            "valu_roofline": {"bound": "valu", "achieved": valu_rate / 1e12, "peak": VALU_PEAK_LANEOPS / 1e12,
-                              "unit": "T lane-op/s", "frac": valu_frac,
-                              "basis": "executed lane-ops of all matcher launches of the timed region / its wall time",
-                              "per_launch_achieved": valu_rate_launch / 1e12, "launches": n_launch,
-                              "concurrent_matcher_contexts": len(mctx),
-                              "distances_per_launch": distances, "valu_ops_per_distance": laneops,
-                              "valu_ops_source": laneops_src, "dense_ops_per_distance": LANEOPS_DENSE},
+                                       if world > 1 else "1 GPU"),
+                       "sharded_step0_equals_unsharded": check},
+            "roofline": roofline,
         }
-        if world > 1:
+        if world > 1 or use_dist:
             out["cpu_baseline"] = None                                      # timed at N = 1 only (rank 0)
-        elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
-                                               args.iterations, args.min_inliers)
+        else:
+            if "chained" in extras:
+                out["chained"] = run_chained(torch, capi, local_rank, args)
+            if "configs" in extras:
+                out["configs"] = run_configs(torch, capi, synth, local_rank, args)
+            if "adapter" in extras:
+                out["adapter_path"] = run_adapter_path(torch, capi, local_rank, desc, pts, off, frames, args)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
+                                                   args.iterations, args.min_inliers)
         print(json.dumps(out))
-    for c in (octx, vctx, cctx if overlap else None):
-        if c is not None:
-            c.close()
-    for c in mctx:
-        c.close()
+    sp.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -42,7 +42,7 @@ template <class A> struct Slots { A a[kMaxSlots]; };
 
 struct AdjArgs { ObjJob job; float span, err; };
 struct JobArgs { ObjJob job; };
-struct PrepArgs { ObjJob job; uint32_t* nvalid; };
+struct PrepArgs { ObjJob job; uint32_t* stats; };   // stats[0] = |valid|, [1] = sum of sample degrees inside valid, [2] = triangle found
 struct DrawArgs { ObjJob job; const uint32_t* rnd; uint32_t window_len, S; DrawEntry* table; };
 struct ChainArgs {
   const DrawEntry* table; uint32_t S, n_req, attempts0, out_base;
@@ -115,11 +115,18 @@ __global__ __launch_bounds__(256) void finite_kernel(Slots<JobArgs> S) {
   }
 }
 
-// per round: sample degree inside the valid set, the ">= 7" filter mask (:211-213), |valid|
+// per round: sample degree inside the valid set, the ">= 7" filter mask (:211-213), |valid| -- and whether the sample
+// graph on the valid matches holds a triangle at all. Without one, no drawIndexSampleHelper attempt can succeed
+// (sac_model_registration_graph.h:102-132 needs three mutually sample-adjacent indices), and a failing attempt consumes a
+// number of rand() calls that does not depend on the values drawn: the top level draws and erases every valid index once
+// (|valid| draws); under pick v the second level draws and erases every not-yet-erased neighbour of v (one draw each --
+// its own third level is empty, so it returns before drawing), i.e. every edge is paid for exactly once, at whichever
+// endpoint is picked first. A triangle-free object therefore advances the stream by exactly 1000 (|valid| + |E|) draws
+// (getSamples' 1000 attempts, :141-168) and yields nothing: the host skips its draw table and chain walk altogether.
 __global__ __launch_bounds__(256) void round_prep_kernel(Slots<PrepArgs> S) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.y].job;
-  uint32_t* const nvalid = S.a[blockIdx.y].nvalid;
+  uint32_t* const stats = S.a[blockIdx.y].stats;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   bool isv = false;
   uint32_t d = 0;
@@ -130,9 +137,28 @@ __global__ __launch_bounds__(256) void round_prep_kernel(Slots<PrepArgs> S) {
     job.sampdeg[v] = d;
   }
   const u64 b7 = __ballot(isv && d >= kGateMinimal), bv = __ballot(isv);
+  const uint32_t dsum = wave_sum(d);
   if (lane_id() == 0 && (v >> 6) < job.W) {
     job.deg7[v >> 6] = b7;
-    if (bv) atomicAdd(nvalid, (uint32_t)__popcll(bv));
+    if (bv) atomicAdd(stats, (uint32_t)__popcll(bv));
+    if (dsum) atomicAdd(stats + 1, dsum);
+  }
+  // triangle through v: a neighbour j > v that shares a neighbour with v (all inside valid). One finder is enough.
+  if (isv && d >= 2u) {
+    const u64* rv = job.samp + (size_t)v * job.W;
+    for (uint32_t wj = v >> 6; wj < job.W; ++wj) {
+      u64 nb = rv[wj] & job.valid[wj];
+      if (wj == (v >> 6)) nb &= (v & 63u) == 63u ? 0ull : ~0ull << ((v & 63u) + 1u);
+      while (nb) {
+        if (__hip_atomic_load(stats + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+        const uint32_t j = wj * 64u + (uint32_t)__ffsll((long long)nb) - 1u;
+        nb &= nb - 1ull;
+        const u64* rj = job.samp + (size_t)j * job.W;
+        u64 common = 0;
+        for (uint32_t w = 0; w < job.W; ++w) common |= rv[w] & rj[w] & job.valid[w];
+        if (common) { __hip_atomic_store(stats + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+      }
+    }
   }
 }
 
@@ -1706,7 +1732,7 @@ struct ObjSpan {
   uint32_t obj, offset, n;
   // this object's slices of the slot's adjacency / bitset / degree buffers (all objects of a frame are prepared in
   // one tick, so each needs its own), and its first round's |valid|
-  uint64_t adj_off = 0; uint32_t bits_off = 0, deg_off = 0, nvalid = 0;
+  uint64_t adj_off = 0; uint32_t bits_off = 0, deg_off = 0, nvalid = 0, degsum = 0, triangle = 1;
 };
 struct DepthInput { const void* d_depth; int is_u16; float fx, fy, cx, cy; };
 
@@ -1756,6 +1782,10 @@ struct Slot {
   ObjJob job = {};
   uint32_t n_all = 0;
   bool pending_invalidate = false;
+  // window-size hint for the next object's first draw window: what the previous objects of this frame consumed when their
+  // getSamples gave up (1000 failing attempts, ~4-9k draws). Frames with many stray matches hold runs of such objects; a
+  // first window sized for a healthy object (576) made each of them crawl through three windows = three ticks
+  uint32_t s_hint = 0;
   todhip_round_trace tr = {};
   RoundState r;
 };
@@ -1821,12 +1851,23 @@ struct Engine {
   u64* obj_bits(const Slot& s) const { return s.ws->bits.as<u64>() + s.objs[s.oi].bits_off; }
 
   // one AdjacencyRansac::Ransac call starts with |valid| known (adjacency_ransac.cpp:234-241)
-  void start_round(Slot& s, uint32_t nvalid) {
+  void start_round(Slot& s, uint32_t nvalid, uint32_t degsum, uint32_t triangle) {
     VerifyWs* ws = s.ws;
     RoundState& r = s.r;
-    TOD_DBG("round: n=%u W=%u nvalid=%u", s.job.n, s.job.W, nvalid);
+    TOD_DBG("round: n=%u W=%u nvalid=%u edges=%u triangle=%u", s.job.n, s.job.W, nvalid, degsum / 2u, triangle);
     if (nvalid < 3) { round_done(s, false); return; }      // :238-241
+    if (!triangle) {
+      // no three mutually sample-adjacent valid matches: getSamples fails 1000 times, each attempt consuming exactly
+      // |valid| + |E| draws whatever their values (round_prep_kernel), selection.empty() ends computeModel at
+      // iterations_ == 0 (ransac.h:100-101) and Ransac returns nothing. No kernel, no tick.
+      r = RoundState();
+      s.abs_pos += (uint64_t)kMaxSampleChecks * ((uint64_t)nvalid + degsum / 2u);
+      s.tr.iterations = 0; s.tr.best_iteration = 0; s.tr.best_count = -INT_MAX;
+      round_done(s, false);
+      return;
+    }
     r = RoundState();
+    r.s_floor = s.s_hint;
     r.nvalid = nvalid;
     r.total_iters = prm->n_ransac_iterations + 1u;          // iterations_ runs 0 .. max_iterations (ransac.h:132-134)
     SLOT_HIP(ws->iter_samples.reserve((size_t)(r.total_iters + 1) * 3 * sizeof(uint32_t)));
@@ -1869,15 +1910,15 @@ struct Engine {
     if (s.ph == PH_PREPALL) {
       // FillAdjacency and the first round's validity/degree pass of EVERY object of the frame in this one tick: they
       // do not depend on the rand() stream, and an object with < 3 valid matches then costs no tick at all
-      L.zero.push_back({nullptr, ws->nvalid.as<uint32_t>(), (uint32_t)std::max<size_t>(s.objs.size(), 1)});
+      L.zero.push_back({nullptr, ws->nvalid.as<uint32_t>(), 4u * (uint32_t)std::max<size_t>(s.objs.size(), 1)});
       for (size_t i = 0; i < s.objs.size(); ++i) {
         if (s.objs[i].n < 3) continue;
         const ObjJob job = make_job(s, s.objs[i]);
         L.finite.push_back({job});
         L.adj.push_back({job, spans[s.objs[i].obj], prm->sensor_error});
-        L.prep.push_back({job, ws->nvalid.as<uint32_t>() + i});
+        L.prep.push_back({job, ws->nvalid.as<uint32_t>() + 4 * i});
       }
-      L.copy_out.push_back({ws->nvalid.as<uint32_t>(), ws->m_nvalid.as<uint32_t>(), (uint32_t)std::max<size_t>(s.objs.size(), 1)});
+      L.copy_out.push_back({ws->nvalid.as<uint32_t>(), ws->m_nvalid.as<uint32_t>(), 4u * (uint32_t)std::max<size_t>(s.objs.size(), 1)});
       s.ph = PH_PREPALL_WAIT;
       return;
     }
@@ -1891,7 +1932,7 @@ struct Engine {
       s.pending_invalidate = false;
       s.tr = todhip_round_trace();
       s.tr.object = o.obj; s.tr.draws_before = s.start_draws + s.abs_pos; s.tr.best_count = -INT_MAX;
-      start_round(s, o.nvalid);                             // -> PH_DRAW, or straight on to the next object
+      start_round(s, o.nvalid, o.degsum, o.triangle);       // -> PH_DRAW, or straight on to the next object
     }
     if (s.ph == PH_ROUND) {                                 // one AdjacencyRansac::Ransac call (GuessGenerator.cpp:192-231)
       if (s.pending_invalidate) {
@@ -1899,7 +1940,7 @@ struct Engine {
         s.pending_invalidate = false;
       }
       L.zero.push_back({nullptr, d_small, 64u});
-      L.prep.push_back({s.job, d_small});
+      L.prep.push_back({s.job, d_small + 5});             // words 5..7: |valid|, degree sum, triangle (1..4 = ChainOut)
       export_small(s);
       s.tr = todhip_round_trace();
       s.tr.object = s.objs[s.oi].obj; s.tr.draws_before = s.start_draws + s.abs_pos; s.tr.best_count = -INT_MAX;
@@ -2064,12 +2105,14 @@ struct Engine {
     }
     if (s.ph == PH_PREPALL_WAIT) {
       const uint32_t* nv = ws->m_nvalid.as<uint32_t>();
-      for (size_t i = 0; i < s.objs.size(); ++i) s.objs[i].nvalid = nv[i];
+      for (size_t i = 0; i < s.objs.size(); ++i) {
+        s.objs[i].nvalid = nv[4 * i]; s.objs[i].degsum = nv[4 * i + 1]; s.objs[i].triangle = nv[4 * i + 2];
+      }
       s.ph = PH_OBJECT;
       return;
     }
     if (s.ph == PH_PREP_WAIT) {                             // a further round of the same object, after an accepted pose
-      start_round(s, m[0]);
+      start_round(s, m[5], m[6], m[7]);
       return;
     }
     if (s.ph == PH_DRAW_WAIT) {
@@ -2081,7 +2124,13 @@ struct Engine {
       r.got += co.n_done;
       r.consumed += co.pos_end;
       r.attempts_carry = co.attempts;
-      if (co.flag == 2) r.selection_empty = true;
+      if (co.flag == 2) {
+        r.selection_empty = true;
+        // the walk that just gave up consumed r.consumed draws in all: the next object's first window covers that much
+        uint32_t hint = 1024u;
+        while (hint < r.consumed + 512u && hint < (1u << 20)) hint <<= 1;
+        s.s_hint = std::max(s.s_hint, hint);
+      }
       if (co.flag == 1) r.s_floor = std::min<uint32_t>(std::max(r.S, 1024u) * 4u, 1u << 20);   // e.g. 1000 failing attempts in a row
       if (co.flag == 1 && co.n_done == 0 && co.pos_end == 0) {
         // a single attempt longer than the window: enlarge the look-ahead, give up beyond 64M draws
@@ -2131,7 +2180,7 @@ struct Engine {
     const size_t n_objs_here = std::max<size_t>(s.objs.size(), 1);
     if (ws->phys.reserve((size_t)std::max<uint64_t>(adj, 1) * 8) != hipSuccess || ws->samp.reserve((size_t)std::max<uint64_t>(adj, 1) * 8) != hipSuccess ||
         ws->bits.reserve((size_t)std::max<uint64_t>(bits, 8) * 8) != hipSuccess || ws->sampdeg.reserve((size_t)std::max<uint64_t>(deg, 1) * 4) != hipSuccess ||
-        ws->nvalid.reserve(n_objs_here * 4) != hipSuccess || ws->m_nvalid.reserve(n_objs_here * 4) != hipSuccess) {
+        ws->nvalid.reserve(n_objs_here * 16) != hipSuccess || ws->m_nvalid.reserve(n_objs_here * 16) != hipSuccess) {
       fail(s, TODHIP_EHIP);
       return false;
     }
@@ -2553,7 +2602,7 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   launch_list(st, finite_kernel, std::vector<JobArgs>{{job}}, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
   launch_list(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
               [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
-  launch_list(st, round_prep_kernel, std::vector<PrepArgs>{{job, d_small}}, 256, 0, 1,
+  launch_list(st, round_prep_kernel, std::vector<PrepArgs>{{job, d_small + 5}}, 256, 0, 1,
               [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
   EvalArgs A;
   A.job = job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = 0; A.it_end = n_triples;
