@@ -336,7 +336,6 @@ struct GateLds {
   uint16_t *flist, *cur, *nxt, *tmp;           // m each
   uint32_t *C, *deg, *keys;                    // m each
   uint32_t *S, *SOld, *lbase, *lsize, *lcap;   // m + 2 each
-  u64* aprime;                                 // m x MW position-space adjacency of the list being coloured, or nullptr
   uint16_t* lstack;                            // LDS part of the per-level vertex lists (the rest is in global memory)
   uint32_t lstack_cap;
 };
@@ -372,14 +371,8 @@ __device__ __forceinline__ GateLds gate_carve(unsigned char* base, uint32_t m, u
   L.cur = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
   L.nxt = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
   L.tmp = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
-  // whatever the launch's LDS allocation has left: colouring scratch first (lists of <= 512 vertices), then the stack
+  // whatever the launch's LDS allocation has left is the first part of the level stack
   uint32_t used = ((uint32_t)(base - base0) + 15u) & ~15u;
-  L.aprime = nullptr;
-  const uint32_t ap_bytes = 8u * m * MW;
-  if (m > 64u && m <= 512u && used + ap_bytes <= lds_bytes) {
-    L.aprime = reinterpret_cast<u64*>(base0 + used);
-    used += (ap_bytes + 15u) & ~15u;
-  }
   L.lstack = reinterpret_cast<uint16_t*>(base0 + used);
   L.lstack_cap = lds_bytes > used ? (lds_bytes - used) / 2u : 0u;
   return L;
@@ -488,185 +481,105 @@ __device__ __forceinline__ void degrees_in_list(const GateLds& L, const uint16_t
 // equals colouring class by class (each class = greedy independent set in list order), which is what the
 // bit-parallel loop below does. With min_k >= 2 class 1 is never filled (:242-245), so every vertex gets
 // k = 1 < min_k, the order is unchanged and only C[r-1] = 0 is written (:247-248).
-// Register form of the class-by-class colouring for lists of up to 64 * NCH vertices. Phase 1 builds the
-// adjacency of the list in POSITION space (row i = bits over list positions), one ballot per (row, chunk), with no
-// dependency between rows, so the LDS reads pipeline; row i lives in lane (i & 63), chunk-row (i >> 6). Phase 2 is
-// the sequential greedy pass: the candidate set Q and the uncoloured set are wave-uniform scalars, a pick costs a
-// find-first-set, NCH v_readlane pairs and NCH and-not operations -- no LDS read on the critical path.
-template <int NCH>
-__device__ __forceinline__ void colour_sort_regs(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW) {
+// First-fit colouring in list order with one LANE per colour class (graphs of up to 512 vertices).
+// ColorSort (maximum_clique.cpp:219-261) gives vertex i the smallest class none of whose members it is adjacent to; lane c
+// keeps class c's members as a bitset over GRAPH vertices in MWT registers, so "is v adjacent to a member of class c" is
+// (row_v & class_c) != 0 for all classes at once: MWT broadcast LDS reads of row_v (prefetched: the list order is known),
+// MWT and-or pairs, one ballot, one find-first-set. Nothing on the critical path waits for LDS, and no position-space
+// adjacency has to be built (the class-by-class forms that this replaces paid ~600 cycles per coloured vertex for both).
+// A second register set serves classes 64..127 once the first 64 are in use; with more than 128 classes the caller falls
+// back to the generic class-by-class loop. Output as ColorSort's: the list regrouped by class (each class in list order),
+// C[position] = class.
+template <uint32_t MWT>
+__device__ __forceinline__ bool colour_first_fit(const GateLds& L, uint16_t* list, uint32_t r) {
   const uint32_t l = lane_id();
-  const uint32_t nch = (r + 63u) / 64u;
-  uint32_t hreg[NCH];
-  u64 arow[NCH][NCH];
+  u64 cls0[MWT], cls1[MWT];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    hreg[c] = (c * 64u + l) < r ? list[c * 64u + l] : 0xFFFFFFFFu;
+  for (uint32_t w = 0; w < MWT; ++w) { cls0[w] = 0ull; cls1[w] = 0ull; }
+  uint32_t cnt0 = 0u, cnt1 = 0u;                           // members of class l / class 64 + l so far
+  bool wide = false, overflow = false;                     // wave-uniform
+  for (uint32_t c0 = 0; c0 < r; c0 += 64u) {
+    const uint32_t cnt = min(64u, r - c0);
+    const uint32_t vmine = (c0 + l) < r ? (uint32_t)list[c0 + l] : 0u;
+    uint32_t rec = 0u;                                     // lane li: (class << 16 | index inside the class) of position c0 + li
+    // one vertex: `row` holds its adjacency row (loaded one vertex ahead), `next` receives the following vertex's
+    auto place = [&](const u64 (&row)[MWT], u64 (&next)[MWT], uint32_t li) {
+      const uint32_t v = rdlane(vmine, li);
+      {
+        const u64* g = L.adjc + (size_t)rdlane(vmine, min(li + 1u, cnt - 1u)) * MWT;   // the chunk's last re-reads itself
 #pragma unroll
-    for (int c2 = 0; c2 < NCH; ++c2) arow[c][c2] = 0ull;
-  }
-  constexpr uint32_t kInFlight = 4;
+        for (uint32_t w = 0; w < MWT; ++w) next[w] = g[w];
+      }
+      u64 hit = 0ull;
 #pragma unroll
-  for (int ci = 0; ci < NCH; ++ci) {
-    if ((uint32_t)ci < nch) {                              // wave-uniform
-      const uint32_t cnt = min(64u, r - ci * 64u);
-      for (uint32_t li0 = 0; li0 < cnt; li0 += kInFlight) {
-        u64 wv[kInFlight][NCH];
+      for (uint32_t w = 0; w < MWT; ++w) hit |= row[w] & cls0[w];
+      const u64 free0 = __ballot(hit == 0ull);
+      uint32_t k;
+      if (free0 != 0ull) {
+        k = (uint32_t)__ffsll((long long)free0) - 1u;
+      } else {
+        wide = true;
+        u64 hit1 = 0ull;
 #pragma unroll
-        for (uint32_t jj = 0; jj < kInFlight; ++jj) {
-          const uint32_t gi = rdlane(hreg[ci], min(li0 + jj, cnt - 1u));
-          const u64* grow = L.adjc + (size_t)gi * MW;
+        for (uint32_t w = 0; w < MWT; ++w) hit1 |= row[w] & cls1[w];
+        const u64 free1 = __ballot(hit1 == 0ull);
+        if (free1 == 0ull) { overflow = true; k = 127u; } else k = 64u + (uint32_t)__ffsll((long long)free1) - 1u;
+      }
+      // vertex v joins class k: only lane k (mod 64) executes the update; which register pair receives the bit is decided
+      // on the scalar side (v is wave-uniform), so the arrays are only ever indexed statically and stay in registers
+      const bool mine = l == (k & 63u);
+      const u64 bit = 1ull << (v & 63u);
+      const uint32_t vw = v >> 6;
+      const uint32_t idx = k < 64u ? rdlane(cnt0, k & 63u) : rdlane(cnt1, k & 63u);
+      if (mine) {
+        if (k < 64u) {
 #pragma unroll
-          for (int c = 0; c < NCH; ++c)
-            wv[jj][c] = ((uint32_t)c < nch && hreg[c] != 0xFFFFFFFFu) ? grow[hreg[c] >> 6] : 0ull;
-        }
+          for (uint32_t w = 0; w < MWT; ++w) cls0[w] |= (vw == w) ? bit : 0ull;
+        } else {
 #pragma unroll
-        for (uint32_t jj = 0; jj < kInFlight; ++jj) {
-          const uint32_t li = li0 + jj;
-          if (li < cnt) {                                  // wave-uniform
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-              if ((uint32_t)c < nch) {
-                const u64 bal = __ballot(((wv[jj][c] >> (hreg[c] & 63u)) & 1ull) != 0ull);
-                if (l == li) arow[ci][c] = bal;
-              }
-            }
-          }
+          for (uint32_t w = 0; w < MWT; ++w) cls1[w] |= (vw == w) ? bit : 0ull;
         }
       }
+      cnt0 += (mine && k < 64u) ? 1u : 0u;                  // (branch-free: a merged store through a selected address would
+      cnt1 += (mine && k >= 64u) ? 1u : 0u;                 //  put both counters into scratch memory)
+      if (l == li) rec = (k << 16) | idx;
+    };
+    u64 rowA[MWT], rowB[MWT];
+    {
+      const u64* g = L.adjc + (size_t)rdlane(vmine, 0u) * MWT;
+#pragma unroll
+      for (uint32_t w = 0; w < MWT; ++w) rowA[w] = g[w];
     }
-  }
-  u64 uncol[NCH], Q[NCH];                                  // wave-uniform
-#pragma unroll
-  for (int c = 0; c < NCH; ++c)
-    uncol[c] = (uint32_t)c < nch ? ((c * 64u + 64u <= r) ? ~0ull : ((1ull << (r - c * 64u)) - 1ull)) : 0ull;
-  uint32_t k = 1, outpos = 0;
-  while (true) {
-    u64 any = 0ull;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) { any |= uncol[c]; Q[c] = uncol[c]; }
-    if (any == 0ull) break;
-    while (true) {
-      int wi = -1;
-      u64 wq = 0ull;
-#pragma unroll
-      for (int c = NCH - 1; c >= 0; --c)
-        if (Q[c] != 0ull) { wi = c; wq = Q[c]; }
-      if (wi < 0) break;
-      const uint32_t bit = (uint32_t)__ffsll((long long)wq) - 1u;
-      uint32_t g = 0;
-      u64 row[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) row[c] = 0ull;
-#pragma unroll
-      for (int ci = 0; ci < NCH; ++ci) {
-        if (wi == ci) {                                    // wave-uniform
-          g = rdlane(hreg[ci], bit);
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) row[c] = rdlane64(arow[ci][c], bit);
-        }
-      }
-      if (l == 0) { L.tmp[outpos] = (uint16_t)g; L.C[outpos] = k; }
-      ++outpos;
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const u64 self = (c == wi) ? (1ull << bit) : 0ull;
-        Q[c] &= ~(row[c] | self);                          // neighbours cannot join this class
-        uncol[c] &= ~self;
-      }
+    uint32_t li = 0;
+    for (; li + 2u <= cnt; li += 2u) {                     // two vertices per trip: the row buffers swap roles, nothing is copied
+      place(rowA, rowB, li);
+      place(rowB, rowA, li + 1u);
     }
-    ++k;
+    if (li < cnt) place(rowA, rowB, li);
+    if (c0 + l < r) L.keys[c0 + l] = rec;
+  }
+  if (overflow) return false;                              // > 128 classes: the list itself is untouched
+  // class c's block starts after all smaller classes: exclusive prefix of the class sizes over the lanes
+  const uint32_t incl0 = wave_incl_scan(cnt0), total0 = uni(__shfl(incl0, 63));
+  const uint32_t base0 = incl0 - cnt0;
+  uint32_t base1 = 0u;
+  if (wide) { const uint32_t incl1 = wave_incl_scan(cnt1); base1 = total0 + incl1 - cnt1; }
+  __syncthreads();
+  for (uint32_t i = l; i < r + 63u - ((r + 63u) & 63u); i += 64u) {   // whole waves: the shuffles need every lane
+    const uint32_t rec = i < r ? L.keys[i] : 0u;
+    const uint32_t k = rec >> 16;
+    uint32_t b = __shfl(base0, k & 63u);
+    if (wide) { const uint32_t b1 = __shfl(base1, k & 63u); b = k >= 64u ? b1 : b; }
+    if (i < r) {
+      const uint32_t pos = b + (rec & 0xFFFFu);
+      L.tmp[pos] = list[i];
+      L.C[pos] = k + 1u;
+    }
   }
   __syncthreads();
   for (uint32_t i = l; i < r; i += 64u) list[i] = L.tmp[i];
   __syncthreads();
-}
-
-// Same colouring for lists of 65..512 vertices when the launch has LDS to spare: the position-space rows go to
-// LDS (ap[i * nch + c]), Q and the uncoloured set are spread over the lanes (lane c = positions 64c..64c+63). A pick
-// is a ballot, two find-first-set, one LDS row read and an and-not, whatever the list length.
-// NCH = number of 64-position chunks of the list, a template parameter: the per-chunk work is straight-line code (the
-// wave-uniform `c < nch` tests of a run-time chunk count compiled to a branch pair per chunk and row)
-template <uint32_t NCH>
-__device__ __forceinline__ void colour_sort_rows(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW) {
-  const uint32_t l = lane_id();
-  constexpr uint32_t nch = NCH;
-  u64* ap = L.aprime;
-  uint32_t hoff[NCH], hbit[NCH];             // word offset and bit of this lane's member of every chunk
-#pragma unroll
-  for (uint32_t c = 0; c < NCH; ++c) {
-    const uint32_t h = (c * 64u + l) < r ? list[c * 64u + l] : 0xFFFFFFFFu;
-    hoff[c] = h == 0xFFFFFFFFu ? 0xFFFFFFFFu : (h >> 6);
-    hbit[c] = h & 63u;
-  }
-  constexpr uint32_t kInFlight = 4;
-  for (uint32_t ci = 0; ci < nch; ++ci) {
-    const uint32_t cnt = min(64u, r - ci * 64u);
-    const uint32_t myv = (ci * 64u + l) < r ? list[ci * 64u + l] : 0u;
-    uint32_t acc_lo[NCH], acc_hi[NCH];                      // row (64 ci + l)
-#pragma unroll
-    for (uint32_t c = 0; c < NCH; ++c) { acc_lo[c] = 0u; acc_hi[c] = 0u; }
-    for (uint32_t li0 = 0; li0 < cnt; li0 += kInFlight) {
-      u64 wv[kInFlight][NCH];
-#pragma unroll
-      for (uint32_t jj = 0; jj < kInFlight; ++jj) {
-        const uint32_t gi = rdlane(myv, min(li0 + jj, cnt - 1u));
-        const u64* grow = L.adjc + (size_t)gi * MW;
-#pragma unroll
-        for (uint32_t c = 0; c < NCH; ++c)
-          wv[jj][c] = hoff[c] != 0xFFFFFFFFu ? grow[hoff[c]] : 0ull;
-      }
-#pragma unroll
-      for (uint32_t jj = 0; jj < kInFlight; ++jj) {
-        const uint32_t li = li0 + jj;
-        if (li < cnt) {                                    // wave-uniform
-#pragma unroll
-          for (uint32_t c = 0; c < NCH; ++c) {
-            const u64 bal = __ballot(((wv[jj][c] >> hbit[c]) & 1ull) != 0ull);
-            if (l == li) { acc_lo[c] = (uint32_t)bal; acc_hi[c] = (uint32_t)(bal >> 32); }
-          }
-        }
-      }
-    }
-    if (ci * 64u + l < r) {
-#pragma unroll
-      for (uint32_t c = 0; c < NCH; ++c) ap[(size_t)(ci * 64u + l) * nch + c] = ((u64)acc_hi[c] << 32) | acc_lo[c];
-    }
-  }
-  __syncthreads();
-  u64 uncol = 0ull;
-  if (l < nch) uncol = (l * 64u + 64u <= r) ? ~0ull : ((1ull << (r - l * 64u)) - 1ull);
-  uint32_t k = 1, outpos = 0;
-  uint32_t mypos = 0, myk = 0;                             // lane (outpos & 63) records a pick; flushed every 64 picks
-  while (__ballot(uncol != 0ull) != 0ull) {
-    u64 Q = uncol;
-    while (true) {
-      const u64 balQ = __ballot(Q != 0ull);
-      if (balQ == 0ull) break;
-      const uint32_t ll = (uint32_t)__ffsll((long long)balQ) - 1u;
-      const u64 wq = rdlane64(Q, ll);
-      const uint32_t bit = (uint32_t)__ffsll((long long)wq) - 1u;
-      const uint32_t pos = ll * 64u + bit;
-      const u64 rowc = l < nch ? ap[(size_t)pos * nch + l] : 0ull;
-      const u64 self = (l == ll) ? (1ull << bit) : 0ull;
-      uncol &= ~self;
-      Q &= ~(rowc | self);                                 // neighbours cannot join this class
-      if (l == (outpos & 63u)) { mypos = pos; myk = k; }
-      ++outpos;
-      if ((outpos & 63u) == 0u) { L.keys[outpos - 64u + l] = mypos; L.C[outpos - 64u + l] = myk; }
-    }
-    ++k;
-  }
-  if (l < (outpos & 63u)) { L.keys[(outpos & ~63u) + l] = mypos; L.C[(outpos & ~63u) + l] = myk; }
-  __syncthreads();
-  uint16_t moved[NCH];
-#pragma unroll
-  for (uint32_t c = 0; c < NCH; ++c) moved[c] = (c * 64u + l) < r ? list[L.keys[c * 64u + l]] : (uint16_t)0;
-  __syncthreads();
-#pragma unroll
-  for (uint32_t c = 0; c < NCH; ++c)
-    if ((c * 64u + l) < r) list[c * 64u + l] = moved[c];
-  __syncthreads();
+  return true;
 }
 
 __device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW, uint32_t qmax, uint32_t qsz) {
@@ -690,21 +603,21 @@ __device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, ui
     __syncthreads();
     return;
   }
-  if (r <= 64u) { colour_sort_regs<1>(L, list, r, MW); return; }
-  if (r <= 512u && L.aprime) {
-    switch ((r + 63u) / 64u) {                            // wave-uniform
-      case 2: colour_sort_rows<2>(L, list, r, MW); break;
-      case 3: colour_sort_rows<3>(L, list, r, MW); break;
-      case 4: colour_sort_rows<4>(L, list, r, MW); break;
-      case 5: colour_sort_rows<5>(L, list, r, MW); break;
-      case 6: colour_sort_rows<6>(L, list, r, MW); break;
-      case 7: colour_sort_rows<7>(L, list, r, MW); break;
-      default: colour_sort_rows<8>(L, list, r, MW); break;
+  if (MW <= 8u) {                                          // graphs of up to 512 vertices: one lane per colour class
+    bool done = false;
+    switch (MW) {                                          // wave-uniform
+      case 1: done = colour_first_fit<1>(L, list, r); break;
+      case 2: done = colour_first_fit<2>(L, list, r); break;
+      case 3: done = colour_first_fit<3>(L, list, r); break;
+      case 4: done = colour_first_fit<4>(L, list, r); break;
+      case 5: done = colour_first_fit<5>(L, list, r); break;
+      case 6: done = colour_first_fit<6>(L, list, r); break;
+      case 7: done = colour_first_fit<7>(L, list, r); break;
+      default: done = colour_first_fit<8>(L, list, r); break;
     }
-    return;
+    if (done) return;                                      // else: more than 128 classes -> the generic loop below
   }
-  if (r <= 256u) { colour_sort_regs<4>(L, list, r, MW); return; }
-  if (r <= 512u) { colour_sort_regs<8>(L, list, r, MW); return; }
+  // generic class-by-class colouring (graphs beyond 512 vertices, or more than 128 classes)
   const uint32_t nchunks = (r + 63u) / 64u;
   u64 uncol = 0ull;                                        // lane c holds positions [64c, 64c + 64)
   if (l < nchunks) uncol = (l * 64u + 64u <= r) ? ~0ull : ((1ull << (r - l * 64u)) - 1ull);
@@ -1869,6 +1782,12 @@ struct Engine {
     r = RoundState();
     r.s_floor = s.s_hint;
     r.nvalid = nvalid;
+    // First evaluation batch: an object with many valid matches is expensive to evaluate (its clique gate walks a graph of
+    // about that many vertices, one wave per hypothesis, and a tick lasts as long as its slowest hypothesis), and when it is
+    // real its first hypotheses end the loop: with w = consensus / valid, k = log(0.01) / log(1 - w^3) (ransac.h:123-130) is
+    // <= 2 from w = 0.966 on (<= 1 only from 0.9967 on). So two hypotheses, not 16; the replay asks for more if k says so.
+    // Small objects keep the batch of 16 (cheap evaluations, usually needing many).
+    if (nvalid >= 64u) r.batch = 2;
     r.total_iters = prm->n_ransac_iterations + 1u;          // iterations_ runs 0 .. max_iterations (ransac.h:132-134)
     SLOT_HIP(ws->iter_samples.reserve((size_t)(r.total_iters + 1) * 3 * sizeof(uint32_t)));
     SLOT_HIP(ws->gate_m.reserve((size_t)(r.total_iters + 1) * sizeof(uint32_t)));
