@@ -1,8 +1,10 @@
-// adapter/ecto_cells.hpp -- the two detection cells of wg-perception/tod, re-hosted on libtodhip.
+// adapter/ecto_cells.hpp -- the detection cells of wg-perception/tod's plasm, re-hosted on libtodhip.
 //
 // Same cell names, parameter names, tendril names and tendril types as the reference cells
 //   tod::DescriptorMatcher   src/detection/DescriptorMatcher.cpp:58-269
 //   tod::GuessGenerator      src/detection/GuessGenerator.cpp:69-276
+// and as the third-party cell the reference's graph instantiates for stage A
+//   ecto_opencv.features2d.FeatureDescriptor   python/object_recognition_tod/detector.py:10,27,35-36,41,44,71-74,80-81
 // so that python/object_recognition_tod/detector.py and conf/*.ork run unchanged.
 // The cells hold no algorithm: they convert tendril types to the flat buffers of include/todhip.h.
 //
@@ -93,10 +95,15 @@ struct DescriptorMatcher
     const std::string js = params.get<std::string>("search_json_params");
     radius_ = (unsigned int)json_number(js, "radius", 0);
     ratio_ = (unsigned int)json_number(js, "ratio", 0);
+    // "ratio": 0.8 of the shipped configs is stored in an `unsigned int` by the reference, i.e. 0: its (empty) ratio block
+    // never runs (:223-227). The test itself exists here (todhip_set_ratio_test) and is reachable through a key of its own,
+    // "lowe_ratio" (a float in (0, 1]), so that the reference's configs keep their reference behaviour.
+    lowe_ratio_ = (float)json_number(js, "lowe_ratio", 0.0);
     // The reference accepts only "LSH" and `throw;`s otherwise (:182-186). The LSH table parameters
     // (n_tables, key_size, multi_probe_level) select an *approximate* index there; here the search is exact.
     if (json_string(js, "type", "") != "LSH") throw std::runtime_error("Search not implemented for that type");
     ctx_ = shared_context();
+    if (todhip_set_ratio_test(ctx_, lowe_ratio_) != TODHIP_OK) throw std::runtime_error("lowe_ratio must lie in [0, 1]");
   }
   // DescriptorMatcher.cpp:60-129. `docs`: per object the "descriptors" (n x 32 CV_8U) and "points" attachments.
   struct ObjectModel { ObjectId id; cv::Mat descriptors, points; };
@@ -110,9 +117,9 @@ struct DescriptorMatcher
       keep_.push_back(docs[i].descriptors.isContinuous() ? docs[i].descriptors : docs[i].descriptors.clone());
       keep_.push_back(pts.isContinuous() ? pts : pts.clone());
       todhip_object o;
-      o.desc = keep_[2 * i].template ptr<uint8_t>(0);
-      o.pts_xyz = keep_[2 * i + 1].template ptr<float>(0);
       o.n = (uint32_t)keep_[2 * i].rows;
+      o.desc = o.n ? keep_[2 * i].template ptr<uint8_t>(0) : nullptr;    // an empty model: no row 0 to point at
+      o.pts_xyz = o.n ? keep_[2 * i + 1].template ptr<float>(0) : nullptr;
       objs.push_back(o);
       object_ids_.push_back(docs[i].id);
     }
@@ -169,6 +176,7 @@ struct DescriptorMatcher
 
   todhip_ctx* ctx_ = nullptr;
   unsigned int radius_ = 0, ratio_ = 0;
+  float lowe_ratio_ = 0.f;
   std::vector<ObjectId> object_ids_;
   std::map<ObjectId, float> spans_;
   std::vector<cv::Mat> keep_;
@@ -232,6 +240,8 @@ struct GuessGenerator {
 #endif
     if (!point_cloud.empty()) {                                          // :147-152: the 2D-only branch is a TODO
       const uint32_t nq = (uint32_t)matches.size();
+      if (keypoints.size() < matches.size())                               // the library reads nq keypoints
+        throw std::runtime_error("GuessGenerator: fewer keypoints than match lists");
       std::vector<float> kp(2 * (size_t)keypoints.size());
       for (size_t i = 0; i < keypoints.size(); ++i) { kp[2 * i] = keypoints[i].pt.x; kp[2 * i + 1] = keypoints[i].pt.y; }
       std::vector<uint32_t> row_ptr(nq + 1, 0u);
@@ -251,12 +261,22 @@ struct GuessGenerator {
       }
       cv::Mat cloud = point_cloud.isContinuous() ? point_cloud : point_cloud.clone();
       todhip_verify_params prm = {min_inliers_, n_ransac_iterations_, sensor_error_};
-      std::vector<todhip_pose> poses(256);
-      std::vector<uint32_t> inl((size_t)256 * (keypoints.size() + 1));
-      uint32_t n_poses = (uint32_t)poses.size(), n_inl = (uint32_t)inl.size();
-      const int rc = todhip_verify(ctx_, kp.data(), nq, cloud.template ptr<float>(0), (uint32_t)cloud.rows,
-                                   (uint32_t)cloud.cols, row_ptr.data(), flat.data(), xyz.data(), span_by_index.data(),
-                                   (uint32_t)span_by_index.size(), &prm, &rng_, poses.data(), &n_poses, inl.data(), &n_inl);
+      // the reference has no limit on the number of poses: on TODHIP_ECAPACITY the frame is redone from the same
+      // generator state with twice the room
+      std::vector<todhip_pose> poses;
+      std::vector<uint32_t> inl;
+      uint32_t n_poses = 0, n_inl = 0;
+      int rc = TODHIP_ECAPACITY;
+      for (size_t cap = 256; rc == TODHIP_ECAPACITY && cap <= (1u << 16); cap *= 2) {
+        poses.resize(cap);
+        inl.resize(cap * (keypoints.size() + 1));
+        n_poses = (uint32_t)poses.size(); n_inl = (uint32_t)inl.size();
+        todhip_rng rng = rng_;
+        rc = todhip_verify(ctx_, kp.data(), nq, cloud.template ptr<float>(0), (uint32_t)cloud.rows, (uint32_t)cloud.cols,
+                           row_ptr.data(), flat.data(), xyz.data(), span_by_index.data(), (uint32_t)span_by_index.size(), &prm,
+                           &rng, poses.data(), &n_poses, inl.data(), &n_inl);
+        if (rc == TODHIP_OK) rng_ = rng;
+      }
       if (rc != TODHIP_OK) throw std::runtime_error("todhip_verify failed");
       for (uint32_t i = 0; i < n_poses; ++i) {                            // :223-230
         cv::Mat R(3, 3, CV_32F), T(3, 1, CV_32F);
@@ -291,10 +311,87 @@ struct GuessGenerator {
 #endif
 };
 
+// ------------------------------------------------------------------------------------------------------------
+// Stage A. The reference's graph takes its features from ecto_opencv's FeatureDescriptor cell (third party; not in the
+// reference tree): parameters json_feature_params / json_descriptor_params (the `feature:` / `descriptor:` blocks of
+// conf/detection.ork:23-31 as JSON strings, forwarded at detector.py:35-36), inputs image and mask (detector.py:41,71-74),
+// outputs keypoints and descriptors (detector.py:44,80-81). Only ORB exists here (the configs' type); `pattern` is an
+// extension: the 256 x 4 int8 test pairs (x0, y0, x1, y1) -- OpenCV's learned bit_pattern_31_ when descriptors must
+// interoperate with OpenCV-trained models; empty = the library's built-in seeded pattern.
+struct FeatureDescriptor {
+  static void declare_params(ecto::tendrils& p) {
+    p.declare<std::string>("json_feature_params", "Parameters for the feature as a JSON string. It should have the format: "
+                           "\"{\"type\":\"ORB/SIFT whatever\", \"module\":\"where_it_is\", \"param_1\":val1, ....}",
+                           std::string("{\"type\": \"ORB\", \"module\": \"ecto_opencv.features2d\"}"));
+    p.declare<std::string>("json_descriptor_params", "Parameters for the descriptor as a JSON string. It should have the "
+                           "format: \"{\"type\":\"ORB/SIFT whatever\", \"module\":\"where_it_is\", \"param_1\":val1, ....}",
+                           std::string("{\"type\": \"ORB\", \"module\": \"ecto_opencv.features2d\"}"));
+    p.declare<cv::Mat>("pattern", "Optional 256 x 4 int8 rBRIEF test pairs (x0, y0, x1, y1); empty = built-in pattern", cv::Mat());
+  }
+  static void declare_io(const ecto::tendrils&, ecto::tendrils& inputs, ecto::tendrils& outputs) {
+    inputs.declare<cv::Mat>("image", "An input image.");
+    inputs.declare<cv::Mat>("mask", "An mask, same size as image.");
+    outputs.declare<std::vector<cv::KeyPoint> >("keypoints", "The keypoints.");
+    outputs.declare<cv::Mat>("descriptors", "The descriptors per keypoints");
+  }
+  void configure(const ecto::tendrils& params, const ecto::tendrils&, const ecto::tendrils&) {
+    const std::string jf = params.get<std::string>("json_feature_params"), jd = params.get<std::string>("json_descriptor_params");
+    if (json_string(jf, "type", "ORB") != "ORB" || json_string(jd, "type", "ORB") != "ORB")
+      throw std::runtime_error("FeatureDescriptor: only ORB features/descriptors are implemented");
+    n_features_ = (uint32_t)json_number(jf, "n_features", 1000);
+    n_levels_ = (uint32_t)json_number(jf, "n_levels", 3);
+    scale_factor_ = (float)json_number(jf, "scale_factor", 1.2);
+    const cv::Mat& pat = params.get<cv::Mat>("pattern");
+    pattern_.clear();
+    if (!pat.empty()) {
+      if (pat.rows * pat.cols != 1024) throw std::runtime_error("FeatureDescriptor: pattern must hold 256 x 4 int8 values");
+      pattern_.assign(pat.template ptr<int8_t>(0), pat.template ptr<int8_t>(0) + 1024);
+    }
+    ctx_ = shared_context();
+  }
+  int process(const ecto::tendrils& inputs, const ecto::tendrils& outputs) {
+    cv::Mat image = inputs.get<cv::Mat>("image");
+#ifdef TOD_AMD_WITH_ORK
+    if (image.channels() == 3) { cv::Mat g; cv::cvtColor(image, g, CV_RGB2GRAY); image = g; }   // cv::ORB converts as well
+#endif
+    const cv::Mat& mask = inputs.get<cv::Mat>("mask");
+    if (!image.isContinuous()) image = image.clone();
+    const uint32_t H = (uint32_t)image.rows, W = (uint32_t)image.cols;
+    std::vector<float> kp(2 * (size_t)n_features_), aux(4 * (size_t)n_features_);
+    cv::Mat desc((int)n_features_, 32, CV_8U);
+    uint32_t n = n_features_;
+    const bool use_mask = !mask.empty() && (uint32_t)mask.rows == H && (uint32_t)mask.cols == W;
+    cv::Mat mk = use_mask ? (mask.isContinuous() ? mask : mask.clone()) : cv::Mat();
+    const int rc = todhip_orb_masked(ctx_, image.template ptr<uint8_t>(0), use_mask ? mk.template ptr<uint8_t>(0) : nullptr, H, W, W,
+                                     n_features_, n_levels_, scale_factor_, pattern_.empty() ? nullptr : pattern_.data(), kp.data(),
+                                     aux.data(), n_features_ ? desc.template ptr<uint8_t>(0) : nullptr, &n);
+    if (rc != TODHIP_OK) throw std::runtime_error("todhip_orb failed");
+    std::vector<cv::KeyPoint> keypoints(n);
+    for (uint32_t i = 0; i < n; ++i) {
+      keypoints[i].pt.x = kp[2 * i]; keypoints[i].pt.y = kp[2 * i + 1];
+      keypoints[i].size = aux[4 * i]; keypoints[i].angle = aux[4 * i + 1]; keypoints[i].response = aux[4 * i + 2];
+      keypoints[i].octave = (int)aux[4 * i + 3]; keypoints[i].class_id = -1;
+    }
+    cv::Mat out((int)n, 32, CV_8U);
+    if (n) std::memcpy(out.template ptr<uint8_t>(0), desc.template ptr<uint8_t>(0), (size_t)n * 32);
+    outputs["keypoints"] << keypoints;
+    outputs["descriptors"] << out;
+    return ecto::OK;
+  }
+
+  todhip_ctx* ctx_ = nullptr;
+  uint32_t n_features_ = 1000, n_levels_ = 3;
+  float scale_factor_ = 1.2f;
+  std::vector<int8_t> pattern_;
+};
+
 }  // namespace tod_amd
 
 #ifdef TOD_AMD_WITH_ORK
 // src/detection/module.cpp:38 and the ECTO_CELL lines of the two reference files (:269, :275)
 ECTO_CELL(ecto_detection, tod_amd::DescriptorMatcher, "DescriptorMatcher", "Given descriptors, find matches, relating to objects.");
 ECTO_CELL(ecto_detection, tod_amd::GuessGenerator, "GuessGenerator", "Given descriptors and 3D positions, compute object guesses.");
+// stage A: registered under the name detector.py imports from ecto_opencv.features2d (INTEGRATION.md shows the one-line
+// change of that import, or the ecto_opencv-side shadowing that needs no change at all)
+ECTO_CELL(ecto_detection, tod_amd::FeatureDescriptor, "FeatureDescriptor", "Compute features and descriptors for an image (ORB on the GPU).");
 #endif

@@ -96,6 +96,14 @@ int todhip_db_info(const todhip_ctx*, uint64_t* total_rows, uint64_t* shard_firs
 int todhip_match(todhip_ctx*, const uint8_t* q_desc, uint32_t nq, uint32_t k, uint32_t radius,
                  uint32_t* row_ptr, todhip_dmatch* matches, float* matches_xyz);
 
+/* Lowe's ratio test, the step the reference announces and leaves empty (DescriptorMatcher.cpp:223-227; its shipped configs
+ * ask for ratio 0.8, conf/detection.ork:39, which its `unsigned int ratio_` turns into 0 = off). Off by default; when set
+ * (0 < ratio <= 1), every todhip_match* form drops all matches of a query whose two nearest DB rows (d1 <= d2, exact, over
+ * the whole DB whatever the radius) do not satisfy (float)d1 < ratio * (float)d2; a one-row DB passes. The radius cut then
+ * applies to the survivors. The sharded forms need k >= 2 while it is on. Definition = oracle/tod_oracle.cpp
+ * orc_match_ratio (there is no reference behaviour to be identical to). */
+int todhip_set_ratio_test(todhip_ctx*, float ratio);
+
 /* Device-resident form of the same call (inputs already in HBM, outputs stay in HBM):
  * d_counts[nq] (matches kept per query), d_matches[nq*k], d_matches_xyz[nq*k*3], fixed stride k. */
 int todhip_match_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t k, uint32_t radius,
@@ -184,6 +192,12 @@ int todhip_verify_batch_device_depth(todhip_ctx*, uint32_t n_frames, const void*
 int todhip_orb(todhip_ctx*, const uint8_t* gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
                uint32_t n_levels, float scale_factor, const int8_t* pattern, float* kp_xy, float* kp_aux,
                uint8_t* desc, uint32_t* n_out);
+
+/* The same with the cell's `mask` input (detector.py:41 forwards it to FeatureDescriptor; cv::ORB's second argument): only
+ * pixels with mask != 0 (H x W u8, row stride `stride`, level 0) can become keypoints. mask == NULL: todhip_orb. */
+int todhip_orb_masked(todhip_ctx*, const uint8_t* gray, const uint8_t* mask, uint32_t H, uint32_t W, uint32_t stride,
+                      uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, float* kp_xy,
+                      float* kp_aux, uint8_t* desc, uint32_t* n_out);
 
 /* Device-resident form: d_gray (H x W u8, row stride `stride`) is in HBM, keypoints and descriptors stay in HBM
  * (d_kp_xy[cap*2] f32, d_kp_aux[cap*4] f32, d_desc[cap*32] u8); only the count comes back. *n_out: capacity in. */

@@ -48,6 +48,9 @@ void orc_spans(const float* pts_xyz, const uint32_t* obj_off, uint32_t n_obj, fl
 int orc_match(const uint8_t* db_desc, const uint32_t* obj_off, uint32_t n_obj, const float* db_pts_xyz,
               uint32_t desc_bytes, const uint8_t* q_desc, uint32_t nq, uint32_t k, uint32_t radius,
               uint32_t* row_ptr, orc_dmatch* matches, float* matches_xyz);
+int orc_match_ratio(const uint8_t* db_desc, const uint32_t* obj_off, uint32_t n_obj, const float* db_pts_xyz,
+              uint32_t desc_bytes, const uint8_t* q_desc, uint32_t nq, uint32_t k, uint32_t radius, float ratio,
+              uint32_t* row_ptr, orc_dmatch* matches, float* matches_xyz);
 /* exact k-NN keys only: key = (distance << 32) | global_row, ascending, k per query (UINT64_MAX padded) */
 void orc_knn_keys(const uint8_t* db_desc, uint64_t n_db, uint32_t desc_bytes, const uint8_t* q_desc,
                   uint32_t nq, uint32_t k, uint64_t* keys);

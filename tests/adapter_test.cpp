@@ -42,7 +42,46 @@ int main(int argc, char** argv) {
     for (const char* n : want_g_out) if (!go.has(n)) return 3;
     for (const char* n : want_g_par) if (!gp.has(n)) return 3;
     if (gp.get<unsigned int>("min_inliers") != 15u || gp.get<unsigned int>("n_ransac_iterations") != 1000u) return 3;
+    // stage A: the names detector.py:35-36,41,44,71-74,80-81 uses on ecto_opencv's FeatureDescriptor
+    ecto::tendrils fp, fi, fo;
+    tod_amd::FeatureDescriptor::declare_params(fp);
+    tod_amd::FeatureDescriptor::declare_io(fp, fi, fo);
+    if (!fp.has("json_feature_params") || !fp.has("json_descriptor_params") || !fi.has("image") || !fi.has("mask") ||
+        !fo.has("keypoints") || !fo.has("descriptors")) return 3;
     if (argc > 2) { std::cout << "declare ok\n"; return 0; }
+
+    // ---- stage A as conf/detection.ork:23-31 configures it (n_features reduced to the frame's 500), with and without a mask
+    {
+      fp["json_feature_params"] << std::string("{\"type\": \"ORB\", \"module\": \"ecto_opencv.features2d\", \"n_features\": 500, "
+                                               "\"n_levels\": 3, \"scale_factor\": 1.2}");
+      fp["json_descriptor_params"] << std::string("{\"type\": \"ORB\", \"module\": \"ecto_opencv.features2d\"}");
+      tod_amd::FeatureDescriptor feat;
+      feat.configure(fp, fi, fo);
+      std::vector<uint8_t> img = slurp<uint8_t>(dir + "/image.bin"), msk = slurp<uint8_t>(dir + "/mask.bin");
+      cv::Mat im(480, 640, CV_8U), mk(480, 640, CV_8U);
+      std::memcpy(im.ptr<uint8_t>(0), img.data(), img.size());
+      std::memcpy(mk.ptr<uint8_t>(0), msk.data(), msk.size());
+      for (int pass = 0; pass < 2; ++pass) {
+        fi["image"] << im;
+        fi["mask"] << (pass ? mk : cv::Mat());
+        if (feat.process(fi, fo) != ecto::OK) return 7;
+        const std::vector<cv::KeyPoint>& kps = fo.get<std::vector<cv::KeyPoint> >("keypoints");
+        const cv::Mat& d = fo.get<cv::Mat>("descriptors");
+        if ((int)kps.size() != d.rows || d.cols != 32) return 7;
+        std::vector<float> kpf;
+        for (const cv::KeyPoint& k : kps) { kpf.push_back(k.pt.x); kpf.push_back(k.pt.y); kpf.push_back(k.size); kpf.push_back(k.angle);
+                                            kpf.push_back(k.response); kpf.push_back((float)k.octave); }
+        std::vector<uint8_t> dv(d.ptr<uint8_t>(0), d.ptr<uint8_t>(0) + (size_t)d.rows * 32);
+        dump(dir + (pass ? "/out_orb_kp_masked.bin" : "/out_orb_kp.bin"), kpf);
+        dump(dir + (pass ? "/out_orb_desc_masked.bin" : "/out_orb_desc.bin"), dv);
+      }
+      ecto::tendrils badp;
+      tod_amd::FeatureDescriptor::declare_params(badp);
+      badp["json_feature_params"] << std::string("{\"type\": \"SIFT\"}");
+      bool threw = false;
+      try { tod_amd::FeatureDescriptor f2; f2.configure(badp, fi, fo); } catch (const std::exception&) { threw = true; }
+      if (!threw) return 8;
+    }
 
     // ---- configure as conf/detection.ork:32-42 would
     mp["search_json_params"] << std::string("{\"type\": \"LSH\", \"module\": \"ecto_opencv.features2d\", \"key_size\": 16, "

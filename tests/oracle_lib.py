@@ -67,6 +67,7 @@ def lib():
     L.orc_cluster_consensus.restype = C.c_uint32
     L.orc_cluster_ransac.restype = C.c_uint32
     L.orc_match.restype = C.c_int
+    L.orc_match_ratio.restype = C.c_int
     L.orc_verify.restype = C.c_int
     L.orc_cluster_kabsch.restype = C.c_int
     L.orb_detect.restype = C.c_uint32
@@ -105,7 +106,7 @@ def knn_keys(db, q, k):
     return keys
 
 
-def match(db, obj_off, db_pts, q, k, radius):
+def match(db, obj_off, db_pts, q, k, radius, ratio=0.0):
     db = np.ascontiguousarray(db, np.uint8)
     q = np.ascontiguousarray(q, np.uint8)
     obj_off = np.ascontiguousarray(obj_off, np.uint32)
@@ -114,10 +115,10 @@ def match(db, obj_off, db_pts, q, k, radius):
     row_ptr = np.zeros(nq + 1, np.uint32)
     m = np.zeros(nq * k, DMATCH_DTYPE)
     xyz = np.zeros((nq * k, 3), np.float32)
-    rc = lib().orc_match(_p(db, C.c_uint8), _p(obj_off, C.c_uint32), C.c_uint32(len(obj_off) - 1),
-                         _p(db_pts, C.c_float), C.c_uint32(db.shape[1]), _p(q, C.c_uint8), C.c_uint32(nq),
-                         C.c_uint32(k), C.c_uint32(radius), _p(row_ptr, C.c_uint32),
-                         m.ctypes.data_as(C.c_void_p), _p(xyz, C.c_float))
+    rc = lib().orc_match_ratio(_p(db, C.c_uint8), _p(obj_off, C.c_uint32), C.c_uint32(len(obj_off) - 1),
+                               _p(db_pts, C.c_float), C.c_uint32(db.shape[1]), _p(q, C.c_uint8), C.c_uint32(nq),
+                               C.c_uint32(k), C.c_uint32(radius), C.c_float(ratio), _p(row_ptr, C.c_uint32),
+                               m.ctypes.data_as(C.c_void_p), _p(xyz, C.c_float))
     n = int(row_ptr[nq])
     return rc, row_ptr, m[:n].copy(), xyz[:n].copy()
 

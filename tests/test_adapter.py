@@ -32,12 +32,16 @@ def test_adapter_frame_equals_c_abi():
         _build()
     desc, pts, off = synth.make_db_ragged([3000, 10, 2500], seed=5)
     fr = synth.make_frame(desc, pts, off, 500, frame=3, visible_object=2)
+    image = synth.make_image(11)
+    mask = np.zeros((480, 640), np.uint8); mask[100:400, 150:500] = 255
     with tempfile.TemporaryDirectory() as d:
         for name, arr in (("desc", desc), ("pts", pts), ("obj_off", off.astype(np.uint32)), ("q_desc", fr["q_desc"]),
-                          ("kp_xy", fr["kp_xy"]), ("cloud", fr["cloud"])):
+                          ("kp_xy", fr["kp_xy"]), ("cloud", fr["cloud"]), ("image", image), ("mask", mask)):
             np.ascontiguousarray(arr).tofile(os.path.join(d, name + ".bin"))
         out = subprocess.run([EXE, d], capture_output=True, text=True)
         assert out.returncode == 0, out.stdout + out.stderr
+        orb_out = {tag: (np.fromfile(os.path.join(d, "out_orb_kp%s.bin" % tag), np.float32).reshape(-1, 6),
+                         np.fromfile(os.path.join(d, "out_orb_desc%s.bin" % tag), np.uint8).reshape(-1, 32)) for tag in ("", "_masked")}
         m = np.fromfile(os.path.join(d, "out_matches.bin"), np.int32).reshape(-1, 3)
         dist = np.fromfile(os.path.join(d, "out_dist.bin"), np.float32)
         rt = np.fromfile(os.path.join(d, "out_poses.bin"), np.float32).reshape(-1, 12)
@@ -53,4 +57,12 @@ def test_adapter_frame_equals_c_abi():
     assert np.array_equal(rt[0, :9].reshape(3, 3), poses[0]["R"]) and np.array_equal(rt[0, 9:], poses[0]["t"])
     assert inl[0] == poses[0]["object"] == 2 and inl[1] == len(poses[0]["inliers"])
     assert np.array_equal(inl[2:], poses[0]["inliers"])
+    # the FeatureDescriptor cell == the C ABI's ORB, with and without the cell's mask input
+    for tag, mk in (("", None), ("_masked", mask)):
+        kp, aux, de = ctx.orb(image, 500, 3, 1.2, mask=mk)
+        kpf, dd = orb_out[tag]
+        assert len(kp) == len(kpf) > 100 and np.array_equal(kpf[:, :2], kp) and np.array_equal(kpf[:, 2:], aux) and np.array_equal(dd, de)
+        if mk is not None:
+            l0 = aux[:, 3] == 0
+            assert (mask[kp[l0, 1].astype(int), kp[l0, 0].astype(int)] != 0).all()
     ctx.close()

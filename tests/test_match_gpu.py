@@ -360,3 +360,60 @@ def test_c3_partition_1m_rows_8_shards_equals_unsharded(ctx):
     for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
         assert np.array_equal(ms[f], m[f]), f
     assert np.array_equal(xyzs, xyz)
+
+
+@pytest.mark.parametrize("k", [1, 2, 5])
+@pytest.mark.parametrize("ratio", [0.6, 0.8, 1.0])
+def test_ratio_test_equals_its_definition(ctx, k, ratio):
+    """N4: Lowe's ratio test on the two exact nearest neighbours (the block DescriptorMatcher.cpp:223-227 leaves empty),
+    defined by orc_match_ratio -- parity unpinned by construction. Duplicated DB rows make d1 == d2 (ratio 1.0 must still
+    reject them: the test is strict), k = 1 needs the second neighbour internally, and the radius applies afterwards."""
+    desc, pts, off = synth.make_db_ragged([1500, 40, 900], seed=31)
+    desc[2000] = desc[10]                                              # two identical rows: d1 == d2 for their queries
+    fr = synth.make_frame(desc, pts, off, 300, frame=3, visible_object=0, flip_p=0.10)
+    q = fr["q_desc"]
+    q[0] = desc[10]
+    ctx.db_load(desc, pts, off)
+    ctx.set_ratio_test(ratio)
+    try:
+        for radius in (30, 60, 255):
+            row_ptr, m, xyz = ctx.match(q, k, radius)
+            rc, o_row_ptr, o_m, o_xyz = O.match(desc, off, pts, q, k, radius, ratio)
+            assert rc == 0 and np.array_equal(row_ptr, o_row_ptr) and np.array_equal(xyz, o_xyz)
+            for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
+                assert np.array_equal(m[f], o_m[f]), f
+            assert row_ptr[1] == row_ptr[0]                            # query 0 has two neighbours at distance 0: ambiguous
+        plain = O.match(desc, off, pts, q, k, 255, 0.0)[1]               # (o_row_ptr is the radius-255 pass of the loop)
+        assert int(o_row_ptr[-1]) < int(plain[-1])                       # the test removes something (query 0 at the least)
+    finally:
+        ctx.set_ratio_test(0.0)
+
+
+def test_ratio_test_sharded_equals_unsharded(ctx):
+    desc, pts, off = synth.make_db_ragged([900, 50, 0, 1200, 700, 5, 333, 2000, 41, 800], seed=77)
+    fr = synth.make_frame(desc, pts, off, 400, frame=8, visible_object=3, flip_p=0.10)
+    import torch
+    nq, k, radius, n_shards = 400, 2, 55, 3
+    d_q = torch.from_numpy(fr["q_desc"]).cuda()
+    keys_all = torch.empty((n_shards, nq, k), dtype=torch.int64, device="cuda")
+    ctxs = []
+    for s in range(n_shards):
+        c = capi.Context(0); c.set_matcher_engine(ENGINE["name"]); c.set_ratio_test(0.8)
+        c.db_load(desc, pts, off, shard_rank=s, shard_count=n_shards)
+        c.match_shard_device(d_q.data_ptr(), nq, k, radius, keys_all[s].data_ptr()); c.synchronize()
+        ctxs.append(c)
+    counts = torch.zeros(nq, dtype=torch.int32, device="cuda"); mm = torch.zeros((nq * k, 4), dtype=torch.int32, device="cuda")
+    xx = torch.zeros((nq * k, 3), dtype=torch.float32, device="cuda")
+    ctxs[0].merge_shards_device(keys_all.data_ptr(), n_shards, nq, k, radius, counts.data_ptr(), mm.data_ptr(), xx.data_ptr())
+    ctxs[0].synchronize()
+    with pytest.raises(capi.TodError):
+        ctxs[0].match_shard_device(d_q.data_ptr(), nq, 1, radius, keys_all[0].data_ptr())   # k = 1 cannot carry the second neighbour
+    for c in ctxs:
+        c.close()
+    rc, o_row_ptr, o_m, o_xyz = O.match(desc, off, pts, fr["q_desc"], k, radius, 0.8)
+    cnt = counts.cpu().numpy()
+    assert np.array_equal(cnt, np.diff(o_row_ptr.astype(np.int64)))
+    keep = np.arange(k)[None, :] < cnt[:, None]
+    m = mm.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(nq, k)[keep]
+    for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
+        assert np.array_equal(m[f], o_m[f]), f

@@ -104,3 +104,23 @@ def test_c5_shape_batch_of_1080p_frames_orb2000(ctx):
         o_kp, o_aux, o_desc, _ = O.orb(imgs[f], 2000, 3, 1.2)
         assert np.array_equal(kp[f].cpu().numpy(), o_kp) and np.array_equal(desc[f].cpu().numpy(), o_desc)
         assert np.array_equal(aux[f].cpu().numpy()[:, [0, 2, 3]], o_aux[:, [0, 2, 3]])
+
+
+def test_masked_orb_equals_cpu_restatement():
+    """todhip_orb_masked (the FeatureDescriptor cell's `mask` input, detector.py:41): keypoints only where mask != 0,
+    bit-identical to the CPU restatement with the same mask (parity with cv::ORB unpinned, as for the unmasked form)."""
+    ctx = capi.Context(0)
+    img = synth.make_image(5)
+    mask = np.zeros(img.shape, np.uint8)
+    mask[60:420, 90:560] = 255
+    mask[200:260, 300:380] = 0                                          # a hole
+    kp, aux, d = ctx.orb(img, 800, 3, 1.2, mask=mask)
+    o_kp, o_aux, o_d, _ = O.orb(img, 800, 3, 1.2, mask=mask)
+    assert len(kp) == len(o_kp) > 300
+    assert np.array_equal(kp, o_kp) and np.array_equal(d, o_d)
+    assert np.array_equal(aux[:, [0, 2, 3]], o_aux[:, [0, 2, 3]])     # size, Harris response, octave: bit-exact
+    da = np.abs(aux[:, 1] - o_aux[:, 1])
+    assert np.minimum(da, 360.0 - da).max() < 1e-2                     # the angle in degrees goes through atan2f (device libm)
+    l0 = aux[:, 3] == 0                                                 # level-0 keypoints sit on the pixel the mask was sampled at
+    assert l0.sum() > 100 and (mask[kp[l0, 1].astype(int), kp[l0, 0].astype(int)] != 0).all()
+    ctx.close()

@@ -52,9 +52,9 @@ class Counters(C.Structure):
 # every symbol include/todhip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "todhip_version", "todhip_create", "todhip_destroy", "todhip_stream", "todhip_last_hip_error",
-    "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_db_load", "todhip_db_info",
+    "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_set_ratio_test", "todhip_db_load", "todhip_db_info",
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device", "todhip_merge_shards_device_on",
-    "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_test_clique",
+    "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_orb_masked", "todhip_test_clique",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
     "todhip_orb_device", "todhip_verify_device_depth", "todhip_orb_batch_device",
     "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
@@ -143,6 +143,10 @@ class Context:
         """0 auto, 1 vector ALU (K4), 2 matrix cores (K4x): identical results"""
         _check(lib().todhip_set_matcher_engine(self._h, C.c_int({"auto": 0, "valu": 1, "mfma": 2}.get(engine, engine))),
                "todhip_set_matcher_engine")
+
+    def set_ratio_test(self, ratio):
+        """Lowe's ratio test on the two nearest neighbours (0 = off, the reference's effective setting)"""
+        _check(lib().todhip_set_ratio_test(self._h, C.c_float(ratio)), "todhip_set_ratio_test")
 
     def set_kernel_timing(self, enable):
         _check(lib().todhip_set_kernel_timing(self._h, C.c_int(1 if enable else 0)), "todhip_set_kernel_timing")
@@ -383,19 +387,20 @@ class Context:
         return int(out[0]), int(out[1]), int(out[2])
 
     # ---------------------------------------------------------------- stage A
-    def orb(self, gray, n_features=1000, n_levels=3, scale_factor=1.2, pattern=None):
+    def orb(self, gray, n_features=1000, n_levels=3, scale_factor=1.2, pattern=None, mask=None):
         g = np.ascontiguousarray(gray, np.uint8)
+        mk = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         H, W = g.shape
         kp = np.zeros((n_features, 2), np.float32)
         aux = np.zeros((n_features, 4), np.float32)
         desc = np.zeros((n_features, 32), np.uint8)
         n_out = C.c_uint32(n_features)
         pat = None if pattern is None else np.ascontiguousarray(pattern, np.int8)
-        rc = lib().todhip_orb(self._h, _np_ptr(g), C.c_uint32(H), C.c_uint32(W), C.c_uint32(W),
-                              C.c_uint32(n_features), C.c_uint32(n_levels), C.c_float(scale_factor),
-                              None if pat is None else _np_ptr(pat), _np_ptr(kp), _np_ptr(aux), _np_ptr(desc),
-                              C.byref(n_out))
-        _check(rc, "todhip_orb")
+        rc = lib().todhip_orb_masked(self._h, _np_ptr(g), None if mk is None else _np_ptr(mk), C.c_uint32(H), C.c_uint32(W),
+                                     C.c_uint32(W), C.c_uint32(n_features), C.c_uint32(n_levels), C.c_float(scale_factor),
+                                     None if pat is None else _np_ptr(pat), _np_ptr(kp), _np_ptr(aux), _np_ptr(desc),
+                                     C.byref(n_out))
+        _check(rc, "todhip_orb_masked")
         n = n_out.value
         return kp[:n].copy(), aux[:n].copy(), desc[:n].copy()
 

@@ -89,6 +89,12 @@ int todhip_set_matcher_engine(todhip_ctx* ctx, int engine) {
   return TODHIP_OK;
 }
 
+int todhip_set_ratio_test(todhip_ctx* ctx, float ratio) {
+  if (!ctx || !(ratio >= 0.f) || ratio > 1.f) return TODHIP_EINVAL;
+  ctx->ratio = ratio;
+  return TODHIP_OK;
+}
+
 // Object-aligned contiguous shards: object o belongs to the shard whose row range contains its first row
 // when the rows are cut into shard_count equal pieces (an object never straddles two devices).
 static void shard_bounds(const std::vector<uint32_t>& off, uint32_t n_objs, uint32_t rank, uint32_t count,
@@ -185,6 +191,7 @@ int todhip_db_info(const todhip_ctx* ctx, uint64_t* total_rows, uint64_t* shard_
 int todhip_match_shard_device(todhip_ctx* ctx, const void* d_q_desc, uint32_t nq, uint32_t k, uint32_t radius,
                               void* d_keys) {
   if (!ctx || !d_q_desc || !d_keys || k == 0 || k > 8 || radius == 0) return TODHIP_EINVAL;
+  if (ctx->ratio > 0.f && k < 2) return TODHIP_EINVAL;        // the ratio test needs every shard's two nearest
   if (ctx->total_rows == 0) return TODHIP_ENODB;
   return tod_match_shard_keys(ctx, d_q_desc, nq, k, radius, reinterpret_cast<uint64_t*>(d_keys));
 }
@@ -194,7 +201,8 @@ int todhip_merge_shards_device(todhip_ctx* ctx, const void* d_keys_all, uint32_t
   if (!ctx || !d_keys_all || !d_counts || !d_matches || !d_matches_xyz) return TODHIP_EINVAL;
   if (k == 0 || k > 8 || radius == 0 || n_shards == 0) return TODHIP_EINVAL;
   if (ctx->total_rows == 0) return TODHIP_ENODB;
-  return tod_match_finalize(ctx, reinterpret_cast<const uint64_t*>(d_keys_all), n_shards, nq, k, radius,
+  if (ctx->ratio > 0.f && k < 2) return TODHIP_EINVAL;
+  return tod_match_finalize(ctx, reinterpret_cast<const uint64_t*>(d_keys_all), n_shards, nq, k, k, radius,
                             reinterpret_cast<uint32_t*>(d_counts), reinterpret_cast<todhip_dmatch*>(d_matches),
                             reinterpret_cast<float*>(d_matches_xyz));
 }
@@ -204,7 +212,8 @@ int todhip_merge_shards_device_on(todhip_ctx* ctx, void* hip_stream, const void*
   if (!ctx || !hip_stream || !d_keys_all || !d_counts || !d_matches || !d_matches_xyz) return TODHIP_EINVAL;
   if (k == 0 || k > 8 || radius == 0 || n_shards == 0) return TODHIP_EINVAL;
   if (ctx->total_rows == 0) return TODHIP_ENODB;
-  return tod_match_finalize(ctx, reinterpret_cast<const uint64_t*>(d_keys_all), n_shards, nq, k, radius,
+  if (ctx->ratio > 0.f && k < 2) return TODHIP_EINVAL;
+  return tod_match_finalize(ctx, reinterpret_cast<const uint64_t*>(d_keys_all), n_shards, nq, k, k, radius,
                             reinterpret_cast<uint32_t*>(d_counts), reinterpret_cast<todhip_dmatch*>(d_matches),
                             reinterpret_cast<float*>(d_matches_xyz), reinterpret_cast<hipStream_t>(hip_stream));
 }
@@ -217,11 +226,12 @@ int todhip_match_device(todhip_ctx* ctx, const void* d_q_desc, uint32_t nq, uint
   if (ctx->shard_rows != ctx->total_rows) return TODHIP_EINVAL; // sharded DBs use the two-step form
   if (nq == 0) return TODHIP_OK;
   // single device: the stage-1 merge lists go straight into the finalize kernel (lists == "shards")
-  TOD_HIP(ctx->m_keys.reserve(tod_match_lists_bytes(nq, k)));
+  const uint32_t k_in = (ctx->ratio > 0.f && k < 2) ? 2u : k;          // the ratio test looks at the two nearest
+  TOD_HIP(ctx->m_keys.reserve(tod_match_lists_bytes(nq, k_in)));
   uint32_t n_lists = 0;
-  int rc = tod_match_lists(ctx, d_q_desc, nq, k, radius, ctx->m_keys.as<uint64_t>(), &n_lists);
+  int rc = tod_match_lists(ctx, d_q_desc, nq, k_in, radius, ctx->m_keys.as<uint64_t>(), &n_lists);
   if (rc != TODHIP_OK) return rc;
-  rc = tod_match_finalize(ctx, ctx->m_keys.as<uint64_t>(), n_lists, nq, k, radius,
+  rc = tod_match_finalize(ctx, ctx->m_keys.as<uint64_t>(), n_lists, nq, k_in, k, radius,
                           reinterpret_cast<uint32_t*>(d_counts), reinterpret_cast<todhip_dmatch*>(d_matches),
                           reinterpret_cast<float*>(d_matches_xyz));
   if (rc == TODHIP_OK) { ctx->counters.last_nq = nq; ctx->counters.last_k = k; }

@@ -97,6 +97,7 @@ struct todhip_ctx {
   uint64_t ev_head = 0, ev_tail = 0;   // pairs [ev_tail, ev_head) are recorded and not yet read
   todhip_counters counters = {};
   int matcher_engine = TODHIP_ENGINE_AUTO;   // todhip_set_matcher_engine
+  float ratio = 0.f;                         // todhip_set_ratio_test (0 = off)
 
   std::vector<todhip_round_trace> traces;
 
@@ -114,7 +115,8 @@ int tod_match_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, u
                     uint32_t* n_lists);
 size_t tod_match_lists_bytes(uint32_t nq, uint32_t k);
 int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint32_t radius, uint64_t* d_keys);
-int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
+// k_in: entries per list; k_out: matches per query in the outputs (k_in > k_out only for the ratio test with k == 1)
+int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k_in, uint32_t k_out,
                        uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz,
                        hipStream_t stream = nullptr);   // nullptr: the context's stream
 // verify.hip / orb.hip

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void select_keys_kernel(const uint64_t* __r
 // (DescriptorMatcher.cpp:212-220), map the global row to (imgIdx, trainIdx) through the object prefix
 // sums (DB load order, :60-129) and gather the model point of every kept match (:231-244).
 __global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __restrict__ keys_all, uint32_t n_shards,
-                                                          uint32_t nq, uint32_t k, uint32_t radius,
+                                                          uint32_t nq, uint32_t k_in, uint32_t k_out, uint32_t radius, float ratio,
                                                           const uint32_t* __restrict__ obj_off, uint32_t n_objs,
                                                           const float* __restrict__ pts,
                                                           uint32_t* __restrict__ counts,
@@ -593,16 +593,18 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __rest
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
   if (qi >= nq) return;
-  uint32_t kept = 0;
+  // the k_out (for the ratio test: at least 2) smallest keys over all lists: every list is ascending and keys are unique
+  // (the row is part of the key), so each list's candidate is its first key greater than the last one taken
+  uint64_t picked[9];
+  const uint32_t want = ratio > 0.f ? max(k_out, 2u) : k_out;
+  uint32_t n_picked = 0;
   uint64_t last = 0;
   bool have_last = false;
-  for (uint32_t j = 0; j < k; ++j) {
-    // next key after `last`: every shard list is ascending and keys are unique (the row is part of the key),
-    // so each shard's candidate is its first key greater than `last`
+  for (uint32_t j = 0; j < want; ++j) {
     uint64_t nxt = ~0ull;
     for (uint32_t s = 0; s < n_shards; ++s) {
-      const uint64_t* lst = keys_all + ((size_t)s * nq + qi) * k;
-      for (uint32_t i = 0; i < k; ++i) {
+      const uint64_t* lst = keys_all + ((size_t)s * nq + qi) * k_in;
+      for (uint32_t i = 0; i < k_in; ++i) {
         uint64_t v = lst[i];
         if (have_last && v <= last) continue;
         if (v < nxt) nxt = v;
@@ -612,9 +614,16 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __rest
     if (nxt == ~0ull) break;
     last = nxt;
     have_last = true;
-    const uint32_t d = (uint32_t)(nxt >> 32);
-    if ((float)d > (float)radius) break;
-    const uint32_t row = (uint32_t)nxt;
+    picked[n_picked++] = nxt;
+  }
+  // Lowe's ratio test on the two nearest neighbours (the block the reference leaves empty, DescriptorMatcher.cpp:223-227;
+  // definition: include/todhip.h, todhip_set_ratio_test): an ambiguous query keeps nothing
+  if (ratio > 0.f && n_picked >= 2u && !((float)(uint32_t)(picked[0] >> 32) < ratio * (float)(uint32_t)(picked[1] >> 32))) n_picked = 0;
+  uint32_t kept = 0;
+  for (uint32_t j = 0; j < n_picked && j < k_out; ++j) {
+    const uint32_t d = (uint32_t)(picked[j] >> 32);
+    if ((float)d > (float)radius) break;                    // radius truncation, :212-220 (float vs unsigned compare)
+    const uint32_t row = (uint32_t)picked[j];
     uint32_t lo = 0, hi = n_objs;            // last object whose first row is <= row
     while (hi - lo > 1) {
       uint32_t mid = (lo + hi) >> 1;
@@ -625,8 +634,8 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const uint64_t* __rest
     m.trainIdx = (int32_t)(row - obj_off[lo]);
     m.imgIdx = (int32_t)lo;
     m.distance = (float)d;
-    matches[(size_t)qi * k + kept] = m;
-    float* o = xyz + ((size_t)qi * k + kept) * 3;
+    matches[(size_t)qi * k_out + kept] = m;
+    float* o = xyz + ((size_t)qi * k_out + kept) * 3;
     o[0] = pts[(size_t)row * 3 + 0];
     o[1] = pts[(size_t)row * 3 + 1];
     o[2] = pts[(size_t)row * 3 + 2];
@@ -815,6 +824,7 @@ int tod_timing_end(todhip_ctx* ctx, int slot) {
 int tod_match_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint32_t radius, uint64_t* d_lists,
                     uint32_t* n_lists) {
   if (ctx->desc_bytes != 32) return TODHIP_EINVAL;
+  if (ctx->ratio > 0.f) radius = 256u;   // the ratio test needs the true second neighbour, however far: no radius bound in the search
   const uint32_t* q = reinterpret_cast<const uint32_t*>(d_q);
   switch (k) {
     case 1: return launch_topk<1>(ctx, q, nq, radius, d_lists, n_lists);
@@ -847,12 +857,12 @@ int tod_match_shard_keys(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t
   return TODHIP_OK;
 }
 
-int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k,
+int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_shards, uint32_t nq, uint32_t k_in, uint32_t k_out,
                        uint32_t radius, uint32_t* d_counts, todhip_dmatch* d_matches, float* d_xyz, hipStream_t stream) {
   if (nq == 0) return TODHIP_OK;
   const uint32_t blocks = (nq + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(kBlock), 0, stream ? stream : ctx->stream, d_keys_all, n_shards, nq, k, radius,
-                     ctx->db_obj_off.as<uint32_t>(), ctx->n_objs, ctx->db_pts.as<float>(), d_counts, d_matches,
+  hipLaunchKernelGGL(finalize_kernel, dim3(blocks), dim3(kBlock), 0, stream ? stream : ctx->stream, d_keys_all, n_shards, nq, k_in, k_out,
+                     radius, ctx->ratio, ctx->db_obj_off.as<uint32_t>(), ctx->n_objs, ctx->db_pts.as<float>(), d_counts, d_matches,
                      d_xyz);
   TOD_HIP(hipGetLastError());
   return TODHIP_OK;

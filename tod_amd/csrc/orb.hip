@@ -625,20 +625,28 @@ int todhip_orb_batch_device(todhip_ctx* ctx, const void* d_gray, uint32_t n_fram
                     reinterpret_cast<uint8_t*>(d_desc), cap, n_out);
 }
 
-int todhip_orb(todhip_ctx* ctx, const uint8_t* gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
-               uint32_t n_levels, float scale_factor, const int8_t* pattern, float* kp_xy, float* kp_aux, uint8_t* desc,
-               uint32_t* n_out) {
+int todhip_orb_masked(todhip_ctx* ctx, const uint8_t* gray, const uint8_t* mask, uint32_t H, uint32_t W, uint32_t stride,
+                      uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern, float* kp_xy, float* kp_aux,
+                      uint8_t* desc, uint32_t* n_out) {
   if (!ctx || !gray || !kp_xy || !kp_aux || !desc || !n_out || stride < W) return TODHIP_EINVAL;
   TOD_HIP(hipSetDevice(ctx->device));
   OrbWs* ws = ows_of(ctx);
   const uint32_t cap = *n_out;
   *n_out = 0;
   if (cap == 0) return TODHIP_ECAPACITY;
-  TOD_HIP(ws->in_img.reserve((size_t)H * stride));
+  const size_t img_bytes = (size_t)H * stride;
+  TOD_HIP(ws->in_img.reserve(mask ? 2 * img_bytes : img_bytes));       // the mask rides behind the image
   TOD_HIP(ws->kp_xy.reserve((size_t)cap * 8)); TOD_HIP(ws->kp_aux.reserve((size_t)cap * 16)); TOD_HIP(ws->desc.reserve((size_t)cap * 32));
-  TOD_HIP(hipMemcpyAsync(ws->in_img.p, gray, (size_t)H * stride, hipMemcpyHostToDevice, ctx->stream));
+  TOD_HIP(hipMemcpyAsync(ws->in_img.p, gray, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+  const uint8_t* d_mask = nullptr;
+  if (mask) {
+    // orb_device reads the mask with row pitch W: repack rows when the caller's stride is larger
+    uint8_t* dm = ws->in_img.as<uint8_t>() + img_bytes;
+    TOD_HIP(hipMemcpy2DAsync(dm, W, mask, stride, W, H, hipMemcpyHostToDevice, ctx->stream));
+    d_mask = dm;
+  }
   uint32_t n = 0;
-  const int rc = orb_device(ctx, ws->in_img.as<uint8_t>(), 0, nullptr, 1, H, W, stride, n_features, n_levels, scale_factor, pattern,
+  const int rc = orb_device(ctx, ws->in_img.as<uint8_t>(), 0, d_mask, 1, H, W, stride, n_features, n_levels, scale_factor, pattern,
                             ws->kp_xy.as<float>(), ws->kp_aux.as<float>(), ws->desc.as<uint8_t>(), cap, &n);
   if (rc != TODHIP_OK) return rc;
   if (n) {
@@ -649,6 +657,12 @@ int todhip_orb(todhip_ctx* ctx, const uint8_t* gray, uint32_t H, uint32_t W, uin
   }
   *n_out = n;
   return TODHIP_OK;
+}
+
+int todhip_orb(todhip_ctx* ctx, const uint8_t* gray, uint32_t H, uint32_t W, uint32_t stride, uint32_t n_features,
+               uint32_t n_levels, float scale_factor, const int8_t* pattern, float* kp_xy, float* kp_aux, uint8_t* desc,
+               uint32_t* n_out) {
+  return todhip_orb_masked(ctx, gray, nullptr, H, W, stride, n_features, n_levels, scale_factor, pattern, kp_xy, kp_aux, desc, n_out);
 }
 
 }  // extern "C"

@@ -490,12 +490,17 @@ __device__ __forceinline__ void degrees_in_list(const GateLds& L, const uint16_t
 // A second register set serves classes 64..127 once the first 64 are in use; with more than 128 classes the caller falls
 // back to the generic class-by-class loop. Output as ColorSort's: the list regrouped by class (each class in list order),
 // C[position] = class.
-template <uint32_t MWT>
+// WIDE = false: classes 0..63 only (one register set); returns false as soon as a vertex finds all 64 taken, and the caller
+// starts over with WIDE = true (two sets, 128 classes). Lists that need more than 64 classes are rare (dense graphs of
+// several hundred vertices), so the common loop carries no second set and no range checks.
+template <uint32_t MWT, bool WIDE>
 __device__ __forceinline__ bool colour_first_fit(const GateLds& L, uint16_t* list, uint32_t r) {
   const uint32_t l = lane_id();
-  u64 cls0[MWT], cls1[MWT];
+  u64 cls0[MWT], cls1[WIDE ? MWT : 1];
 #pragma unroll
-  for (uint32_t w = 0; w < MWT; ++w) { cls0[w] = 0ull; cls1[w] = 0ull; }
+  for (uint32_t w = 0; w < MWT; ++w) cls0[w] = 0ull;
+#pragma unroll
+  for (uint32_t w = 0; w < (WIDE ? MWT : 1); ++w) cls1[w] = 0ull;
   uint32_t cnt0 = 0u, cnt1 = 0u;                           // members of class l / class 64 + l so far
   bool wide = false, overflow = false;                     // wave-uniform
   for (uint32_t c0 = 0; c0 < r; c0 += 64u) {
@@ -514,35 +519,40 @@ __device__ __forceinline__ bool colour_first_fit(const GateLds& L, uint16_t* lis
 #pragma unroll
       for (uint32_t w = 0; w < MWT; ++w) hit |= row[w] & cls0[w];
       const u64 free0 = __ballot(hit == 0ull);
-      uint32_t k;
+      uint32_t k = 0u;
+      bool second = false;
       if (free0 != 0ull) {
         k = (uint32_t)__ffsll((long long)free0) - 1u;
-      } else {
-        wide = true;
+      } else if (WIDE) {
+        wide = true; second = true;
         u64 hit1 = 0ull;
 #pragma unroll
-        for (uint32_t w = 0; w < MWT; ++w) hit1 |= row[w] & cls1[w];
+        for (uint32_t w = 0; w < (WIDE ? MWT : 1); ++w) hit1 |= row[w] & cls1[w];
         const u64 free1 = __ballot(hit1 == 0ull);
-        if (free1 == 0ull) { overflow = true; k = 127u; } else k = 64u + (uint32_t)__ffsll((long long)free1) - 1u;
+        if (free1 == 0ull) overflow = true; else k = (uint32_t)__ffsll((long long)free1) - 1u;
+      } else {
+        overflow = true;
       }
-      // vertex v joins class k: only lane k (mod 64) executes the update; which register pair receives the bit is decided
-      // on the scalar side (v is wave-uniform), so the arrays are only ever indexed statically and stay in registers
-      const bool mine = l == (k & 63u);
-      const u64 bit = 1ull << (v & 63u);
+      // vertex v joins class k (of the first or second set): only lane k executes the update; which register pair receives
+      // the bit is a scalar branch on the (wave-uniform) word index, so the arrays are only ever indexed statically and stay
+      // in registers, and one word is touched instead of all of them
       const uint32_t vw = v >> 6;
-      const uint32_t idx = k < 64u ? rdlane(cnt0, k & 63u) : rdlane(cnt1, k & 63u);
-      if (mine) {
-        if (k < 64u) {
+      const u64 bit = 1ull << (v & 63u);
+      const uint32_t idx = second ? rdlane(cnt1, k) : rdlane(cnt0, k);
+      if (l == k) {
+        if (!second) {
+          cnt0 += 1u;
 #pragma unroll
-          for (uint32_t w = 0; w < MWT; ++w) cls0[w] |= (vw == w) ? bit : 0ull;
-        } else {
+          for (uint32_t w = 0; w < MWT; ++w)
+            if (vw == w) { cls0[w] |= bit; asm volatile("" ::: "memory"); }   // (the empty asm keeps this a branch, not MWT selects)
+        } else if (WIDE) {
+          cnt1 += 1u;
 #pragma unroll
-          for (uint32_t w = 0; w < MWT; ++w) cls1[w] |= (vw == w) ? bit : 0ull;
+          for (uint32_t w = 0; w < (WIDE ? MWT : 1); ++w)
+            if (vw == w) { cls1[w] |= bit; asm volatile("" ::: "memory"); }
         }
       }
-      cnt0 += (mine && k < 64u) ? 1u : 0u;                  // (branch-free: a merged store through a selected address would
-      cnt1 += (mine && k >= 64u) ? 1u : 0u;                 //  put both counters into scratch memory)
-      if (l == li) rec = (k << 16) | idx;
+      if (l == li) rec = ((second ? k + 64u : k) << 16) | idx;
     };
     u64 rowA[MWT], rowB[MWT];
     {
@@ -551,14 +561,14 @@ __device__ __forceinline__ bool colour_first_fit(const GateLds& L, uint16_t* lis
       for (uint32_t w = 0; w < MWT; ++w) rowA[w] = g[w];
     }
     uint32_t li = 0;
-    for (; li + 2u <= cnt; li += 2u) {                     // two vertices per trip: the row buffers swap roles, nothing is copied
+    for (; li + 2u <= cnt && !overflow; li += 2u) {        // two vertices per trip: the row buffers swap roles, nothing is copied
       place(rowA, rowB, li);
       place(rowB, rowA, li + 1u);
     }
-    if (li < cnt) place(rowA, rowB, li);
+    if (li < cnt && !overflow) place(rowA, rowB, li);
+    if (overflow) return false;                            // nothing has been written to the list or to C
     if (c0 + l < r) L.keys[c0 + l] = rec;
   }
-  if (overflow) return false;                              // > 128 classes: the list itself is untouched
   // class c's block starts after all smaller classes: exclusive prefix of the class sizes over the lanes
   const uint32_t incl0 = wave_incl_scan(cnt0), total0 = uni(__shfl(incl0, 63));
   const uint32_t base0 = incl0 - cnt0;
@@ -606,14 +616,14 @@ __device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, ui
   if (MW <= 8u) {                                          // graphs of up to 512 vertices: one lane per colour class
     bool done = false;
     switch (MW) {                                          // wave-uniform
-      case 1: done = colour_first_fit<1>(L, list, r); break;
-      case 2: done = colour_first_fit<2>(L, list, r); break;
-      case 3: done = colour_first_fit<3>(L, list, r); break;
-      case 4: done = colour_first_fit<4>(L, list, r); break;
-      case 5: done = colour_first_fit<5>(L, list, r); break;
-      case 6: done = colour_first_fit<6>(L, list, r); break;
-      case 7: done = colour_first_fit<7>(L, list, r); break;
-      default: done = colour_first_fit<8>(L, list, r); break;
+      case 1: done = colour_first_fit<1, false>(L, list, r) || colour_first_fit<1, true>(L, list, r); break;
+      case 2: done = colour_first_fit<2, false>(L, list, r) || colour_first_fit<2, true>(L, list, r); break;
+      case 3: done = colour_first_fit<3, false>(L, list, r) || colour_first_fit<3, true>(L, list, r); break;
+      case 4: done = colour_first_fit<4, false>(L, list, r) || colour_first_fit<4, true>(L, list, r); break;
+      case 5: done = colour_first_fit<5, false>(L, list, r) || colour_first_fit<5, true>(L, list, r); break;
+      case 6: done = colour_first_fit<6, false>(L, list, r) || colour_first_fit<6, true>(L, list, r); break;
+      case 7: done = colour_first_fit<7, false>(L, list, r) || colour_first_fit<7, true>(L, list, r); break;
+      default: done = colour_first_fit<8, false>(L, list, r) || colour_first_fit<8, true>(L, list, r); break;
     }
     if (done) return;                                      // else: more than 128 classes -> the generic loop below
   }
@@ -677,22 +687,21 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
   uint32_t pf_isect = 0, pf_sort = 0, pf_col = 0, pf_vfull = 0, pf_big = 0, pf_vbig = 0;
   uint16_t* cur = L.cur;
   uint16_t* nxt = L.nxt;
-  bool reload = false;
-  // entry of level 1: QMax is empty; S[1] = S[1] + S[0] - SOld[1] = 0, SOld[1] = S[0] = 0  (:300-301)
+  // The current level's frame -- list size, S[level], and where its list sits on the stack -- lives in scalar registers;
+  // the LDS arrays are only touched when the level changes, and then all of a frame's words come back in ONE LDS round trip
+  // (S, SOld, lbase, lsize, lcap are consecutive arrays of `ma` words: lane j reads array j at [level]). A lone wave pays
+  // ~130 cycles per dependent LDS read, and the per-word form of this bookkeeping cost a dozen of them per step.
+  const uint32_t ma = (m + 7u) & ~3u;
+  auto frame_word = [&](uint32_t lvl) -> uint32_t { return l < 5u ? (L.S + (size_t)l * ma)[lvl] : 0u; };
+  uint32_t sz = m, S_cur = 0u, base_cur = 0u, cap_cur = m;     // level 1: S[1] = S[1] + S[0] - SOld[1] = 0, SOld[1] = S[0] = 0 (:300-301)
   while (true) {
-    const uint32_t sz = uni(L.lsize[level]);
-    if (reload) {
-      const uint32_t b = uni(L.lbase[level]);
-      for (uint32_t i = l; i < sz; i += 64u) cur[i] = stk_get(stack, b + i);
-      __syncthreads();
-      reload = false;
-    }
     bool ret = false;
     if (sz == 0u) {
       ret = true;                                          // while (!R.empty()) falls through, function returns
     } else {
-      const uint32_t p = uni(cur[sz - 1u]);
-      const uint32_t c = uni(top > 0u ? L.C[top - 1u] : 0u);   // C.back(), decision D3
+      const uint32_t pv = cur[sz - 1u];
+      const uint32_t cv = top > 0u ? L.C[top - 1u] : 0u;   // C.back(), decision D3
+      const uint32_t p = uni(pv), c = uni(cv);
       if (qsz + c > qmax) {                                // :307
         ++qsz;                                             // Q.push_back(p)
         // Intersection(p, R, Rp), :209-217 -- order preserving compaction
@@ -715,7 +724,7 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
         if (rp > 0u) {
           // :313 is (double)S[level] / all_steps_ < 0.025. With all_steps <= 100001 a quotient other than 1/40
           // differs from 1/40 by more than 1e-7, and 1/40 itself rounds to the literal: the test is 40 S < all_steps
-          if ((uint64_t)uni(L.S[level]) * 40ull < (uint64_t)all_steps) {
+          if ((uint64_t)S_cur * 40ull < (uint64_t)all_steps) {
             degrees_in_list(L, nxt, rp, MW);
             rank_sort_desc(nxt, L.tmp, L.deg, rp, L.keys);
           }
@@ -727,27 +736,29 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
             pf_col += dt;
             if ((int)qmax - (int)qsz + 1 < 2) { pf_vfull += rp; if (rp > 64u) { pf_big += dt; pf_vbig += rp; } }
           }
-          if (l == 0) L.S[level] += 1u;
+          S_cur += 1u;
           ++all_steps;
-          __syncthreads();
           if (all_steps > kStepCap) {
             ret = true;                                    // :318-319: returns without popping Q
           } else {
-            const uint32_t nb = uni(L.lbase[level]) + uni(L.lcap[level]);
+            const uint32_t nb = base_cur + cap_cur;
             if (nb + rp > stack_cap) { *err = 1; break; }
             for (uint32_t i = l; i < rp; i += 64u) stk_put(stack, nb + i, nxt[i]);
+            // leave this level: its frame goes to LDS; read the child's S / SOld in the same round trip
+            const uint32_t child = frame_word(level + 1u);
+            if (l == 0) { L.S[level] = S_cur; L.lsize[level] = sz; L.lbase[level] = base_cur; L.lcap[level] = cap_cur; }
+            const uint32_t s_child = rdlane(child, 0u), sold_child = rdlane(child, 1u);
             ++level;
-            if (l == 0) { L.lbase[level] = nb; L.lsize[level] = rp; L.lcap[level] = rp; }
-            uint16_t* t = cur; cur = nxt; nxt = t;
-            __syncthreads();
-            if (qmax >= minimal_size) {                    // :290-291 at the entry of the child
+            { uint16_t* t = cur; cur = nxt; nxt = t; }
+            if (qmax >= minimal_size) {                    // :290-291 at the entry of the child: it returns at once; its S and
+              // SOld stay as they were. Its frame must still be readable when the common return path below stores S
+              if (l == 0) L.S[level] = s_child;
+              S_cur = s_child; sz = rp; base_cur = nb; cap_cur = rp;
               ret = true;
             } else {
-              if (l == 0) {                                // :300-301
-                const uint32_t sprev = L.S[level - 1u];
-                L.S[level] = L.S[level] + sprev - L.SOld[level];
-                L.SOld[level] = sprev;
-              }
+              if (l == 0) L.SOld[level] = S_cur;           // :300-301: S[level] += S[level - 1] - SOld[level]; SOld[level] = S[level - 1]
+              S_cur = s_child + S_cur - sold_child;
+              sz = rp; base_cur = nb; cap_cur = rp;
               __syncthreads();
               continue;
             }
@@ -763,19 +774,21 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
         ret = true;                                        // :331-332
       }
       if (!ret) {                                          // R.pop_back(); C.pop_back(), :333-334
-        if (l == 0) L.lsize[level] = sz - 1u;
+        --sz;
         if (top > 0u) --top;
-        __syncthreads();
         continue;
       }
     }
     // the current level's function returns; its caller continues after the recursive call (:320)
     if (level == 1u) break;
+    if (l == 0) L.S[level] = S_cur;                        // a later sibling re-enters this level and reads it (:300)
     --level;
-    reload = true;
     --qsz;                                                 // Q.pop_back()
-    if (l == 0) L.lsize[level] -= 1u;                      // R.pop_back()
     if (top > 0u) --top;                                   // C.pop_back()
+    __syncthreads();
+    const uint32_t fw = frame_word(level);                 // S, -, lbase, lsize, lcap of the caller: one round trip
+    S_cur = rdlane(fw, 0u); base_cur = rdlane(fw, 2u); sz = rdlane(fw, 3u) - 1u; cap_cur = rdlane(fw, 4u);   // R.pop_back()
+    for (uint32_t i = l; i < sz; i += 64u) cur[i] = stk_get(stack, base_cur + i);
     __syncthreads();
   }
   if (steps_out) *steps_out = (uint32_t)all_steps;

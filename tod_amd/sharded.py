@@ -16,7 +16,7 @@ grows with the rank count.
 
 `ShardedMatcher` is the ONE implementation of steps 1-4's choreography: bench.py runs it on the GPU (GpuOps: torch
 streams/events, RCCL through torch.distributed, libtodhip for the compute) and tests/test_sharded_cpu.py runs the same
-class over gloo with the CPU oracle as the compute. With `overlap` the collectives and the merge have a stream of
+class over gloo with a CPU restatement as the compute. With `overlap` the collectives and the merge have a stream of
 their own, double buffered, so that the DB pass of step i + 1 follows that of step i without a gap:
 
   comm stream, identical on every rank:  gather(0), gather(1), exchange(0), merge(0), gather(2), exchange(1), merge(1), ...
