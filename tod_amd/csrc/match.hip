@@ -371,10 +371,15 @@ __device__ __forceinline__ void mfma_step(const Fp4Row& a, Fp4Row& a_next, const
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     if (t & 1) acc_odd = dot_block(a, qb[t]); else acc_even = dot_block(a, qb[t]);
-    if (t == 0) a_next.s[0] = expand_word(p_next.x, kc);
-    if (t == 1) a_next.s[1] = expand_word(p_next.y, kc);
-    if (t == 2) a_next.s[2] = expand_word(p_next.z, kc);
-    if (t == 3) a_next.s[3] = expand_word(p_next.w, kc);
+    if (QT >= 4) {
+      if (t == 0) a_next.s[0] = expand_word(p_next.x, kc);
+      if (t == 1) a_next.s[1] = expand_word(p_next.y, kc);
+      if (t == 2) a_next.s[2] = expand_word(p_next.z, kc);
+      if (t == 3) a_next.s[3] = expand_word(p_next.w, kc);
+    } else {                                             // two blocks per step: two words each
+      if (t == 0) { a_next.s[0] = expand_word(p_next.x, kc); a_next.s[1] = expand_word(p_next.y, kc); }
+      if (t == 1) { a_next.s[2] = expand_word(p_next.z, kc); a_next.s[3] = expand_word(p_next.w, kc); }
+    }
     if (t == 0) mfma_block_test<K, MASK, IMAX>(acc_odd, thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]);   // previous step's last block
     else mfma_block_test<K, MASK, IMAX>((t & 1) ? acc_even : acc_odd, thr[t - 1], r_lane, n_lim, best[t - 1]);
   }
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
                                                                uint32_t share_period,
                                                                uint32_t* __restrict__ part, uint32_t* bound,
                                                                uint8_t* __restrict__ stored) {
-  static_assert(QT % 2 == 0 && QT >= 4, "two query blocks share a 64-query flag byte; the expansion uses four blocks");
+  static_assert(QT % 2 == 0 && QT >= 2, "two query blocks share a 64-query flag byte");
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   uint32_t tile, qw;
   if (tiles_per_xcd) {
@@ -508,6 +513,90 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
       }
       if (lane == 0) stored[(size_t)tile * n_qw64 + (q0 >> 6) + u] = 0;
     }
+  }
+}
+
+// K4x for at most 32 queries: ONE query block per wave, so a 32-row step (1 KB of the DB) costs 4 MFMAs -- the matrix pipe
+// could take 16 TB/s of rows at that rate, and the pass is bound by HBM alone (BASELINE.json's "achieved HBM GB/s on
+// BF-matcher"; tools/k4_small_q.py). Same exact arithmetic, same per-lane lists, same output format as hamming_topk_mfma; the
+// accumulators of consecutive steps alternate so that the test of step s runs beside the MFMAs of step s + 1, and four
+// steps' packed rows are in flight per wave.
+template <int K, bool IMAX>
+__global__ __launch_bounds__(kBlock) void hamming_topk_mfma_q32(const uint32_t* __restrict__ db, const uint32_t* __restrict__ q,
+                                                                uint32_t n_rows, uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
+                                                                uint32_t n_tiles, uint32_t n_qw64, uint32_t cut, uint32_t share_period,
+                                                                uint32_t* __restrict__ part, uint32_t* bound,
+                                                                uint8_t* __restrict__ stored) {
+  const uint32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  if (tile >= n_tiles) return;
+  const uint32_t lane = threadIdx.x & 63u, c = lane & 31u, h = lane >> 5;
+  const Fp4Consts kc = fp4_consts();
+  Fp4Row qb;
+  {
+    const uint4 p = *reinterpret_cast<const uint4*>(q + (size_t)(c < nq ? c : nq - 1u) * kWords + 4u * h);
+    expand_row(p, qb, kc);
+  }
+  uint32_t best[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) best[j] = 0xFFFFFFFFu;
+  float thr = thr_of_limit(cut);
+  const uint32_t row0 = tile * rows_per_tile;
+  const uint32_t n_local = min(n_rows, row0 + rows_per_tile) - row0;
+  const uint32_t n_full = n_local / 32u, n_steps = (n_local + 31u) / 32u;
+  const uint32_t last_row = n_rows - 1u;
+  auto load_step = [&](uint32_t step) -> uint4 {
+    const uint32_t r = min(row0 + 32u * min(step, n_steps - 1u) + c, last_row);
+    return *reinterpret_cast<const uint4*>(db + (size_t)r * kWords + 4u * h);
+  };
+  uint4 p0 = load_step(0), p1 = load_step(1), p2 = load_step(2), p3 = load_step(3);
+  mfma_f32x16 acc_a, acc_b;                                          // acc_b: pending block of the previous step -- none yet
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc_b[i] = -1024.f;
+  uint32_t* my_bound = bound + (c < nq ? c : nq - 1u);
+  uint32_t seen = 0xFFFFFFFFu, next_share = 2u, step = 0;
+  for (; step + 4u <= n_full; step += 4u) {                          // four steps per trip: p0..p3 rotate by name, nothing is copied
+    Fp4Row a;
+    expand_row(p0, a, kc); p0 = load_step(step + 4u);
+    acc_a = dot_block(a, qb);
+    mfma_block_test<K, false, IMAX>(acc_b, thr, 32u * step - 32u + 4u * h, n_local, best);
+    expand_row(p1, a, kc); p1 = load_step(step + 5u);
+    acc_b = dot_block(a, qb);
+    mfma_block_test<K, false, IMAX>(acc_a, thr, 32u * step + 4u * h, n_local, best);
+    expand_row(p2, a, kc); p2 = load_step(step + 6u);
+    acc_a = dot_block(a, qb);
+    mfma_block_test<K, false, IMAX>(acc_b, thr, 32u * step + 32u + 4u * h, n_local, best);
+    expand_row(p3, a, kc); p3 = load_step(step + 7u);
+    acc_b = dot_block(a, qb);
+    mfma_block_test<K, false, IMAX>(acc_a, thr, 32u * step + 64u + 4u * h, n_local, best);
+    if (step + 4u >= next_share) {                                   // wave-uniform; as hamming_topk_mfma
+      next_share += share_period;
+      const uint32_t worst_d = best[K - 1] >> kLocalBits;
+      if (worst_d < (0xFFFFFFFFu >> kLocalBits) && worst_d < seen) atomicMin(my_bound, worst_d);
+      if (seen != 0xFFFFFFFFu) thr = fmaxf(thr, thr_of_limit(seen + 1u));
+      seen = __hip_atomic_load(my_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // the pending block of the last full trip, then up to three full and one partial step, one at a time (masked form)
+  mfma_block_test<K, true, IMAX>(acc_b, thr, 32u * step - 32u + 4u * h, step ? n_local : 0u, best);
+  for (; step < n_steps; ++step) {
+    Fp4Row a;
+    expand_row(p0, a, kc);
+    p0 = p1; p1 = p2; p2 = p3; p3 = load_step(step + 4u);
+    acc_a = dot_block(a, qb);
+    mfma_block_test<K, true, IMAX>(acc_a, thr, 32u * step + 4u * h, n_local, best);
+  }
+  uint32_t other[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) other[j] = __shfl_xor(best[j], 32);
+#pragma unroll
+  for (int j = 0; j < K; ++j) topk_insert<K>(best, other[j]);
+  // nq <= 32: this block is the only one of its 64-query group, so the flag byte is this wave's alone
+  if (__builtin_amdgcn_ballot_w64(c < nq && best[0] != 0xFFFFFFFFu) != 0ull) {
+    if (h == 0u && c < nq) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) part[((size_t)tile * K + j) * nq_pad + c] = best[j];
+    }
+    if (lane == 0) stored[(size_t)tile * n_qw64] = 0;
   }
 }
 
@@ -654,8 +743,9 @@ int k4_engine(const todhip_ctx* ctx, uint32_t nq) {
   if (env && env[0] == 'm') return 1;
   // Measured (tools/k4_engines.py, ms per launch K4 | K4x): 16 000 x 1M 3.2 | 1.1 on independent bits and 5.7 | 1.35 on this
   // repo's ORB descriptors; 1000 x 1M 0.25 | 0.085; 1000 x 100k 0.035 | 0.021; 500 x 5000 0.008 | 0.013. The matrix form
-  // pays from ~2^24 pairs on; below, a wave's 128-256 query columns and its fixed start-up cost more than they save.
-  return nq >= 64u && (uint64_t)nq * ctx->shard_rows >= (1ull << 24) ? 1 : 0;
+  // pays from ~2^24 pairs on; below, a wave's fixed start-up costs more than it saves. (Few queries over a big DB are
+  // matrix-engine work too: both engines pad to 64 query columns, and 8 MFMAs per KB of rows keep up with HBM.)
+  return (uint64_t)nq * ctx->shard_rows >= (1ull << 24) ? 1 : 0;
 }
 
 template <int K, int QT>
@@ -714,19 +804,57 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
 }
 
 template <int K>
+int launch_topk_mfma_q32(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radius, uint64_t* d_lists, uint32_t* n_lists) {
+  const uint32_t cut = radius >= 256u ? 0xFFFFFFFFu >> kLocalBits : radius + 1u;
+  const uint32_t n_rows = (uint32_t)ctx->shard_rows, n_qw64 = 1u, nq_pad = 64u;
+  // one wave per tile; about 32 waves per CU in all (each holds four 1 KB loads in flight), tiles of >= 2048 rows
+  uint32_t n_tiles = std::max(1u, std::min<uint32_t>((uint32_t)ctx->n_cu * 32u, n_rows / 2048u));
+  n_tiles = std::min(n_tiles, 8192u);
+  uint32_t rows_per_tile = ((n_rows + n_tiles - 1) / n_tiles + 31u) & ~31u;
+  if (rows_per_tile > kLocalMask) return TODHIP_EINVAL;
+  n_tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
+  const int env_share = getenv("TODHIP_K4X_SHARE") ? atoi(getenv("TODHIP_K4X_SHARE")) : 16;
+  const uint32_t groups = n_tiles < (uint32_t)kMergeGroups ? n_tiles : (uint32_t)kMergeGroups;
+  TOD_HIP(ctx->m_part.reserve((size_t)n_tiles * K * nq_pad * sizeof(uint32_t)));
+  const size_t bound_bytes = (size_t)nq_pad * sizeof(uint32_t), flag_bytes = (size_t)n_tiles * n_qw64;
+  TOD_HIP(ctx->m_bound.reserve(bound_bytes + flag_bytes));
+  TOD_HIP(hipMemsetAsync(ctx->m_bound.p, 0xFF, bound_bytes + flag_bytes, ctx->stream));
+  uint8_t* const d_stored = ctx->m_bound.as<uint8_t>() + bound_bytes;
+  int slot = -1;
+  if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
+  auto kern = cut <= 128u ? hamming_topk_mfma_q32<K, true> : hamming_topk_mfma_q32<K, false>;
+  hipLaunchKernelGGL(kern, dim3((n_tiles + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, ctx->stream,
+                     ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw64, cut,
+                     (uint32_t)std::max(4, env_share), ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>(), d_stored);
+  if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
+  hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
+                     ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
+                     d_stored, n_qw64, d_lists);
+  TOD_HIP(hipGetLastError());
+  *n_lists = groups;
+  return TODHIP_OK;
+}
+
+template <int K>
 int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radius, uint64_t* d_lists, uint32_t* n_lists) {
+  if (nq <= 32u && !(getenv("TODHIP_K4X_QT") && atoi(getenv("TODHIP_K4X_QT")) > 0))
+    return launch_topk_mfma_q32<K>(ctx, d_q, nq, radius, d_lists, n_lists);
   // Query blocks of 32 per wave (QT): as many as the registers hold beside the k-entry lists -- 8 for k <= 2, 6 for k <= 5
   // (the reference's k, DescriptorMatcher.cpp:211), 4 beyond -- and among those the one that pads nq the least (a wave
   // computes all its blocks; 1000 queries are 4 x 256 but 6 x 192). TODHIP_K4X_QT forces one (experiments).
+  // With at most 64 queries a wave holds two blocks (QT = 2): 8 MFMAs per 1 KB of rows -- the pass is then bound by HBM,
+  // not by the matrix pipe (BASELINE.json's "achieved HBM GB/s on BF-matcher" regime; tools/k4_small_q.py).
   constexpr int kMaxQT = K <= 2 ? 8 : (K <= 5 ? 6 : 4);
   const int env_qt = getenv("TODHIP_K4X_QT") ? atoi(getenv("TODHIP_K4X_QT")) : 0;
   auto padded = [&](uint32_t qt) { return (nq + 32u * qt - 1u) / (32u * qt) * (32u * qt); };
   int qt = kMaxQT;
   if (kMaxQT >= 8 && padded(6) < padded((uint32_t)qt)) qt = 6;
   if (kMaxQT >= 6 && padded(4) < padded((uint32_t)qt)) qt = 4;
-  if ((env_qt == 4 || env_qt == 6 || env_qt == 8) && env_qt <= kMaxQT) qt = env_qt;
+  if (padded(2) < padded((uint32_t)qt)) qt = 2;
+  if ((env_qt == 2 || env_qt == 4 || env_qt == 6 || env_qt == 8) && env_qt <= kMaxQT) qt = env_qt;
   if (qt == 8) return launch_topk_mfma_qt<K, (kMaxQT >= 8 ? 8 : 4)>(ctx, d_q, nq, radius, d_lists, n_lists);
   if (qt == 6) return launch_topk_mfma_qt<K, (kMaxQT >= 6 ? 6 : 4)>(ctx, d_q, nq, radius, d_lists, n_lists);
+  if (qt == 2) return launch_topk_mfma_qt<K, 2>(ctx, d_q, nq, radius, d_lists, n_lists);
   return launch_topk_mfma_qt<K, 4>(ctx, d_q, nq, radius, d_lists, n_lists);
 }
 
