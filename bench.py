@@ -79,8 +79,8 @@ def parse():
     ap.add_argument("--min-inliers", type=int, default=8, help="min_inliers (conf/detection.ork:39)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", default="chained,configs,adapter", help="N=1 only, after the timed region: comma list of "
-                    "chained,configs,adapter ('' = none)")
+    ap.add_argument("--extras", default="chained,configs,adapter,hbm", help="N=1 only, after the timed region: comma list of "
+                    "chained,configs,adapter,hbm ('' = none)")
     return ap.parse_args()
 
 
@@ -370,6 +370,46 @@ def run_adapter_path(torch, capi, device, desc, pts, off, frames, args):
             "poses_per_frame": n_poses / max(len(per_frame), 1)}
 
 
+def run_hbm_regime(torch, capi, device, args):
+    """BASELINE.json's "achieved HBM GB/s on BF-matcher" where it can be measured: few queries per pass over a DB far larger than
+    the 256 MiB Infinity Cache, so every 32-byte row comes from HBM and is used by only Q queries (at the headline's 16 000
+    queries per pass the same kernel family is three orders of magnitude on the compute side of that roof)."""
+    rows, Q, k, radius = 40_000_000, 16, args.k, args.radius
+    rng = np.random.Generator(np.random.PCG64(77))
+    desc = rng.integers(0, 256, size=(rows, 32), dtype=np.uint8)
+    pts = np.zeros((rows, 3), np.float32)
+    off = (np.arange(rows // 5000 + 1, dtype=np.uint64) * 5000).astype(np.uint32)
+    ctx = capi.Context(device)
+    ctx.db_load(desc, pts, off)
+    qrows = rng.choice(rows, Q, replace=False)
+    q = desc[qrows] ^ np.packbits(rng.random((Q, 256)) < 0.08, axis=1, bitorder="little")
+    del desc, pts
+    d_q = torch.from_numpy(np.ascontiguousarray(q)).cuda()
+    cnt = torch.zeros(Q, dtype=torch.int32, device="cuda"); mm = torch.zeros((Q * k, 4), dtype=torch.int32, device="cuda")
+    xx = torch.zeros((Q * k, 3), dtype=torch.float32, device="cuda")
+    out = {}
+    for eng in ("mfma", "valu"):
+        ctx.set_matcher_engine(eng)
+        call = lambda: ctx.match_device(d_q.data_ptr(), Q, k, radius, cnt.data_ptr(), mm.data_ptr(), xx.data_ptr())
+        for _ in range(2):
+            call()
+        ctx.synchronize(); ctx.set_kernel_timing(True); c0 = ctx.counters()
+        for _ in range(6):
+            call()
+        ctx.synchronize(); ms, n_l = launch_ms(c0, ctx.counters()); ctx.set_kernel_timing(False)
+        out[eng] = (ms, int(cnt.sum().item()))
+    ctx.close()
+    alg_bytes = rows * 32 + Q * (32 + k * 8)
+    gbs = alg_bytes / (out["mfma"][0] * 1e-3) / 1e9
+    return {"what": "%d queries per pass over a %d-row DB (%.2f GB of descriptors: five times the Infinity Cache), k=%d, radius %d; "
+                    "todhip_match_device, kernel hamming_topk_mfma_q32 (one 32-query block per wave: 4 MFMAs per KB of rows)"
+                    % (Q, rows, rows * 32 / 1e9, k, radius),
+            "roofline": {"kernel": "hamming_topk_mfma_q32", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "launch_ms": out["mfma"][0], "algorithmic_bytes": alg_bytes, "traffic": None},
+            "vector_engine_launch_ms": out["valu"][0], "vector_engine_GBs": alg_bytes / (out["valu"][0] * 1e-3) / 1e9,
+            "queries_with_a_match": out["mfma"][1], "engines_agree_on_match_count": out["mfma"][1] == out["valu"][1]}
+
+
 def run_configs(torch, capi, synth, device, args):
     """BASELINE.json configs other than the headline's (C3), each on one GPU: frames/s + the dominant kernel's time."""
     out = {}
@@ -634,7 +674,8 @@ def main():
                         "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                                 "note": "BASELINE.json's 'achieved HBM GB/s on BF-matcher': every 32-byte row is reused by all %d queries "
                                         "of the pass, so the pass is three orders of magnitude on the compute side of the HBM roof; "
-                                        "tools/k4_small_q.py measures the memory-bound regime (a few queries per pass)" % q_launch},
+                                        "`hbm_regime` (and tools/k4_small_q.py) measure the memory-bound regime: a few queries per "
+                                        "pass over a DB beyond the Infinity Cache" % q_launch},
                         "measured_mfma_roof": pmc.get("measured_mfma_roof"),
                         "note": "exact 256-bit Hamming distances as fp4 (+-1) dot products on the matrix cores: 512 flop per (query, row) "
                                 "pair, v_mfma_f32_32x32x64_f8f6f4; data independent. launch_ms = HIP events around the launch on its "
@@ -698,6 +739,8 @@ def main():
                 out["configs"] = run_configs(torch, capi, synth, local_rank, args)
             if "adapter" in extras:
                 out["adapter_path"] = run_adapter_path(torch, capi, local_rank, desc, pts, off, frames, args)
+            if "hbm" in extras:
+                out["hbm_regime"] = run_hbm_regime(torch, capi, local_rank, args)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
                                                    args.iterations, args.min_inliers)

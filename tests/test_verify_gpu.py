@@ -494,15 +494,26 @@ def test_object_with_more_than_4096_matches(ctx):
     assert len(poses) >= 1 and len(poses[0]["inliers"]) > 100
 
 
-def test_maximum_object_size_and_one_beyond(ctx):
-    """Exactly 16384 matches on one object (the documented maximum) equals the oracle; one keypoint more is refused
-    with TODHIP_ESCRATCH instead of computing something else."""
-    sc = synth.make_verify_scene(4096, n_objects=1, per_object=6000, visible=((0, 0.2),), matches_per_kp=4, seed=91,
+def test_shipped_config_worst_case_25000_matches_on_one_object(ctx):
+    """conf/detection.ork:26 sets n_features 5000 and the cell's k is 5 (DescriptorMatcher.cpp:211): on a 1-object DB every
+    one of the 25 000 matches can land on that object (the reference has no size limit, adjacency_ransac.h:48-133). Bitset
+    rows span 391 words (7 per lane of a wave); equal to the oracle (few iterations: the CPU side is what takes time)."""
+    sc = synth.make_verify_scene(5000, n_objects=1, per_object=8000, visible=((0, 0.2),), matches_per_kp=5, seed=93,
                                  nan_frac=0.0)
-    assert len(sc["matches"]) == 16384
-    poses, rounds = _compare_frame(ctx, sc, 8, 100)
+    assert len(sc["matches"]) == 25000
+    poses, rounds = _compare_frame(ctx, sc, 8, 12)
     assert len(poses) == 1 and len(poses[0]["inliers"]) > 500
-    sc = synth.make_verify_scene(4097, n_objects=1, per_object=6000, visible=((0, 0.1),), matches_per_kp=4, seed=91,
+
+
+def test_maximum_object_size_and_one_beyond(ctx):
+    """Exactly 32768 matches on one object (the documented maximum) equals the oracle; one keypoint more is refused
+    with TODHIP_ESCRATCH instead of computing something else."""
+    sc = synth.make_verify_scene(8192, n_objects=1, per_object=9000, visible=((0, 0.1),), matches_per_kp=4, seed=91,
+                                 nan_frac=0.0)
+    assert len(sc["matches"]) == 32768
+    poses, rounds = _compare_frame(ctx, sc, 8, 8)
+    assert len(poses) == 1 and len(poses[0]["inliers"]) > 300
+    sc = synth.make_verify_scene(8193, n_objects=1, per_object=9000, visible=((0, 0.1),), matches_per_kp=4, seed=91,
                                  nan_frac=0.0)
     rng = capi.rng_new(1)
     with pytest.raises(capi.TodError) as e:

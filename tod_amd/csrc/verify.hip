@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
   while (true) {
     // ---- estimateRigidTransformationSVD (sac_model_registration_graph.h:304-347) on the current inliers
     // ordered compaction of the inlier points into LDS (ascending match index = the reference's list order)
-    if (tid < W) sPre[tid] = (uint32_t)__popcll(inl[tid]);
+    for (uint32_t w = tid; w < W; w += 256u) sPre[w] = (uint32_t)__popcll(inl[w]);
     __syncthreads();
     if (tid == 0) {
       uint32_t acc = 0;

@@ -11,8 +11,8 @@ namespace tod {
 
 typedef unsigned long long u64;
 
-constexpr int kMaxWords = 256;     // n <= 16384 matches per object
-constexpr int kWPL = 4;            // bitset words per lane (kMaxWords / 64)
+constexpr int kMaxWords = 512;     // n <= 32768 matches per object (conf/detection.ork:26,  n_features 5000 x the cell's k = 5 -> 25000)
+constexpr int kWPL = 8;            // bitset words per lane (kMaxWords / 64)
 constexpr uint32_t kMaxSampleChecks = 1000;   // sac_model_registration_graph.h:366
 constexpr uint32_t kGateMinimal = 7;          // min(best_inlier_number_, 7) is always 7 (:85,:203,:268)
 constexpr int kStepCap = 100000;              // maximum_clique.cpp:318

@@ -1,10 +1,10 @@
 #!/bin/bash
-# kernel trace + stats of the default bench on the GPU box -> gpurun_out/prof_<tag>/
+# kernel trace + stats of the default bench.py pipeline (all three stages, no extras): the matcher launch average here must
+# agree with roofline.launch_ms of the bench line. Result: gpurun_out/prof_full; copy the kernel_stats.csv into profiles/.
 set -e
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-TAG=${1:-trace}
-shift || true
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" > $OUT/prof_$TAG.log 2>&1
-cat $OUT/prof_$TAG/*/*_kernel_stats.csv | cut -c1-200
+rm -rf $OUT/prof_full
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_full -- python3 bench.py --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --extras= > $OUT/prof_full.log 2>&1
+tail -c 600 $OUT/prof_full.log
