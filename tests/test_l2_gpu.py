@@ -126,3 +126,24 @@ def test_one_gemm_path_with_overflowing_candidate_lists(ctx):
     ctx.db_load(desc, pts, off)
     for k in (1, 4, 8):
         _assert_same(ctx, desc, pts, off, q, k, 1.0e9)
+
+
+def test_candidates_clustered_in_one_chunk_spill_from_slot_to_shared_list(ctx):
+    """Pass 2 keeps a (query, DB chunk, lane half)'s first 8 candidates in a private slot and appends the rest to the query's shared
+    list (csrc/l2.hip, CandSink). 60 near-copies of one vector in CONSECUTIVE rows land in one or two chunks, so both
+    containers are in use for the queries next to it and neither overflows; pass 3 must merge them into the oracle's answer."""
+    rng = np.random.Generator(np.random.PCG64(321))
+    n = 70000
+    desc = (rng.random((n, 128)) * 200).astype(np.float32)
+    base = (rng.random(128) * 200).astype(np.float32)
+    desc[31000:31060] = base[None, :] + rng.normal(0, 0.02, (60, 128)).astype(np.float32)
+    pts = rng.random((n, 3)).astype(np.float32)
+    off = np.array([0, 30000, 70000], np.uint32)
+    q = np.concatenate([base[None, :] + rng.normal(0, 0.02, (6, 128)).astype(np.float32),
+                        (rng.random((20, 128)) * 200).astype(np.float32)]).astype(np.float32)
+    ctx.db_load(desc, pts, off)
+    for k in (2, 8):
+        row_ptr, m = _assert_same(ctx, desc, pts, off, q, k, 1.0e9)
+        glob = (off[m["imgIdx"]].astype(np.int64) + m["trainIdx"]).reshape(len(q), k)
+        assert ((glob[:6] >= 31000) & (glob[:6] < 31060)).all()
+

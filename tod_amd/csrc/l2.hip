@@ -10,20 +10,21 @@
 //   (bf16 rounding moves each vector by <= 2^-9 of its norm, Cauchy-Schwarz on the two error terms, the f32
 //   accumulation of 128 products and of the norms is below 2^-16 of |q||r|; the second term covers the rounding
 //   of the sequential f32 sum that DEFINES d2, see include/todhip.h).
-//   pass 0  seed(q) = k-th smallest score over a sample of the DB    (an upper bound of A_k: a subset's k-th smallest)
+//   pass 0  seed(q) >= A_k from a sample of the DB                  (the k-th smallest of per-partition minima, or of per-lane lists)
 //   pass 1  A_k(q) = k-th smallest score over the DB                (GEMM + per-lane top-8 in registers; only scores
 //                                                                    below the seed are ever inserted)
-//   pass 2  candidates = { r : score <= A_k + 2 eps }                (same GEMM, atomic append, <= kCandCap per query)
+//   pass 2  candidates = { r : score <= A_k + 2 eps }                (same GEMM; a lane's candidates go to its private slot)
 //           every row of the true top-k is a candidate: its d2 <= T_k <= A_k + |q|^2 + eps
 //   DBs of >= 64k rows skip pass 1: the sample is an evenly spaced quarter of the DB (at most 64k rows) and seed + 2 eps
 //   is used as the threshold of pass 2 -- seed >= A_k, so the candidates are a superset (rows of rank <= ~k N / n_sample
 //   plus the eps band) and pass 3 returns the same result from it
 //   pass 3  exact d2 of the candidates in the defining order (sequential f32, no fma), k smallest by (d2, row);
-//           a query whose candidate list overflowed is redone by an exact scan of the whole DB
-// L2G  l2_gemm_kernel<PASS>    block = 4 waves x 4 query tiles of 32 = 512 queries; DB tiles of 32 rows x 128 bf16
-//                              (8 KB) stream through a 4-slot LDS ring filled by global_load_lds 2-3 tiles ahead; per 32 DB rows and query tile 8
-//                              v_mfma_f32_32x32x16_bf16 with the row norms as the C operand and the queries
-//                              pre-scaled by -2 (exact in bf16), so the accumulator IS the score
+//           a query whose candidate lists overflowed is redone by an exact scan of the whole DB
+// L2G  l2_gemm_kernel<PASS, KT>  wave = (DB chunk, 4 query tiles of 32): the queries are 128 VGPRs of B fragments; the DB is stored
+//                              in A-fragment order and streams through a per-wave two-slot ring in LDS that global_load_lds fills
+//                              two tiles ahead (no barrier anywhere); per 32 DB rows and query tile 8 v_mfma_f32_32x32x16_bf16
+//                              with the row norms as the C operand and the queries pre-scaled by -2 (exact in bf16), so the
+//                              accumulator IS the score
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -36,20 +37,22 @@
 namespace {
 
 constexpr uint32_t kDim = 128;
-constexpr uint32_t kTileRows = 32;                        // DB rows of one MFMA A tile = one LDS ring slot (8 KB)
-constexpr uint32_t kRing = 4;                             // LDS ring slots: loads run 2-3 tiles ahead of the MFMAs
+constexpr uint32_t kTileRows = 32;                        // DB rows of one MFMA A tile (8 KB of bf16)
+constexpr uint32_t kRingSlotBytes = kTileRows * kDim * 2u + 256u;   // a wave's ring slot in LDS: one tile's fragments + its 32 norms, twice
 constexpr uint32_t kQTilesPerWave = 4;
 constexpr uint32_t kWaves = 4;
-constexpr uint32_t kBlockQueries = kWaves * kQTilesPerWave * 32u;   // 256
+constexpr uint32_t kBlockQueries = kWaves * kQTilesPerWave * 32u;   // 512
 constexpr uint32_t kTop = 8;                              // per-lane list length of pass 1 (k <= 8)
-constexpr uint32_t kCandCap = 1024;                        // candidates per query before the exact-scan fallback
+constexpr uint32_t kSlot = 8;                             // candidate rows a (query, chunk, lane half) keeps in its private slot
+constexpr uint32_t kCandCap = 1024;                       // shared list per query for what the slots cannot hold; beyond it the exact scan
+constexpr uint32_t kListCap = 2048;                       // candidates per query all told (pass 3's list in LDS); beyond it the exact scan
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 = 4 VGPRs: one MFMA A/B fragment
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct L2Ws {
-  DevBuf db_bf16, db_norm, q_bf16, q_eps, part, thr, cand, cand_cnt, keys, scal;
+  DevBuf db_bf16, db_norm, q_bf16, q_eps, part, thr, slots, slot_cnt, cand, cand_cnt, keys, scal;
   uint32_t n_pad = 0;
 };
 
@@ -64,14 +67,20 @@ __device__ __forceinline__ uint16_t bf16_rne(float x) {
 }
 
 // one wave per row: bf16 image (scaled by `scale`, a power of two) and |row|^2; rows >= n are padding
+// frag != 0 (the DB image): a 32-row tile is stored in MFMA A-fragment order -- 8 segments (k-steps s) of 64 lanes x 16 bytes,
+// lane (h = l >> 5, r = l & 31) of segment s holding A[row r][k = 16 s + 8 h + j], j = 0..7 -- so that one wave-load of a
+// segment is 1 KB contiguous AND already the register image v_mfma_f32_32x32x16_bf16 wants: no LDS staging, no swizzle
 __global__ __launch_bounds__(256) void l2_prepare_kernel(const float* __restrict__ src, uint32_t n, uint32_t n_pad, float scale,
                                                          uint16_t* __restrict__ dst, float* __restrict__ norm2,
-                                                         uint32_t* __restrict__ max_norm2_bits) {
+                                                         uint32_t* __restrict__ max_norm2_bits, int frag) {
   const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
   if (row >= n_pad) return;
   float a = 0.f, b = 0.f;
   if (row < n) { a = src[(size_t)row * kDim + 2u * l]; b = src[(size_t)row * kDim + 2u * l + 1u]; }
-  reinterpret_cast<uint32_t*>(dst)[(size_t)row * (kDim / 2u) + l] =
+  const uint32_t k0 = 2u * l;                               // this lane's two dimensions k0, k0 + 1
+  const size_t at = frag ? ((size_t)(row >> 5) * (kTileRows * kDim) + (k0 >> 4) * 512u + (((k0 >> 3) & 1u) * 32u + (row & 31u)) * 8u + (k0 & 7u)) / 2u
+                         : (size_t)row * (kDim / 2u) + l;
+  reinterpret_cast<uint32_t*>(dst)[at] =
       (uint32_t)bf16_rne(a * scale) | ((uint32_t)bf16_rne(b * scale) << 16);
   float s = a * a + b * b;
 #pragma unroll
@@ -91,21 +100,95 @@ __global__ __launch_bounds__(256) void l2_eps_kernel(const float* __restrict__ q
   eps[q] = 0.0079345703125f * nq * rmax + 6.103515625e-05f * (nq + rmax) * (nq + rmax);   // 2^-7 (1 + 2^-6), 2^-14
 }
 
-// KT: per-lane list length of pass 1 (4 when k <= 4: 16 VGPRs less), unused in pass 2
+// Where pass 2 puts a lane's candidates. A lane is the only writer for (query, chunk, lane half): its first kSlot rows go to a
+// private slot with plain stores and a count in a register -- nothing to wait for. (An atomic append to one list per query, the
+// round-1 form, costs a round trip to L2 per candidate with every outstanding load drained first, and with some hundreds
+// of candidates per query at the eps band of bf16 that was most of the pass.) Rows beyond kSlot go to the shared list.
+struct CandSink {
+  uint32_t* __restrict__ slots;        // [nq_pad][n_parts][kSlot]
+  uint32_t* __restrict__ shared;       // [nq_pad][kCandCap]
+  uint32_t* __restrict__ shared_cnt;   // [nq_pad]
+  uint32_t n_parts, part;              // this lane's partition = 2 chunk + h
+};
+
+// What becomes of the 16 scores a lane holds for query q (register i <-> DB row row0 + (i & 3) + 8 (i >> 2), row0 including the
+// lane half's 4 h).
+//   pass 1, KT > 1: the KT smallest below `limit` in `best` (ascending), and the limit follows best[KT - 1]
+//   pass 1, KT = 1: the minimum only -- one instruction behind the min tree, no branch (the seed pass: the k-th smallest of
+//                   the partitions' minima is the score of k distinct rows, hence an upper bound of A_k like the exact k-th)
+//   pass 2: rows with score <= limit are appended to the lane's slot (`cnt` rows so far)
+template <int PASS, uint32_t KT>
+__device__ __forceinline__ void l2_epilogue(const f32x16& sc, float& limit, float (&best)[KT], uint32_t& cnt, uint32_t q, uint32_t row0,
+                                            const CandSink& sink) {
+  if (PASS == 2) {
+    // two levels, so that a tile with one candidate among its 64 x 16 scores (the usual case when there is any) pays four
+    // group tests and four leaf tests rather than sixteen: minima of the four register groups (= row groups 8 g + 4 h ..+3)
+    float gm[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gm[g] = fminf(fminf(fminf(sc[4 * g], sc[4 * g + 1]), sc[4 * g + 2]), sc[4 * g + 3]);
+    const float m = fminf(fminf(fminf(gm[0], gm[1]), gm[2]), gm[3]);
+    if (__builtin_amdgcn_ballot_w64(m <= limit) != 0ull) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (__builtin_amdgcn_ballot_w64(gm[g] <= limit) != 0ull) {   // wave-uniform
+          asm volatile("");                                           // a scalar branch of its own, not folded into the lanes' tests below
+#pragma unroll
+          for (int i = 4 * g; i < 4 * g + 4; ++i) {
+            if (sc[i] <= limit) {
+              uint32_t base = row0;
+              asm volatile("" : "+v"(base));                    // keeps the 16 row numbers from being hoisted into 16 registers of the main path
+              const uint32_t row = base + (uint32_t)(i & 3) + 8u * (uint32_t)(i >> 2);
+              if (cnt < kSlot) {
+                sink.slots[((size_t)q * sink.n_parts + sink.part) * kSlot + cnt] = row;
+              } else {
+                const uint32_t at = atomicAdd(&sink.shared_cnt[q], 1u);
+                if (at < kCandCap) sink.shared[(size_t)q * kCandCap + at] = row;
+              }
+              ++cnt;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+  float m = fminf(fminf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+  for (int i = 3; i < 15; i += 2) m = fminf(fminf(m, sc[i]), sc[i + 1]);
+  m = fminf(m, sc[15]);
+  if (KT == 1) {
+    best[0] = fminf(best[0], m);
+  } else {
+    if (__builtin_amdgcn_ballot_w64(m < limit) != 0ull) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (__builtin_amdgcn_ballot_w64(sc[i] < limit) != 0ull) {    // wave-uniform: usually one value of the 16
+          float v = sc[i] < limit ? sc[i] : FLT_MAX;                  // FLT_MAX falls through the list unchanged
+#pragma unroll
+          for (uint32_t j = 0; j < KT; ++j) { const float lo = fminf(best[j], v); v = fmaxf(best[j], v); best[j] = lo; }
+        }
+      }
+      limit = fminf(limit, best[KT - 1]);
+    }
+  }
+}
+
+// L2G. One WAVE = (DB chunk, 128 queries): 4 query tiles of 32 as B fragments in registers (128 VGPRs); the DB streams through
+// in tiles of 32 rows that are stored in A-fragment order (l2_prepare_kernel), so a tile is 8 contiguous 1 KB wave-loads whose
+// lane l part is exactly what lane l feeds the MFMA -- LDS is only a FIFO between the load and the register, never a
+// transpose. No barrier, no dependence between the waves of a block (they load the same tiles at about the same time, so
+// three of four loads hit the CU's L1). The row norms enter as the C operand of a tile's first MFMA, so the accumulator IS
+// the score; the epilogue of query tile t sits behind the MFMAs of tile t + 1 (two accumulators).
+// KT: per-lane list length of pass 1 (1: minimum only, the seed pass; 4 when k <= 4: 16 VGPRs less), unused in pass 2
 template <int PASS, uint32_t KT>
 __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restrict__ db, const float* __restrict__ dbn,
                                                          uint32_t n_tiles, uint32_t tiles_per_chunk, uint32_t tile_stride,
                                                          const uint16_t* __restrict__ qh, uint32_t nq_pad,
                                                          float* __restrict__ part, const float* __restrict__ thr,
+                                                         uint32_t* __restrict__ slots, uint32_t* __restrict__ slot_cnt,
                                                          uint32_t* __restrict__ cand, uint32_t* __restrict__ cand_cnt) {
   // tile_stride: tile t of the launch is DB tile t * tile_stride (the seed pass samples the DB evenly; 1 otherwise)
   // thr: PASS 1 -- optional per-query seed (only scores below it can matter), PASS 2 -- the candidate threshold
-  // LDS ring of DB tiles, written by global_load_lds (no VGPR staging): a wave-load drops 64 x 16 B = 4 rows
-  // contiguously, so rows are unpadded and the 16-byte chunk c of row r is stored at chunk c ^ (r & 15) instead
-  // (the swizzle is applied to the GLOBAL address each lane fetches from): the column-wise ds_read_b128 of the
-  // A fragment then spreads over all banks (2-way, as a padded image would be)
-  __shared__ __align__(16) unsigned char s_tile[kRing][kTileRows * 256u];
-  __shared__ __align__(16) float s_norm[kRing][64];
   const uint32_t tid = threadIdx.x, wave = tid >> 6, l = tid & 63u, r = l & 31u, h = l >> 5;
   const uint32_t chunk = blockIdx.x;
   const uint32_t q_base = blockIdx.y * kBlockQueries + wave * (kQTilesPerWave * 32u);
@@ -122,110 +205,98 @@ __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restr
   }
   float best[kQTilesPerWave][KT];
   float limit[kQTilesPerWave];
+  uint32_t n_cand[kQTilesPerWave];                          // pass 2: rows this lane has appended per query
 #pragma unroll
   for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
 #pragma unroll
     for (uint32_t j = 0; j < KT; ++j) best[t][j] = FLT_MAX;
     limit[t] = (PASS == 1 && !thr) ? FLT_MAX : thr[q_base + 32u * t + r];
+    n_cand[t] = 0u;
   }
-
-  // wave w moves wave-loads 2w and 2w+1 of the tile's 8 (each 1 KB = rows 4j .. 4j+3) and, redundantly with the
-  // other waves (same bytes, same place), the 32 row norms: 3 loads per wave and tile, so the waits below count in 3s
-  // issued as asm: the compiler would otherwise drain vmcnt to 0 before every LDS read (it cannot know which
-  // slot a read touches), which is exactly the prefetch depth this ring exists for
+  const CandSink sink{slots, cand, cand_cnt, 2u * gridDim.x, 2u * chunk + h};
+  // everything loaded so far is waited for HERE: the compiler does not see the ring's loads below, and a wait of its own for one
+  // of these, placed lazily inside the loop, would be counted without them and drain the ring
+#pragma unroll
+  for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
+#pragma unroll
+    for (uint32_t s = 0; s < 8; ++s) asm volatile("" :: "v"(bq[t][s]));
+    asm volatile("" :: "v"(limit[t]));
+  }
+  // The wave's private ring in LDS: two slots of one DB tile (8 KB of fragments, already in register order) + its 32 row norms
+  // (twice: the 64 lanes of the load bring them as lanes l & 31). A slot is filled by 9 loads that write LDS directly
+  // (global_load_lds: no destination registers, so their depth costs nothing) and read back with ds_read_b128 -- lane l
+  // gets exactly the 16 bytes lane l loaded. Written as asm, with the vmcnt waits counted by hand: loads retire in order, each
+  // tile is exactly 9 of them, and "at most 9 outstanding" therefore means the older of the two tiles in flight has landed
+  // (the compiler would wait for everything before any LDS read, which is the depth this ring exists for).
+  __shared__ __attribute__((aligned(16))) uint8_t ring[kWaves][2][kRingSlotBytes];
   typedef __attribute__((address_space(3))) void* lptr_t;
-  // m0 is named in the clobber list on purpose (the asm writes it; the compiler must not keep a value there across it);
-  // clang flags every reserved register in a clobber list, hence the pragma
+  const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(lptr_t)(&ring[wave][0][0]));
+  const uint32_t frag_off = l * 16u, norm_off = r * 4u;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-#define L2_LOAD_LDS(width_, gaddr_, lds_)                                                                      \
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_" width_ " %0, off"                             \
-               :: "v"(gaddr_), "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)(size_t)(lptr_t)(lds_))) : "memory", "m0")
-  uint32_t src_chunk[2];                                   // this lane's 16-byte chunk inside a tile, per wave-load
+#define L2_DMA(width_, voff_, gaddr_, lds_)                                                                     \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_" width_ " %0, %1" :: "v"(voff_), "s"(gaddr_), "s"(lds_) : "memory", "m0")
+  auto issue = [&](uint32_t tile, uint32_t slot) {
+    tile = min(tile, t_end - 1u);                           // past the chunk: a harmless reload, the count per tile stays 9
+    const uint64_t g = (uint64_t)(db + (size_t)tile * tile_stride * (kTileRows * kDim));
+    const uint64_t gn = (uint64_t)(dbn + (size_t)tile * tile_stride * kTileRows);
+    const uint32_t lds = ring_lds + slot * kRingSlotBytes;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's previous tile has been read out
 #pragma unroll
-  for (uint32_t i = 0; i < 2; ++i) {
-    const uint32_t p = (2u * wave + i) * 64u + l, row = p >> 4, c = p & 15u;
-    src_chunk[i] = row * 16u + (c ^ (row & 15u));
-  }
-#define L2_ISSUE(tile_)                                                                                        \
-  {                                                                                                            \
-    const uint32_t slot_ = ((tile_) - t_begin) % kRing;                                                        \
-    const uint4* src_ = reinterpret_cast<const uint4*>(db + (size_t)(tile_) * tile_stride * kTileRows * kDim); \
-    L2_LOAD_LDS("dwordx4", src_ + src_chunk[0], &s_tile[slot_][(2u * wave) * 1024u]);                          \
-    L2_LOAD_LDS("dwordx4", src_ + src_chunk[1], &s_tile[slot_][(2u * wave + 1u) * 1024u]);                     \
-    L2_LOAD_LDS("dword", dbn + (size_t)(tile_) * tile_stride * kTileRows + r, &s_norm[slot_][0]);              \
-  }
-  // s_waitcnt vmcnt(N), nothing else: N = loads that may stay in flight (simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8)
-#define L2_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
-  for (uint32_t i = 0; i < kRing - 1u; ++i)
-    if (t_begin + i < t_end) L2_ISSUE(t_begin + i);
-  for (uint32_t tile = t_begin; tile < t_end; ++tile) {
-    const uint32_t buf = (tile - t_begin) % kRing;
-    // this wave's loads of `tile` have landed once at most the loads of the later tiles in flight remain
-    if (tile + 2u < t_end) L2_WAIT_VM(6); else if (tile + 1u < t_end) L2_WAIT_VM(3); else L2_WAIT_VM(0);
-    __syncthreads();                                       // ... and everybody else's; slot (tile - 1) % kRing is free again
-    if (tile + kRing - 1u < t_end) L2_ISSUE(tile + kRing - 1u);
-    {
-    // A[row r][k = 16 s + 8 h + j] = chunk 2 s + h of row r, stored at chunk (2 s + h) ^ (r & 15)
-    bf16x8 a[8];
+    for (uint32_t s = 0; s < 8; ++s) L2_DMA("dwordx4", frag_off, g + s * 1024u, lds + s * 1024u);
+    L2_DMA("dword", norm_off, gn, lds + 8192u);
+  };
+  // One DB tile against the wave's 4 query tiles. The tile's fragments live in ONE register set: the last query tile's
+  // MFMA of k-step s is the last reader of a[s], and the next tile's a[s] is read from the ring right behind it (a second
+  // set would not fit beside the 128 query registers at two waves per SIMD; LDS latency is what that distance covers).
+  bf16x8 a[8];
+  // |row|^2 of the rows this lane's accumulators belong to (register 4 g + i <-> row 8 g + 4 h + i): the C operand of a query
+  // tile's first MFMA. Like a[], ONE register set, reloaded behind its last reader.
+  f32x16 nrm;
+  auto read_frag = [&](uint32_t slot, uint32_t s) { return *reinterpret_cast<const bf16x8*>(&ring[wave][slot][s * 1024u + frag_off]); };
+  auto read_norms = [&](uint32_t slot) {
+    const float* np = reinterpret_cast<const float*>(&ring[wave][slot][8192u]) + 4u * h;
 #pragma unroll
-    for (uint32_t s = 0; s < 8; ++s)
-      a[s] = *reinterpret_cast<const bf16x8*>(&s_tile[buf][r * 256u + (((2u * s + h) ^ (r & 15u)) << 4)]);
-    // software pipeline over the wave's query tiles: the MFMAs of tile t + 1 are issued (into the other
-    // accumulator) before the epilogue of tile t, so the matrix pipe never waits for the 16-way min and the ballot
+    for (uint32_t gg = 0; gg < 4; ++gg) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(np + 8u * gg);
+      nrm[4 * gg + 0] = v[0]; nrm[4 * gg + 1] = v[1]; nrm[4 * gg + 2] = v[2]; nrm[4 * gg + 3] = v[3];
+    }
+  };
+  issue(t_begin, 0u);
+  issue(t_begin + 1u, 1u);
+  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+#pragma unroll
+  for (uint32_t s = 0; s < 8; ++s) a[s] = read_frag(0u, s);
+  read_norms(0u);
+  uint32_t cur = 0;
+  for (uint32_t tile = t_begin; tile < t_end; ++tile, cur ^= 1u) {
+    issue(tile + 2u, cur);                                  // in flight now: tile + 1 (the other slot) and tile + 2
     f32x16 acc[2];
     auto mfma_tile = [&](uint32_t t) {
-      // C operand = |row|^2 of the rows this lane's accumulators belong to (reg 4 g + i <-> row 8 g + 4 h + i), read
-      // from LDS straight into the accumulator (no second register set for it)
-      f32x16 c;
+      if (t + 1 == kQTilesPerWave) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // tile + 1 has landed
+      f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[t][0], nrm, 0, 0, 0);
+      if (t + 1 == kQTilesPerWave) { a[0] = read_frag(cur ^ 1u, 0u); read_norms(cur ^ 1u); }
 #pragma unroll
-      for (uint32_t gg = 0; gg < 4; ++gg) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&s_norm[buf][8u * gg + 4u * h]);
-        c[4 * gg + 0] = v[0]; c[4 * gg + 1] = v[1]; c[4 * gg + 2] = v[2]; c[4 * gg + 3] = v[3];
+      for (uint32_t s = 1; s < 8; ++s) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[t][s], c, 0, 0, 0);
+        if (t + 1 == kQTilesPerWave) a[s] = read_frag(cur ^ 1u, s);
       }
-#pragma unroll
-      for (uint32_t s = 0; s < 8; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[t][s], c, 0, 0, 0);
       return c;
     };
     acc[0] = mfma_tile(0);
 #pragma unroll
     for (uint32_t t = 0; t < kQTilesPerWave; ++t) {
       if (t + 1 < kQTilesPerWave) acc[(t + 1) & 1u] = mfma_tile(t + 1);
-      const f32x16& sc = acc[t & 1u];
-      const float m0 = fminf(fminf(sc[0], sc[1]), fminf(sc[2], sc[3])), m1 = fminf(fminf(sc[4], sc[5]), fminf(sc[6], sc[7]));
-      const float m2 = fminf(fminf(sc[8], sc[9]), fminf(sc[10], sc[11])), m3 = fminf(fminf(sc[12], sc[13]), fminf(sc[14], sc[15]));
-      const float m = fminf(fminf(m0, m1), fminf(m2, m3));
-      if (PASS == 1) {
-        if (__builtin_amdgcn_ballot_w64(m < limit[t]) != 0ull) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            if (__builtin_amdgcn_ballot_w64(sc[i] < limit[t]) != 0ull) {    // wave-uniform: usually one value of the 16
-              float v = sc[i] < limit[t] ? sc[i] : FLT_MAX;                  // FLT_MAX falls through the list unchanged
-#pragma unroll
-              for (uint32_t j = 0; j < KT; ++j) { const float lo = fminf(best[t][j], v); v = fmaxf(best[t][j], v); best[t][j] = lo; }
-            }
-          }
-          limit[t] = fminf(limit[t], best[t][KT - 1]);
-        }
-      } else {
-        if (__builtin_amdgcn_ballot_w64(m <= limit[t]) != 0ull) {
-          const uint32_t q = q_base + 32u * t + r;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            if (sc[i] <= limit[t]) {
-              const uint32_t row = tile * kTileRows + (uint32_t)(i & 3) + 8u * (uint32_t)(i >> 2) + 4u * h;
-              const uint32_t at = atomicAdd(&cand_cnt[q], 1u);
-              if (at < kCandCap) cand[(size_t)q * kCandCap + at] = row;
-            }
-          }
-        }
-      }
-    }
+      l2_epilogue<PASS, KT>(acc[t & 1u], limit[t], best[t], n_cand[t], q_base + 32u * t + r, tile * tile_stride * kTileRows + 4u * h, sink);
     }
   }
-#undef L2_ISSUE
-#undef L2_WAIT_VM
-#undef L2_LOAD_LDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing may still be on its way into this block's LDS when it is handed on
+#undef L2_DMA
+#pragma clang diagnostic pop
+  if (PASS == 2) {
+#pragma unroll
+    for (uint32_t t = 0; t < kQTilesPerWave; ++t) slot_cnt[(size_t)(q_base + 32u * t + r) * sink.n_parts + sink.part] = n_cand[t];
+  }
   if (PASS == 1) {
     // partition (chunk, lane half): kTop ascending scores per query
 #pragma unroll
@@ -314,18 +385,45 @@ __device__ __forceinline__ void wave_select(uint64_t (&best)[kTop], uint32_t k, 
 
 // pass 3: one wave per query. keys[q][k] = (f32 bits of d2) << 32 | row, ascending, ~0 padded
 __global__ __launch_bounds__(256) void l2_rerank_kernel(const float* __restrict__ q, uint32_t nq, const float* __restrict__ db,
-                                                        const uint32_t* __restrict__ cand, const uint32_t* __restrict__ cand_cnt,
-                                                        uint32_t k, uint64_t* __restrict__ keys, uint32_t* __restrict__ overflow) {
+                                                        const uint32_t* __restrict__ slots, const uint32_t* __restrict__ slot_cnt,
+                                                        uint32_t n_parts, const uint32_t* __restrict__ cand,
+                                                        const uint32_t* __restrict__ cand_cnt, uint32_t k, uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ overflow) {
   const uint32_t qi = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
   if (qi >= nq) return;
-  const uint32_t cnt = cand_cnt[qi];
-  if (cnt > kCandCap) { if (l == 0) overflow[qi] = 1u; return; }   // redone by l2_exact_scan_kernel
+  const uint32_t cnt = cand_cnt[qi], w = threadIdx.x >> 6;
+  // the query's candidate rows, gathered into one list in LDS first (the slots of 64 partitions at a time: counts, a wave
+  // prefix sum, 32 bytes of rows per lane), so that the exact distances below are spread evenly over the lanes
+  __shared__ uint32_t s_rows[4][kListCap];
+  uint32_t total = 0;
+  for (uint32_t p0 = 0; p0 < n_parts; p0 += 64u) {
+    const uint32_t p = p0 + l;
+    const uint32_t c = p < n_parts ? min(slot_cnt[(size_t)qi * n_parts + p], kSlot) : 0u;
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (l >= (uint32_t)off) incl += t; }
+    const uint32_t at = total + incl - c;
+    if (c) {
+      const uint4* src = reinterpret_cast<const uint4*>(slots + ((size_t)qi * n_parts + p) * kSlot);
+      const uint4 lo = src[0], hi = src[1];
+      const uint32_t rows[kSlot] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (uint32_t j = 0; j < kSlot; ++j) if (j < c && at + j < kListCap) s_rows[w][at + j] = rows[j];
+    }
+    total += __shfl(incl, 63);
+  }
+  for (uint32_t c = l; c < min(cnt, kCandCap); c += 64u)    // what did not fit a slot
+    if (total + c < kListCap) s_rows[w][total + c] = cand[(size_t)qi * kCandCap + c];
+  total += cnt;
+  if (cnt > kCandCap || total > kListCap) { if (l == 0) overflow[qi] = 1u; return; }   // redone by l2_exact_scan_kernel
   if (l == 0) overflow[qi] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   uint64_t best[kTop];
 #pragma unroll
   for (uint32_t j = 0; j < kTop; ++j) best[j] = ~0ull;
-  for (uint32_t c = l; c < cnt; c += 64u) {
-    const uint32_t row = cand[(size_t)qi * kCandCap + c];
+  for (uint32_t c = l; c < total; c += 64u) {
+    const uint32_t row = s_rows[w][c];
     const float d2 = d2_exact(q + (size_t)qi * kDim, db + (size_t)row * kDim);
     keys_insert(best, ((uint64_t)__float_as_uint(d2) << 32) | row);
   }
@@ -388,7 +486,7 @@ __global__ __launch_bounds__(256) void l2_finalize_kernel(const uint64_t* __rest
 void tod_l2_ws_free(todhip_ctx* ctx) {
   if (!ctx->l2_ws) return;
   L2Ws* ws = reinterpret_cast<L2Ws*>(ctx->l2_ws);
-  DevBuf* bufs[] = {&ws->db_bf16, &ws->db_norm, &ws->q_bf16, &ws->q_eps, &ws->part, &ws->thr, &ws->cand, &ws->cand_cnt, &ws->keys,
+  DevBuf* bufs[] = {&ws->db_bf16, &ws->db_norm, &ws->q_bf16, &ws->q_eps, &ws->part, &ws->thr, &ws->slots, &ws->slot_cnt, &ws->cand, &ws->cand_cnt, &ws->keys,
                     &ws->scal};
   for (DevBuf* b : bufs) b->release();
   delete ws;
@@ -406,7 +504,7 @@ int tod_l2_db_prepare(todhip_ctx* ctx) {
   TOD_HIP(hipMemsetAsync(ws->scal.p, 0, 64, ctx->stream));
   if (ws->n_pad)
     hipLaunchKernelGGL(l2_prepare_kernel, dim3((ws->n_pad + 3u) / 4u), dim3(256), 0, ctx->stream, ctx->db_desc.as<float>(), n,
-                       ws->n_pad, 1.0f, ws->db_bf16.as<uint16_t>(), ws->db_norm.as<float>(), ws->scal.as<uint32_t>());
+                       ws->n_pad, 1.0f, ws->db_bf16.as<uint16_t>(), ws->db_norm.as<float>(), ws->scal.as<uint32_t>(), 1);
   TOD_HIP(hipGetLastError());
   return TODHIP_OK;
 }
@@ -428,7 +526,8 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
   const uint32_t q_blocks = nq_pad / kBlockQueries;
   const uint32_t n_tiles = ws->n_pad / kTileRows;
   // 2 blocks per CU in flight; the DB is cut into as many chunks as that allows for this many query blocks
-  uint32_t n_chunks = std::max(1u, (2u * (uint32_t)ctx->n_cu) / q_blocks);
+  static const uint32_t env_cm = getenv("TODHIP_L2_CHUNK_ROUNDS") ? (uint32_t)atoi(getenv("TODHIP_L2_CHUNK_ROUNDS")) : 0u;    // tuning knob
+  uint32_t n_chunks = std::max(1u, (std::max(env_cm, 1u) * 2u * (uint32_t)ctx->n_cu) / q_blocks);
   n_chunks = std::min(n_chunks, std::max(1u, n_tiles));
   const uint32_t tiles_per_chunk = (n_tiles + n_chunks - 1u) / n_chunks;
   n_chunks = (n_tiles + tiles_per_chunk - 1u) / tiles_per_chunk;
@@ -438,10 +537,12 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
   TOD_HIP(ws->part.reserve((size_t)std::max(n_parts, 64u) * nq_pad * kTop * 4));   // the seed pass writes up to 2 x 32 partitions
   TOD_HIP(ws->thr.reserve((size_t)nq_pad * 4 * 2));
   TOD_HIP(ws->cand.reserve((size_t)nq_pad * kCandCap * 4));
+  TOD_HIP(ws->slots.reserve((size_t)nq_pad * n_parts * kSlot * 4));        // 2 x 512 partitions x 8 rows x 4 B x 512 queries per query block: 16 MB whatever nq
+  TOD_HIP(ws->slot_cnt.reserve((size_t)nq_pad * n_parts * 4));
   float* qnorm = ws->q_eps.as<float>() + nq_pad;
   // queries: bf16 image pre-scaled by -2 (a power of two: no extra rounding), |q|^2, eps
   hipLaunchKernelGGL(l2_prepare_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, d_q, nq, nq_pad, -2.0f,
-                     ws->q_bf16.as<uint16_t>(), qnorm, (uint32_t*)nullptr);
+                     ws->q_bf16.as<uint16_t>(), qnorm, (uint32_t*)nullptr, 0);
   hipLaunchKernelGGL(l2_eps_kernel, dim3((nq_pad + 255u) / 256u), dim3(256), 0, st, qnorm, nq_pad, ws->scal.as<uint32_t>(),
                      ws->q_eps.as<float>());
   TOD_HIP(hipMemsetAsync(ws->cand_cnt.p, 0, (size_t)nq_pad * 4, st));
@@ -460,16 +561,22 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
   const uint32_t sample_stride = fast ? n_tiles / sample_tiles : 1u;
   const float* seed = nullptr;
   bool one_gemm = false;
+  // diagnostics: a threshold below every score, so that pass 2 runs its GEMM and finds nothing (timing the bare pass; results are garbage)
+  static const bool no_candidates = getenv("TODHIP_L2_NO_CANDIDATES") != nullptr;
+  const float margin = no_candidates ? -1e30f : 2.f;
   if ((fast || n_tiles >= 8u * sample_tiles) && sample_tiles * kTileRows >= k_eff) {
     static const uint32_t env_sc = getenv("TODHIP_L2_SEED_CHUNKS") ? (uint32_t)atoi(getenv("TODHIP_L2_SEED_CHUNKS")) : 0u;   // tuning knob
     const uint32_t s_chunks = std::min(sample_tiles, fast ? (env_sc ? std::min(env_sc, n_chunks) : n_chunks) : 32u), s_tpc = (sample_tiles + s_chunks - 1u) / s_chunks;
     const uint32_t s_used = (sample_tiles + s_tpc - 1u) / s_tpc;
-    hipLaunchKernelGGL(gemm1, dim3(s_used, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(), ws->db_norm.as<float>(),
-                       sample_tiles, s_tpc, sample_stride, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
-                       (const float*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    // the one-GEMM path's seed needs no exact k-th smallest of the sample: the k-th smallest of the partitions' minima bounds A_k
+    // just as well and costs the GEMM's epilogue one instruction (needs k partitions with a real row: 2 s_used >= 512 here)
+    auto gemm0 = fast ? l2_gemm_kernel<1, 1> : gemm1;
+    hipLaunchKernelGGL(gemm0, dim3(s_used, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
+                       ws->db_norm.as<float>(), sample_tiles, s_tpc, sample_stride, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(),
+                       (const float*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     if (fast) {
       hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), 2u * s_used, nq,
-                         nq_pad, k_eff, (const float*)nullptr, ws->q_eps.as<float>(), 2.f, ws->thr.as<float>());
+                         nq_pad, k_eff, (const float*)nullptr, ws->q_eps.as<float>(), margin, ws->thr.as<float>());
       one_gemm = true;
     } else {
       hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), 2u * s_used, nq_pad,
@@ -482,19 +589,21 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
     if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
     hipLaunchKernelGGL(gemm1, dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(), ws->db_norm.as<float>(), n_tiles,
                        tiles_per_chunk, 1u, ws->q_bf16.as<uint16_t>(), nq_pad, ws->part.as<float>(), seed, (uint32_t*)nullptr,
-                       (uint32_t*)nullptr);
+                       (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; slot = -1; }
     hipLaunchKernelGGL(l2_threshold_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, ws->part.as<float>(), n_parts, nq, nq_pad,
-                       k_eff, seed, ws->q_eps.as<float>(), 2.f, ws->thr.as<float>());
+                       k_eff, seed, ws->q_eps.as<float>(), margin, ws->thr.as<float>());
   } else if (ctx->time_kernels) {
     int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc;
   }
   hipLaunchKernelGGL((l2_gemm_kernel<2, 4>), dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
                      ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, 1u, ws->q_bf16.as<uint16_t>(), nq_pad, (float*)nullptr,
-                     ws->thr.as<float>(), ws->cand.as<uint32_t>(), ws->cand_cnt.as<uint32_t>());
+                     ws->thr.as<float>(), ws->slots.as<uint32_t>(), ws->slot_cnt.as<uint32_t>(), ws->cand.as<uint32_t>(),
+                     ws->cand_cnt.as<uint32_t>());
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
   hipLaunchKernelGGL(l2_rerank_kernel, dim3((nq + 3u) / 4u), dim3(256), 0, st, d_q, nq, ctx->db_desc.as<float>(),
-                     ws->cand.as<uint32_t>(), ws->cand_cnt.as<uint32_t>(), k, ws->keys.as<uint64_t>(), overflow);
+                     ws->slots.as<uint32_t>(), ws->slot_cnt.as<uint32_t>(), n_parts, ws->cand.as<uint32_t>(),
+                     ws->cand_cnt.as<uint32_t>(), k, ws->keys.as<uint64_t>(), overflow);
   hipLaunchKernelGGL(l2_exact_scan_kernel, dim3(nq), dim3(256), 0, st, d_q, nq, ctx->db_desc.as<float>(), n, k,
                      (const uint32_t*)overflow, ws->keys.as<uint64_t>());
   TOD_HIP(hipGetLastError());

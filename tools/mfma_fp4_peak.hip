@@ -14,7 +14,9 @@ __device__ __forceinline__ unsigned mix(unsigned x) { x ^= x >> 16; x *= 0x7feb3
 template <int CHAINS>
 __global__ __launch_bounds__(256) void mfma_kernel(float* out, int seed) {
   i32x8 a[4], b[4];
+#pragma unroll
   for (int s = 0; s < 4; ++s)
+#pragma unroll
     for (int i = 0; i < 8; ++i) {
       a[s][i] = i < 4 ? (int)((mix(threadIdx.x * 131u + s * 17u + i + seed) & 0x88888888u) | 0x22222222u) : 0;
       b[s][i] = i < 4 ? (int)((mix(threadIdx.x * 977u + s * 29u + i * 7u + blockIdx.x) & 0x88888888u) | 0x22222222u) : 0;
