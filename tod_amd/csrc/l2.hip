@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restr
   const uint32_t q_base = blockIdx.y * kBlockQueries + wave * (kQTilesPerWave * 32u);
   const uint32_t t_begin = chunk * tiles_per_chunk, t_end = min(n_tiles, t_begin + tiles_per_chunk);
   if (t_begin >= t_end) return;
+  const uint64_t t_start = (PASS == 2 && part) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // this wave's query fragments: B[k = 16 s + 8 h + j][col r] = q^[q_base + 32 t + r][16 s + 8 h + j]
   bf16x8 bq[kQTilesPerWave][8];
@@ -296,6 +298,10 @@ __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restr
   if (PASS == 2) {
 #pragma unroll
     for (uint32_t t = 0; t < kQTilesPerWave; ++t) slot_cnt[(size_t)(q_base + 32u * t + r) * sink.n_parts + sink.part] = n_cand[t];
+    if (part && l == 0) {                                   // diagnostics (TODHIP_L2_TRACE): when each wave started and ended, 100 MHz ticks
+      uint64_t* tr = reinterpret_cast<uint64_t*>(part) + 2u * (((size_t)blockIdx.y * gridDim.x + chunk) * kWaves + wave);
+      tr[0] = t_start; tr[1] = __builtin_amdgcn_s_memrealtime();
+    }
   }
   if (PASS == 1) {
     // partition (chunk, lane half): kTop ascending scores per query
@@ -563,6 +569,8 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
   bool one_gemm = false;
   // diagnostics: a threshold below every score, so that pass 2 runs its GEMM and finds nothing (timing the bare pass; results are garbage)
   static const bool no_candidates = getenv("TODHIP_L2_NO_CANDIDATES") != nullptr;
+  // diagnostics: pass 2 leaves (start, end) of every wave in the partition buffer, see tools/l2_wave_times.py
+  static const bool trace = getenv("TODHIP_L2_TRACE") != nullptr;
   const float margin = no_candidates ? -1e30f : 2.f;
   if ((fast || n_tiles >= 8u * sample_tiles) && sample_tiles * kTileRows >= k_eff) {
     static const uint32_t env_sc = getenv("TODHIP_L2_SEED_CHUNKS") ? (uint32_t)atoi(getenv("TODHIP_L2_SEED_CHUNKS")) : 0u;   // tuning knob
@@ -597,10 +605,36 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
     int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc;
   }
   hipLaunchKernelGGL((l2_gemm_kernel<2, 4>), dim3(n_chunks, q_blocks), dim3(256), 0, st, ws->db_bf16.as<uint16_t>(),
-                     ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, 1u, ws->q_bf16.as<uint16_t>(), nq_pad, (float*)nullptr,
+                     ws->db_norm.as<float>(), n_tiles, tiles_per_chunk, 1u, ws->q_bf16.as<uint16_t>(), nq_pad, trace ? ws->part.as<float>() : (float*)nullptr,
                      ws->thr.as<float>(), ws->slots.as<uint32_t>(), ws->slot_cnt.as<uint32_t>(), ws->cand.as<uint32_t>(),
                      ws->cand_cnt.as<uint32_t>());
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
+  if (trace) {
+    const size_t n_waves = (size_t)q_blocks * n_chunks * kWaves;
+    std::vector<uint64_t> tr(2 * n_waves);
+    TOD_HIP(hipStreamSynchronize(st));
+    TOD_HIP(hipMemcpy(tr.data(), ws->part.p, tr.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t t0 = ~0ull, t1 = 0;
+    for (size_t i = 0; i < n_waves; ++i) { t0 = std::min(t0, tr[2 * i]); t1 = std::max(t1, tr[2 * i + 1]); }
+    std::vector<double> start(n_waves), end(n_waves);
+    for (size_t i = 0; i < n_waves; ++i) { start[i] = (tr[2 * i] - t0) * 0.01; end[i] = (tr[2 * i + 1] - t0) * 0.01; }
+    std::sort(start.begin(), start.end()); std::sort(end.begin(), end.end());
+    auto pct = [&](const std::vector<double>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
+    for (uint32_t y = 0; y < q_blocks; ++y) {
+      double sum = 0; size_t cnt = 0; double byx[8] = {0}; size_t nx[8] = {0}; double byw[4] = {0};
+      for (uint32_t x = 0; x + 1 < n_chunks; ++x) for (uint32_t w = 0; w < kWaves; ++w) {
+        const double e = (tr[2 * (((size_t)y * n_chunks + x) * kWaves + w) + 1] - t0) * 0.01;
+        sum += e; ++cnt; byx[x & 7] += e; ++nx[x & 7]; byw[w] += e;
+      }
+      fprintf(stderr, "[todhip l2 trace]   query block %u: mean end %.1f us; by chunk %% 8:", y, sum / cnt);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %.1f", byx[i] / nx[i]);
+      fprintf(stderr, "; by wave:");
+      for (int i = 0; i < 4; ++i) fprintf(stderr, " %.1f", byw[i] / (cnt / 4));
+      fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "[todhip l2 trace] pass 2: %zu waves, span %.1f us; wave start p50 %.1f p99 %.1f max %.1f us; wave end min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us\n",
+            n_waves, (t1 - t0) * 0.01, pct(start, 0.5), pct(start, 0.99), start.back(), end.front(), pct(end, 0.1), pct(end, 0.5), pct(end, 0.9), end.back());
+  }
   hipLaunchKernelGGL(l2_rerank_kernel, dim3((nq + 3u) / 4u), dim3(256), 0, st, d_q, nq, ctx->db_desc.as<float>(),
                      ws->slots.as<uint32_t>(), ws->slot_cnt.as<uint32_t>(), n_parts, ws->cand.as<uint32_t>(),
                      ws->cand_cnt.as<uint32_t>(), k, ws->keys.as<uint64_t>(), overflow);
