@@ -194,6 +194,8 @@ struct GuessGenerator {
     params.declare<float>("sensor_error", "The error (in meters) from the Kinect", 0.01f);
     params.declare<bool>("visualize", "If true, display temporary info through highgui", false);
     params.declare<std::string>("db", "The DB to get data from, as a JSON string").required(true);
+    // extension, only read on the 2D-only branch (points3d empty and K given): the reprojection threshold of todhip_verify_2d
+    params.declare<float>("reprojection_error", "2D-only branch: reprojection threshold in pixels", 3.0f);
   }
   // GuessGenerator.cpp:83-99
   static void declare_io(const ecto::tendrils&, ecto::tendrils& inputs, ecto::tendrils& outputs) {
@@ -205,6 +207,9 @@ struct GuessGenerator {
                                                         "point, a 1 by n 3 channel matrix (for x,y and z)");
     inputs.declare<std::map<ObjectId, float> >("spans", "For each found object, its span based on known features.");
     inputs.declare<std::vector<ObjectId> >("object_ids", "The ids used in the matches");
+    // extension: with an empty points3d the reference does nothing (:147-152 "Only use 2d to 3d matching // TODO"); given the camera
+    // matrix the cell solves that PnP problem with todhip_verify_2d instead. Left unconnected, the branch stays empty as in the reference.
+    inputs.declare<cv::Mat>("K", "The camera matrix (3 x 3, float or double); only used when points3d is empty", cv::Mat());
 #ifdef TOD_AMD_WITH_ORK
     outputs.declare<std::vector<object_recognition_core::common::PoseResult> >("pose_results", "The results of object recognition");
 #else
@@ -218,6 +223,7 @@ struct GuessGenerator {
     min_inliers_ = params.get<unsigned int>("min_inliers");
     n_ransac_iterations_ = params.get<unsigned int>("n_ransac_iterations");
     sensor_error_ = params.get<float>("sensor_error");
+    reprojection_error_ = params.get<float>("reprojection_error");
 #ifdef TOD_AMD_WITH_ORK
     db_ = object_recognition_core::db::ObjectDbParameters(params.get<std::string>("db")).generateDb();
 #endif
@@ -238,7 +244,9 @@ struct GuessGenerator {
 #else
     std::vector<PoseOut> pose_results;
 #endif
-    if (!point_cloud.empty()) {                                          // :147-152: the 2D-only branch is a TODO
+    const cv::Mat Kmat = inputs.get<cv::Mat>("K");
+    const bool with_cloud = !point_cloud.empty();
+    if (with_cloud || !Kmat.empty()) {                                   // :147-152: without a cloud AND without K, nothing (the reference's TODO)
       const uint32_t nq = (uint32_t)matches.size();
       if (keypoints.size() < matches.size())                               // the library reads nq keypoints
         throw std::runtime_error("GuessGenerator: fewer keypoints than match lists");
@@ -259,8 +267,18 @@ struct GuessGenerator {
         std::map<ObjectId, float>::const_iterator it = spans.find(object_ids_in[o]);   // :186
         if (it != spans.end()) span_by_index[o] = it->second;
       }
-      cv::Mat cloud = point_cloud.isContinuous() ? point_cloud : point_cloud.clone();
-      todhip_verify_params prm = {min_inliers_, n_ransac_iterations_, sensor_error_};
+      cv::Mat cloud;
+      float K9[9] = {0};
+      if (with_cloud) {
+        cloud = point_cloud.isContinuous() ? point_cloud : point_cloud.clone();
+      } else {
+        if (Kmat.rows != 3 || Kmat.cols != 3 || (Kmat.type() != CV_32F && Kmat.type() != CV_64F))
+          throw std::runtime_error("GuessGenerator: K must be a 3 x 3 float or double matrix");
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j)
+            K9[3 * i + j] = Kmat.type() == CV_32F ? Kmat.template ptr<float>(i)[j] : (float)Kmat.template ptr<double>(i)[j];
+      }
+      todhip_verify_params prm = {min_inliers_, n_ransac_iterations_, with_cloud ? sensor_error_ : reprojection_error_};
       // the reference has no limit on the number of poses: on TODHIP_ECAPACITY the frame is redone from the same
       // generator state with twice the room
       std::vector<todhip_pose> poses;
@@ -272,9 +290,13 @@ struct GuessGenerator {
         inl.resize(cap * (keypoints.size() + 1));
         n_poses = (uint32_t)poses.size(); n_inl = (uint32_t)inl.size();
         todhip_rng rng = rng_;
-        rc = todhip_verify(ctx_, kp.data(), nq, cloud.template ptr<float>(0), (uint32_t)cloud.rows, (uint32_t)cloud.cols,
-                           row_ptr.data(), flat.data(), xyz.data(), span_by_index.data(), (uint32_t)span_by_index.size(), &prm,
-                           &rng, poses.data(), &n_poses, inl.data(), &n_inl);
+        if (with_cloud)
+          rc = todhip_verify(ctx_, kp.data(), nq, cloud.template ptr<float>(0), (uint32_t)cloud.rows, (uint32_t)cloud.cols,
+                             row_ptr.data(), flat.data(), xyz.data(), span_by_index.data(), (uint32_t)span_by_index.size(), &prm,
+                             &rng, poses.data(), &n_poses, inl.data(), &n_inl);
+        else
+          rc = todhip_verify_2d(ctx_, kp.data(), nq, K9, row_ptr.data(), flat.data(), xyz.data(), span_by_index.data(),
+                                (uint32_t)span_by_index.size(), &prm, &rng, poses.data(), &n_poses, inl.data(), &n_inl);
         if (rc == TODHIP_OK) rng_ = rng;
       }
       if (rc != TODHIP_OK) throw std::runtime_error("todhip_verify failed");
@@ -305,7 +327,7 @@ struct GuessGenerator {
   todhip_ctx* ctx_ = nullptr;
   todhip_rng rng_;
   unsigned int min_inliers_ = 15, n_ransac_iterations_ = 1000;
-  float sensor_error_ = 0.01f;
+  float sensor_error_ = 0.01f, reprojection_error_ = 3.0f;
 #ifdef TOD_AMD_WITH_ORK
   object_recognition_core::db::ObjectDbPtr db_;
 #endif

@@ -212,6 +212,27 @@ int todhip_orb_batch_device(todhip_ctx*, const void* d_gray, uint32_t n_frames, 
                             uint32_t stride, uint32_t n_features, uint32_t n_levels, float scale_factor, const int8_t* pattern,
                             void* d_kp_xy, void* d_kp_aux, void* d_desc, uint32_t cap, uint32_t* n_out);
 
+/* ---- stage C without depth (SURVEY 8(f) row N4 b) -------------------------------------------------------- */
+/* The branch GuessGenerator::process leaves empty when `points3d` is empty (GuessGenerator.cpp:147-152 "Only use 2d to 3d
+ * matching // TODO"; doc/source/index.rst:36-46: a PnP problem the reference never plugged in). NOT a reference result:
+ * defined here, checked bit for bit by the tests' CPU definition (oracle/pnp_oracle.c), parity unpinned by construction.
+ *   inputs   kp_xy nq x 2 keypoint pixels; K9 the camera matrix, row-major; matches in CSR form as produced by todhip_match
+ *            (matches_xyz = the model point of each match); spans per object index. prm->sensor_error is the reprojection
+ *            threshold in PIXELS here, prm->n_ransac_iterations the (fixed) number of hypotheses per object.
+ *   per object (ascending index, matches clustered in CSR order, at least max(3, min_inliers) of them):
+ *     hypothesis h = 0 .. n - 1: a sample of three matches, pairwise with keypoints > 20 px apart and distinct model points
+ *       within the object's span, picked by a counter-based hash of (seed, object, h, attempt <= 16); Grunert's P3P in f64 on
+ *       it (up to 4 poses); consensus set of a pose = matches whose model point reprojects within the threshold, in front of
+ *       the camera. The largest consensus set wins, the first (h, root) on ties; it must reach min_inliers.
+ *     the winner is refined by 5 Gauss-Newton steps on its consensus set and the consensus set recomputed; the pose is
+ *       reported if that still reaches min_inliers. One pose per object.
+ *   rng: ONE draw per call supplies the seed (hypotheses do not walk the stream, which is what lets them run side by side).
+ *   outputs as todhip_verify: poses (object -> camera), inlier_kp = keypoint indices of each pose's consensus set, ascending. */
+int todhip_verify_2d(todhip_ctx*, const float* kp_xy, uint32_t nq, const float* K9, const uint32_t* row_ptr,
+                     const todhip_dmatch* matches, const float* matches_xyz, const float* spans, uint32_t n_objs,
+                     const todhip_verify_params*, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp,
+                     uint32_t* n_inlier_kp);
+
 /* ---- training ----------------------------------------------------------------- */
 /* Per-observation arithmetic of the reference's Trainer cell (src/training/Trainer.cpp:121-187, training.cpp:57-195):
  * ORB on the masked view (the reference uses cv::ORB defaults: 500 features, 8 levels, scale 1.2 -- :148-149),

@@ -97,6 +97,13 @@ int orc_verify(const float* kp_xy, uint32_t nq, const float* cloud_xyz, uint32_t
                orc_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp,
                orc_round_trace* rounds, uint32_t* n_rounds);
 
+/* ---- stage C without depth (oracle/pnp_oracle.c): the reference's TODO branch, DEFINED there; parity unpinned by construction.
+ * prm->sensor_error is the reprojection threshold in pixels; best_hyp / best_count: optional, n_obj entries each. */
+int orc_verify_2d(const float* kp_xy, uint32_t nq, const float* K9, const uint32_t* row_ptr, const orc_dmatch* matches,
+                  const float* matches_xyz, const float* spans, uint32_t n_obj, const orc_verify_params* prm, orc_rng* rng,
+                  orc_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp, uint32_t* best_hyp,
+                  uint32_t* best_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,29 @@ int main(int argc, char** argv) {
     }
     dump(dir + "/out_poses.bin", rt);
     dump(dir + "/out_inliers.bin", inl);
+    // ---- the same frame without a cloud: nothing, as in the reference (GuessGenerator.cpp:147-152) ...
+    gi["points3d"] << cv::Mat();
+    if (guess.process(gi, go) != ecto::OK) return 8;
+    if (!go.get<std::vector<tod_amd::PoseOut> >("pose_results").empty()) return 8;
+    // ... and with the camera matrix connected: the PnP extension (todhip_verify_2d)
+    cv::Mat Km = cv::Mat(3, 3, CV_64F);
+    const double Kv[9] = {525.0, 0, 320.0, 0, 525.0, 240.0, 0, 0, 1};
+    std::memcpy(Km.ptr<double>(0), Kv, sizeof(Kv));
+    gi["K"] << Km;
+    if (guess.process(gi, go) != ecto::OK) return 8;
+    {
+      std::vector<float> rt2;
+      std::vector<uint32_t> inl2;
+      for (const tod_amd::PoseOut& p : go.get<std::vector<tod_amd::PoseOut> >("pose_results")) {
+        for (float v : p.R) rt2.push_back(v);
+        for (float v : p.T) rt2.push_back(v);
+        inl2.push_back((uint32_t)std::stoul(p.object_id.substr(7)));
+        inl2.push_back((uint32_t)p.inlier_keypoints.size());
+        for (unsigned v : p.inlier_keypoints) inl2.push_back(v);
+      }
+      dump(dir + "/out_poses_2d.bin", rt2);
+      dump(dir + "/out_inliers_2d.bin", inl2);
+    }
     const std::vector<cv::Mat>& Rs = go.get<std::vector<cv::Mat> >("Rs");
     std::cout << "adapter ok: " << dist.size() << " matches, " << poses.size() << " poses, " << Rs.size() << " Rs\n";
     // a non-LSH search type must throw, as DescriptorMatcher.cpp:182-186 does

@@ -14,6 +14,7 @@
 
 #define CV_8U 0
 #define CV_32F 5
+#define CV_64F 6
 #define CV_32FC3 21
 
 namespace cv {
@@ -25,7 +26,7 @@ class Mat {
   int rows, cols;
   Mat() : rows(0), cols(0), type_(CV_8U) {}
   Mat(int r, int c, int type) : rows(r), cols(c), type_(type), buf_(new std::vector<uint8_t>((size_t)r * c * esz(type))) {}
-  static size_t esz(int type) { return type == CV_8U ? 1 : type == CV_32F ? 4 : 12; }
+  static size_t esz(int type) { return type == CV_8U ? 1 : type == CV_32F ? 4 : type == CV_64F ? 8 : 12; }
   bool empty() const { return rows == 0 || cols == 0; }
   bool isContinuous() const { return true; }
   int type() const { return type_; }

@@ -242,6 +242,33 @@ def verify(kp_xy, cloud, row_ptr, matches, matches_xyz, spans_per_obj, min_inlie
     return rc, out, [rounds[i] for i in range(n_rounds.value)]
 
 
+def verify_2d(kp_xy, K, row_ptr, matches, matches_xyz, spans_per_obj, min_inliers, n_iter, err_px, rng, max_poses=64):
+    """oracle/pnp_oracle.c: the 2D-only branch (no cloud). Returns rc, poses, (best_hyp, best_count) per object."""
+    kp = np.ascontiguousarray(kp_xy, np.float32)
+    K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+    row_ptr = np.ascontiguousarray(row_ptr, np.uint32)
+    matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+    mxyz = np.ascontiguousarray(matches_xyz, np.float32)
+    sp = np.ascontiguousarray(spans_per_obj, np.float32)
+    prm = VerifyParams(min_inliers, n_iter, err_px)
+    poses = (Pose * max_poses)()
+    n_poses = C.c_uint32(max_poses)
+    cap = max(len(kp), 1) * max_poses
+    inl = np.zeros(cap, np.uint32)
+    n_inl = C.c_uint32(cap)
+    bh = np.zeros(len(sp), np.uint32); bc = np.zeros(len(sp), np.uint32)
+    rc = lib().orc_verify_2d(_p(kp, C.c_float), C.c_uint32(len(kp)), _p(K9, C.c_float), _p(row_ptr, C.c_uint32),
+                             matches.ctypes.data_as(C.c_void_p), _p(mxyz, C.c_float), _p(sp, C.c_float), C.c_uint32(len(sp)),
+                             C.byref(prm), C.byref(rng), poses, C.byref(n_poses), _p(inl, C.c_uint32), C.byref(n_inl),
+                             _p(bh, C.c_uint32), _p(bc, C.c_uint32))
+    out = []
+    for i in range(n_poses.value):
+        p = poses[i]
+        out.append(dict(object=int(p.object), R=np.array(p.R[:], np.float32).reshape(3, 3),
+                        t=np.array(p.t[:], np.float32), inliers=inl[p.inlier_begin:p.inlier_end].copy()))
+    return rc, out, (bh, bc)
+
+
 # ------------------------------------------------------------------------------------------ stage A
 def orb(gray, n_features=1000, n_levels=3, scale_factor=1.2, pattern=None, mask=None):
     """oracle/orb_oracle.c. Returns kp_xy f32[n,2], aux f32[n,4] (size, angle, response, octave), desc u8[n,32],

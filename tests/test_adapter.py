@@ -46,6 +46,8 @@ def test_adapter_frame_equals_c_abi():
         dist = np.fromfile(os.path.join(d, "out_dist.bin"), np.float32)
         rt = np.fromfile(os.path.join(d, "out_poses.bin"), np.float32).reshape(-1, 12)
         inl = np.fromfile(os.path.join(d, "out_inliers.bin"), np.uint32)
+        rt2 = np.fromfile(os.path.join(d, "out_poses_2d.bin"), np.float32).reshape(-1, 12)
+        inl2 = np.fromfile(os.path.join(d, "out_inliers_2d.bin"), np.uint32)
     ctx = capi.Context(0)
     spans = ctx.db_load(desc, pts, off)
     row_ptr, gm, xyz = ctx.match(fr["q_desc"], 5, 35)          # the cell's k is 5 (DescriptorMatcher.cpp:211)
@@ -57,6 +59,14 @@ def test_adapter_frame_equals_c_abi():
     assert np.array_equal(rt[0, :9].reshape(3, 3), poses[0]["R"]) and np.array_equal(rt[0, 9:], poses[0]["t"])
     assert inl[0] == poses[0]["object"] == 2 and inl[1] == len(poses[0]["inliers"])
     assert np.array_equal(inl[2:], poses[0]["inliers"])
+    # the cell's 2D-only branch (points3d empty, K connected) == todhip_verify_2d continuing the cell's rand() stream: the 3D call
+    # above left `rng` where the cell's generator stood after its first frame, and the cloudless, K-less call in between draws nothing
+    K = np.array([[525.0, 0, 320.0], [0, 525.0, 240.0], [0, 0, 1]], np.float32)
+    poses2 = ctx.verify_2d(fr["kp_xy"], K, row_ptr, gm, xyz, spans, 8, 2500, 3.0, rng)
+    assert len(poses2) == len(rt2) == 1 and poses2[0]["object"] == inl2[0] == 2
+    assert np.array_equal(rt2[0, :9].reshape(3, 3), poses2[0]["R"]) and np.array_equal(rt2[0, 9:], poses2[0]["t"])
+    assert inl2[1] == len(poses2[0]["inliers"]) and np.array_equal(inl2[2:], poses2[0]["inliers"])
+    assert np.abs(poses2[0]["R"] - poses[0]["R"]).max() < 0.05 and np.abs(poses2[0]["t"] - poses[0]["t"]).max() < 0.02   # the same pose, from pixels alone
     # the FeatureDescriptor cell == the C ABI's ORB, with and without the cell's mask input
     for tag, mk in (("", None), ("_masked", mask)):
         kp, aux, de = ctx.orb(image, 500, 3, 1.2, mask=mk)

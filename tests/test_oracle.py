@@ -246,3 +246,34 @@ def test_ratio_test_definition_against_numpy():
             want = want[:next((i for i, r in enumerate(rows[:k]) if d[qi, r] > radius), k)] if want else want
             got = (off[m["imgIdx"][row_ptr[qi]:row_ptr[qi + 1]]].astype(np.int64) + m["trainIdx"][row_ptr[qi]:row_ptr[qi + 1]]).tolist()
             assert got == want, (k, radius, ratio, qi)
+
+
+def test_verify_2d_definition_recovers_known_poses_and_its_p3p_is_a_p3p():
+    """oracle/pnp_oracle.c DEFINES the 2D-only branch (GuessGenerator.cpp:147-152 is a TODO in the reference: parity
+    unpinned by construction). Checked here against what it claims to be: the poses of a two-object scene come out within
+    the noise of the keypoints, every reported inlier reprojects within the threshold under the reported pose, the rand()
+    stream advances by exactly one draw, and with noise-free keypoints the pose is exact to float precision."""
+    K = np.array([[525.0, 0, 320.0], [0, 525.0, 240.0], [0, 0, 1]], np.float32)
+    for noise, tol_R, tol_t in ((0.002, 0.03, 0.012), (0.0, 2e-4, 2e-4)):
+        sc = synth.make_verify_scene(600, n_objects=5, per_object=300, visible=((1, 0.30), (3, 0.22)), matches_per_kp=3, seed=4, noise=noise)
+        rng = O.rng_new(1)
+        d0 = rng.draws
+        rc, poses, (bh, bc) = O.verify_2d(sc["kp_xy"], K, sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 12, 400, 3.0, rng)
+        assert rc == 0 and rng.draws == d0 + 1
+        assert sorted(p["object"] for p in poses) == [1, 3]
+        for p in poses:
+            R_true, t_true = sc["poses"][p["object"]]
+            assert np.abs(p["R"] - R_true).max() < tol_R and np.abs(p["t"] - t_true).max() < tol_t, (noise, p["R"], R_true, p["t"], t_true)
+            assert np.abs(p["R"] @ p["R"].T - np.eye(3)).max() < 1e-5 and np.linalg.det(p["R"]) > 0.999
+            assert len(p["inliers"]) >= 12 and (np.diff(p["inliers"].astype(np.int64)) > 0).all()
+            # every inlier keypoint has a match to this object whose model point reprojects within 3 px
+            for q in p["inliers"]:
+                ms = range(sc["row_ptr"][q], sc["row_ptr"][q + 1])
+                errs = []
+                for m in ms:
+                    if sc["matches"][m]["imgIdx"] != p["object"]:
+                        continue
+                    Xc = p["R"].astype(np.float64) @ sc["matches_xyz"][m].astype(np.float64) + p["t"].astype(np.float64)
+                    errs.append(np.hypot(525.0 * Xc[0] / Xc[2] + 320.0 - sc["kp_xy"][q, 0], 525.0 * Xc[1] / Xc[2] + 240.0 - sc["kp_xy"][q, 1]))
+                assert errs and min(errs) < 3.0 + 1e-3
+        assert bc[1] >= 100 and bc[3] >= 80 and bh[1] < 400 and bc[0] < 12 and bc[2] < 12

@@ -60,7 +60,7 @@ EXPORTS = [
     "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
     "todhip_match_l2", "todhip_match_l2_device",
     "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
-    "todhip_rescale_depth", "todhip_rescale_depth_device",
+    "todhip_rescale_depth", "todhip_rescale_depth_device", "todhip_verify_2d",
 ]
 
 _lib = None
@@ -260,6 +260,28 @@ class Context:
             out.append(dict(object=int(p.object), R=np.array(p.R[:], np.float32).reshape(3, 3),
                             t=np.array(p.t[:], np.float32), inliers=inl[p.inlier_begin:p.inlier_end].copy()))
         return out
+
+    def verify_2d(self, kp_xy, K, row_ptr, matches, matches_xyz, spans, min_inliers, n_iter, err_px, rng, max_poses=64):
+        """The 2D-only branch (no cloud): todhip_verify_2d. err_px: reprojection threshold in pixels."""
+        kp = np.ascontiguousarray(kp_xy, np.float32)
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        row_ptr = np.ascontiguousarray(row_ptr, np.uint32)
+        matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+        mxyz = np.ascontiguousarray(matches_xyz, np.float32)
+        sp = np.ascontiguousarray(spans, np.float32)
+        prm = VerifyParams(min_inliers, n_iter, err_px)
+        poses = (Pose * max_poses)()
+        n_poses = C.c_uint32(max_poses)
+        cap = max(len(kp), 1) * max_poses
+        inl = np.zeros(cap, np.uint32)
+        n_inl = C.c_uint32(cap)
+        rc = lib().todhip_verify_2d(self._h, _np_ptr(kp), C.c_uint32(len(kp)), _np_ptr(K9), _np_ptr(row_ptr),
+                                    matches.ctypes.data_as(C.c_void_p), _np_ptr(mxyz), _np_ptr(sp), C.c_uint32(len(sp)),
+                                    C.byref(prm), C.byref(rng), poses, C.byref(n_poses), _np_ptr(inl), C.byref(n_inl))
+        _check(rc, "todhip_verify_2d")
+        return [dict(object=int(poses[i].object), R=np.array(poses[i].R[:], np.float32).reshape(3, 3),
+                     t=np.array(poses[i].t[:], np.float32),
+                     inliers=inl[poses[i].inlier_begin:poses[i].inlier_end].copy()) for i in range(n_poses.value)]
 
     def verify_device(self, d_kp_xy, nq, d_cloud, H, W, d_counts, d_matches, d_xyz, k, spans, min_inliers, n_iter,
                       err, rng, max_poses=64):

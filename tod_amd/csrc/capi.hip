@@ -51,6 +51,7 @@ void todhip_destroy(todhip_ctx* ctx) {
   tod_verify_ws_free(ctx);
   tod_orb_ws_free(ctx);
   tod_l2_ws_free(ctx);
+  tod_pnp_ws_free(ctx);
   ctx->db_desc.release(); ctx->db_pts.release(); ctx->db_obj_off.release();
   ctx->m_q.release(); ctx->m_part.release(); ctx->m_keys.release(); ctx->m_counts.release();
   ctx->m_matches.release(); ctx->m_xyz.release(); ctx->m_bound.release(); ctx->h_stage.release();

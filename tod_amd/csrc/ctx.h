@@ -105,6 +105,7 @@ struct todhip_ctx {
   void* verify_ws = nullptr;
   void* orb_ws = nullptr;
   void* l2_ws = nullptr;
+  void* pnp_ws = nullptr;
 };
 
 // match.hip
@@ -122,6 +123,7 @@ int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_s
 // verify.hip / orb.hip
 void tod_verify_ws_free(todhip_ctx* ctx);
 void tod_l2_ws_free(todhip_ctx* ctx);
+void tod_pnp_ws_free(todhip_ctx* ctx);      // pnp.hip
 int tod_l2_db_prepare(todhip_ctx* ctx);      // l2.hip: bf16 image + norms of a 128 x f32 DB resident in db_desc
 void tod_orb_ws_free(todhip_ctx* ctx);
 int tod_orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, uint32_t H, uint32_t W, uint32_t stride,
