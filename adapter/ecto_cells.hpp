@@ -104,6 +104,15 @@ struct DescriptorMatcher
     if (json_string(js, "type", "") != "LSH") throw std::runtime_error("Search not implemented for that type");
     ctx_ = shared_context();
     if (todhip_set_ratio_test(ctx_, lowe_ratio_) != TODHIP_OK) throw std::runtime_error("lowe_ratio must lie in [0, 1]");
+    // "approximate": 1 (a key of this adapter's own) makes those three parameters mean what they mean to the reference: an
+    // LSH index of n_tables x key_size-bit keys probed multi_probe_level bits deep (todhip_set_lsh; FLANN's scheme, own key bits)
+    if (json_number(js, "approximate", 0) != 0) {
+      if (todhip_set_lsh(ctx_, (uint32_t)json_number(js, "n_tables", 0), (uint32_t)json_number(js, "key_size", 0),
+                         (uint32_t)json_number(js, "multi_probe_level", 0)) != TODHIP_OK)
+        throw std::runtime_error("LSH parameters out of range (n_tables <= 32, key_size <= 24, multi_probe_level <= 3)");
+    } else if (todhip_set_lsh(ctx_, 0, 0, 0) != TODHIP_OK) {
+      throw std::runtime_error("todhip_set_lsh failed");
+    }
   }
   // DescriptorMatcher.cpp:60-129. `docs`: per object the "descriptors" (n x 32 CV_8U) and "points" attachments.
   struct ObjectModel { ObjectId id; cv::Mat descriptors, points; };

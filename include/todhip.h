@@ -104,6 +104,19 @@ int todhip_match(todhip_ctx*, const uint8_t* q_desc, uint32_t nq, uint32_t k, ui
  * orc_match_ratio (there is no reference behaviour to be identical to). */
 int todhip_set_ratio_test(todhip_ctx*, float ratio);
 
+/* Optional LSH-approximate mode (SURVEY 8(f) N4 c). The reference's matcher is cv::FlannBasedMatcher over
+ * cv::flann::LshIndexParams(n_tables, key_size, multi_probe_level) (DescriptorMatcher.cpp:175-180; conf/detection.ork:32-38:
+ * 10 tables, 16-bit keys, level 1); this library answers that configuration with the EXACT search by default (a superset of
+ * what any LSH index returns). With n_tables > 0 every todhip_match* form on 32-byte descriptors ranks, instead of the whole
+ * shard, only the rows an index of FLANN's published scheme turns up: per table a key of key_size descriptor bits (table t uses
+ * the first key_size entries of a Fisher-Yates shuffle of 0..255 driven by a 32-bit mix of (t, step): FLANN draws them from
+ * rand(), which cannot be reproduced -- parity unpinned, the CPU checker is oracle/lsh_oracle.c); a query's candidates are the
+ * rows whose key differs from its own in at most multi_probe_level bits in at least one table; the k nearest of those by exact
+ * distance, ties by row. Radius cut, ratio test (on the candidates' two nearest) and the sharded forms work as before.
+ * n_tables = 0 switches back to the exact search. Limits: n_tables <= 32, key_size <= 24, multi_probe_level <= 3.
+ * May be called before or after todhip_db_load (the index is built for the resident shard either way). */
+int todhip_set_lsh(todhip_ctx*, uint32_t n_tables, uint32_t key_size, uint32_t multi_probe_level);
+
 /* Device-resident form of the same call (inputs already in HBM, outputs stay in HBM):
  * d_counts[nq] (matches kept per query), d_matches[nq*k], d_matches_xyz[nq*k*3], fixed stride k. */
 int todhip_match_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t k, uint32_t radius,

@@ -97,6 +97,12 @@ int orc_verify(const float* kp_xy, uint32_t nq, const float* cloud_xyz, uint32_t
                orc_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp,
                orc_round_trace* rounds, uint32_t* n_rounds);
 
+/* ---- the optional LSH-approximate matcher mode (oracle/lsh_oracle.c): FLANN's published scheme with this repo's own choice of
+ * key bits; parity unpinned (OpenCV's FLANN is not in the reference tree) */
+void orc_lsh_key_bits(uint32_t table, uint32_t key_size, uint8_t* pos);
+void orc_lsh_knn_keys(const uint8_t* db_desc, uint64_t n_db, const uint8_t* q_desc, uint32_t nq, uint32_t k, uint32_t n_tables,
+                      uint32_t key_size, uint32_t multi_probe_level, uint64_t* keys, uint32_t* n_candidates);
+
 /* ---- stage C without depth (oracle/pnp_oracle.c): the reference's TODO branch, DEFINED there; parity unpinned by construction.
  * prm->sensor_error is the reprojection threshold in pixels; best_hyp / best_count: optional, n_obj entries each. */
 int orc_verify_2d(const float* kp_xy, uint32_t nq, const float* K9, const uint32_t* row_ptr, const orc_dmatch* matches,

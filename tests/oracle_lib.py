@@ -106,6 +106,17 @@ def knn_keys(db, q, k):
     return keys
 
 
+def lsh_knn_keys(db, q, k, n_tables, key_size, level):
+    """oracle/lsh_oracle.c: keys over each query's LSH candidate set, and the sizes of those sets."""
+    db = np.ascontiguousarray(db, np.uint8)
+    q = np.ascontiguousarray(q, np.uint8)
+    keys = np.zeros((q.shape[0], k), np.uint64)
+    n_cand = np.zeros(q.shape[0], np.uint32)
+    lib().orc_lsh_knn_keys(_p(db, C.c_uint8), C.c_uint64(db.shape[0]), _p(q, C.c_uint8), C.c_uint32(q.shape[0]), C.c_uint32(k),
+                           C.c_uint32(n_tables), C.c_uint32(key_size), C.c_uint32(level), _p(keys, C.c_uint64), _p(n_cand, C.c_uint32))
+    return keys, n_cand
+
+
 def match(db, obj_off, db_pts, q, k, radius, ratio=0.0):
     db = np.ascontiguousarray(db, np.uint8)
     q = np.ascontiguousarray(q, np.uint8)

@@ -277,3 +277,31 @@ def test_verify_2d_definition_recovers_known_poses_and_its_p3p_is_a_p3p():
                     errs.append(np.hypot(525.0 * Xc[0] / Xc[2] + 320.0 - sc["kp_xy"][q, 0], 525.0 * Xc[1] / Xc[2] + 240.0 - sc["kp_xy"][q, 1]))
                 assert errs and min(errs) < 3.0 + 1e-3
         assert bc[1] >= 100 and bc[3] >= 80 and bh[1] < 400 and bc[0] < 12 and bc[2] < 12
+
+
+def test_lsh_definition_against_numpy():
+    """oracle/lsh_oracle.c (the checker of todhip_set_lsh; FLANN's scheme, own key bits, parity unpinned) against a numpy restatement
+    of the same definition, and its structural properties: every table's key bits are distinct, level = key_size admits every row
+    (so the result is the exact k-NN), level 0 with one table admits exactly the rows with the query's key."""
+    import ctypes as C
+    rng = np.random.Generator(np.random.PCG64(11))
+    db = rng.integers(0, 256, (3000, 32), dtype=np.uint8)
+    q = db[rng.integers(0, 3000, 20)] ^ (np.packbits(rng.random((20, 256)) < 0.05, axis=1, bitorder="little"))
+    bits_db = np.unpackbits(db, axis=1, bitorder="little"); bits_q = np.unpackbits(q, axis=1, bitorder="little")
+    dist = (bits_db[None, :, :] != bits_q[:, None, :]).sum(2)
+    for tables, ks, level in ((3, 10, 1), (1, 6, 0), (5, 12, 2)):
+        cand = np.zeros((20, 3000), bool)
+        for t in range(tables):
+            pos = np.zeros(ks, np.uint8)
+            O.lib().orc_lsh_key_bits(C.c_uint32(t), C.c_uint32(ks), pos.ctypes.data_as(C.POINTER(C.c_uint8)))
+            assert len(set(pos.tolist())) == ks
+            cand |= (bits_db[None, :, pos] != bits_q[:, None, pos]).sum(2) <= level
+        keys, n_cand = O.lsh_knn_keys(db, q, 4, tables, ks, level)
+        assert np.array_equal(n_cand, cand.sum(1))
+        for i in range(20):
+            rows = np.flatnonzero(cand[i])
+            order = rows[np.lexsort((rows, dist[i, rows]))][:4]
+            want = [(int(dist[i, r]) << 32) | int(r) for r in order] + [2 ** 64 - 1] * (4 - len(order))
+            assert keys[i].tolist() == want
+    keys, n_cand = O.lsh_knn_keys(db, q, 3, 2, 8, 8)
+    assert (n_cand == 3000).all() and np.array_equal(keys, O.knn_keys(db, q, 3))

@@ -60,7 +60,7 @@ EXPORTS = [
     "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
     "todhip_match_l2", "todhip_match_l2_device",
     "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
-    "todhip_rescale_depth", "todhip_rescale_depth_device", "todhip_verify_2d",
+    "todhip_rescale_depth", "todhip_rescale_depth_device", "todhip_verify_2d", "todhip_set_lsh",
 ]
 
 _lib = None
@@ -147,6 +147,10 @@ class Context:
     def set_ratio_test(self, ratio):
         """Lowe's ratio test on the two nearest neighbours (0 = off, the reference's effective setting)"""
         _check(lib().todhip_set_ratio_test(self._h, C.c_float(ratio)), "todhip_set_ratio_test")
+
+    def set_lsh(self, n_tables, key_size=16, multi_probe_level=1):
+        """LSH-approximate mode of the Hamming matcher (0 tables = the exact search, the default)."""
+        _check(lib().todhip_set_lsh(self._h, C.c_uint32(n_tables), C.c_uint32(key_size), C.c_uint32(multi_probe_level)), "todhip_set_lsh")
 
     def set_kernel_timing(self, enable):
         _check(lib().todhip_set_kernel_timing(self._h, C.c_int(1 if enable else 0)), "todhip_set_kernel_timing")

@@ -52,6 +52,7 @@ void todhip_destroy(todhip_ctx* ctx) {
   tod_orb_ws_free(ctx);
   tod_l2_ws_free(ctx);
   tod_pnp_ws_free(ctx);
+  tod_lsh_ws_free(ctx);
   ctx->db_desc.release(); ctx->db_pts.release(); ctx->db_obj_off.release();
   ctx->m_q.release(); ctx->m_part.release(); ctx->m_keys.release(); ctx->m_counts.release();
   ctx->m_matches.release(); ctx->m_xyz.release(); ctx->m_bound.release(); ctx->h_stage.release();
@@ -173,6 +174,10 @@ int todhip_db_load(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, 
                          hipMemcpyHostToDevice, ctx->stream));
   if (desc_bytes == 512) {
     int rc = tod_l2_db_prepare(ctx);
+    if (rc != TODHIP_OK) return rc;
+  }
+  if (tod_lsh_enabled(ctx)) {                               // todhip_set_lsh before the load: index this shard
+    int rc = tod_lsh_build(ctx);
     if (rc != TODHIP_OK) return rc;
   }
   TOD_HIP(hipStreamSynchronize(ctx->stream));

@@ -106,6 +106,7 @@ struct todhip_ctx {
   void* orb_ws = nullptr;
   void* l2_ws = nullptr;
   void* pnp_ws = nullptr;
+  void* lsh_ws = nullptr;
 };
 
 // match.hip
@@ -124,6 +125,11 @@ int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_s
 void tod_verify_ws_free(todhip_ctx* ctx);
 void tod_l2_ws_free(todhip_ctx* ctx);
 void tod_pnp_ws_free(todhip_ctx* ctx);      // pnp.hip
+// lsh.hip: the optional LSH-approximate mode (todhip_set_lsh)
+void tod_lsh_ws_free(todhip_ctx* ctx);
+bool tod_lsh_enabled(const todhip_ctx* ctx);
+int tod_lsh_build(todhip_ctx* ctx);
+int tod_lsh_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint64_t* d_lists, uint32_t* n_lists);
 int tod_l2_db_prepare(todhip_ctx* ctx);      // l2.hip: bf16 image + norms of a 128 x f32 DB resident in db_desc
 void tod_orb_ws_free(todhip_ctx* ctx);
 int tod_orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask, uint32_t H, uint32_t W, uint32_t stride,

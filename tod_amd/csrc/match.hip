@@ -952,6 +952,7 @@ int tod_timing_end(todhip_ctx* ctx, int slot) {
 int tod_match_lists(todhip_ctx* ctx, const void* d_q, uint32_t nq, uint32_t k, uint32_t radius, uint64_t* d_lists,
                     uint32_t* n_lists) {
   if (ctx->desc_bytes != 32) return TODHIP_EINVAL;
+  if (tod_lsh_enabled(ctx)) return tod_lsh_lists(ctx, d_q, nq, k, d_lists, n_lists);   // todhip_set_lsh: candidates from the index only
   if (ctx->ratio > 0.f) radius = 256u;   // the ratio test needs the true second neighbour, however far: no radius bound in the search
   const uint32_t* q = reinterpret_cast<const uint32_t*>(d_q);
   switch (k) {
