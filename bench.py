@@ -44,6 +44,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_FP4_PEAK_TFLOPS = 10000.0                      # MI355X_MICROARCH.md: FP6/FP4 MFMA ~10 PF dense
 MFMA_BF16_PEAK_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: BF16 MFMA ~2.5 PF dense
+MFMA_BF16_MEASURED_TFLOPS = 1840.0                  # profiles/r02_mfma_bf16_peak_microbench.txt: bare loop, random bf16 operands, sustained
+L2_PASS2_US = 110.9                                 # profiles/r02_l2_kernel_stats.csv: l2_gemm_kernel<2, 4> at the C4 shape
 FLOP_PER_PAIR = 512.0                               # a 256-bit Hamming distance on the matrix cores = 256 multiply-adds
 # 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) issue at 16 lanes/clk/SIMD on gfx950 (tools/valu_peak.hip,
 # profiles/r01_valu_peak_microbench.txt: 38-40 T lane-op/s): the roof of the vector-ALU engine (--engine valu)
@@ -502,7 +504,15 @@ def run_configs(torch, capi, synth, device, args):
                  "frames_per_s": spread([1.0 / s for s in secs]), "ms_per_call": med * 1e3,
                  "roofline": {"bound": "mfma", "achieved": flops / med / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": flops / med / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                              "note": "2 Q N 128 flop of the distance table / the whole call (seed pass + GEMM pass + exact re-ranking)"},
+                              "note": "2 Q N 128 flop of the distance table / the whole call (seed pass + GEMM pass + exact re-ranking)",
+                              "gemm_pass_kernel": {"name": "l2_gemm_kernel<2,4>", "us": L2_PASS2_US, "TFLOPs": flops / (L2_PASS2_US * 1e-6) / 1e12,
+                                                   "frac_of_nominal": flops / (L2_PASS2_US * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                                   "frac_of_measured_roof": flops / (L2_PASS2_US * 1e-6) / 1e12 / MFMA_BF16_MEASURED_TFLOPS,
+                                                   "source": "profiles/r02_l2_kernel_stats.csv (rocprofv3 --kernel-trace of tools/time_l2.py, the same call)"},
+                              "measured_mfma_roof": {"TFLOPs_random_operands": MFMA_BF16_MEASURED_TFLOPS, "TFLOPs_zero_operands": 2480.0,
+                                                     "source": "profiles/r02_mfma_bf16_peak_microbench.txt (tools/mfma_bf16_peak.hip: bare "
+                                                               "v_mfma_f32_32x32x16_bf16 loop, operands in registers; the clock the chip holds "
+                                                               "depends on the data)"}},
                  "queries_with_a_match": int((cnt > 0).sum().item())}
     c4.close()
     return out
