@@ -336,28 +336,31 @@ struct GateLds {
   uint16_t *flist, *cur, *nxt, *tmp;           // m each
   uint32_t *C, *deg, *keys;                    // m each
   uint32_t *S, *SOld, *lbase, *lsize, *lcap;   // m + 2 each
+  uint32_t* trash;                             // 64 words: where the lanes that have nothing to record write (colour_first_fit64)
   uint16_t* lstack;                            // LDS part of the per-level vertex lists (the rest is in global memory)
   uint32_t lstack_cap;
 };
 __host__ __device__ inline uint32_t gate_lds_bytes(uint32_t m) {
   const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;      // ma >= m + 2
-  return 8u * m * MW + 8u * MW + 8u * 4u * ma + 4u * 2u * ma + 64u;
+  return 8u * m * MW + 8u * MW + 8u * 4u * ma + 4u * 2u * ma + 256u + 64u;
 }
 __host__ __device__ inline uint32_t gate_small_bytes(uint32_t m) {           // everything except the adjacency matrix
   const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;
-  return 8u * MW + 8u * 4u * ma + 4u * 2u * ma + 64u;
+  return 8u * MW + 8u * 4u * ma + 4u * 2u * ma + 256u + 64u;
 }
 // ext_adjc != nullptr: the m x MW matrix lives in global scratch (graphs beyond one CU's LDS); same code path,
 // the pointers are generic
 // kExt is a template parameter so that, in the LDS instantiation, every pointer provably comes from the LDS allocation:
 // the compiler then emits ds_read/ds_write for the adjacency rows instead of flat loads (the rows are on the critical
 // path of Intersection and ColorSort)
+// rows: how many adjacency rows to make room for (m, or the object's n when the graph keeps the object's vertex numbers)
 template <bool kExt>
-__device__ __forceinline__ GateLds gate_carve(unsigned char* base, uint32_t m, uint32_t lds_bytes, u64* ext_adjc = nullptr) {
+__device__ __forceinline__ GateLds gate_carve(unsigned char* base, uint32_t m, uint32_t lds_bytes, u64* ext_adjc = nullptr, uint32_t rows = 0) {
   const uint32_t MW = (m + 63u) / 64u, ma = (m + 7u) & ~3u;
+  if (rows == 0u) rows = m;
   unsigned char* const base0 = base;
   GateLds L;
-  if constexpr (kExt) { L.adjc = ext_adjc; } else { L.adjc = reinterpret_cast<u64*>(base); base += 8u * m * MW; }
+  if constexpr (kExt) { L.adjc = ext_adjc; } else { L.adjc = reinterpret_cast<u64*>(base); base += 8u * rows * MW; }
   L.mask = reinterpret_cast<u64*>(base); base += 8u * MW;
   L.C = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
   L.deg = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
@@ -367,6 +370,7 @@ __device__ __forceinline__ GateLds gate_carve(unsigned char* base, uint32_t m, u
   L.lbase = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
   L.lsize = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
   L.lcap = reinterpret_cast<uint32_t*>(base); base += 4u * ma;
+  L.trash = reinterpret_cast<uint32_t*>(base); base += 256u;
   L.flist = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
   L.cur = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
   L.nxt = reinterpret_cast<uint16_t*>(base); base += 2u * ma;
@@ -474,6 +478,82 @@ __device__ __forceinline__ void degrees_in_list(const GateLds& L, const uint16_t
     L.deg[i] = d;
   }
   __syncthreads();
+}
+
+// The same first-fit colouring for at most 64 classes, with nothing but vector instructions between one vertex and the next. A lone
+// wave pays for every hand-over between the vector and the scalar unit (ballot -> find-first-set -> lane compare -> exec mask, the
+// shape of colour_first_fit below, costs ~530 cycles per vertex for ~45 instructions). Here the first free class is found
+// lane-locally: the free-class mask stays in VCC, v_mbcnt counts the free classes below each lane, the one lane that is free
+// with none below it joins -- a select and an or on its own registers. What ColorSort needs for its output order, (class, rank
+// inside the class) per list position, is written by that lane itself: every lane stores one word, the others into a trash slot.
+// Returns false (nothing written to the list or to C) when some vertex found all 64 classes taken: the caller then runs the
+// two-set form below.
+template <uint32_t MWT>
+__device__ __forceinline__ bool colour_first_fit64(const GateLds& L, uint16_t* list, uint32_t r) {
+  const uint32_t l = lane_id();
+  u64 cls[MWT];
+#pragma unroll
+  for (uint32_t w = 0; w < MWT; ++w) cls[w] = 0ull;
+  uint32_t cnt0 = 0u;                                      // members of class l so far
+  uint32_t* const my_trash = L.trash + l;
+  for (uint32_t c0 = 0; c0 < r; c0 += 64u) {
+    const uint32_t cnt = min(64u, r - c0);
+    const uint32_t vmine = (c0 + l) < r ? (uint32_t)list[c0 + l] : 0u;
+    auto place = [&](const u64 (&row)[MWT], u64 (&next)[MWT], uint32_t li) {
+      const uint32_t v = rdlane(vmine, li);
+      {
+        const u64* g = L.adjc + (size_t)rdlane(vmine, min(li + 1u, cnt - 1u)) * MWT;   // the chunk's last re-reads itself
+#pragma unroll
+        for (uint32_t w = 0; w < MWT; ++w) next[w] = g[w];
+      }
+      u64 hit = 0ull;
+#pragma unroll
+      for (uint32_t w = 0; w < MWT; ++w) hit |= row[w] & cls[w];
+      const uint32_t hit32 = (uint32_t)hit | (uint32_t)(hit >> 32);
+      const u64 fm = __ballot(hit32 == 0u);                // classes without a neighbour of v
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+      const uint32_t lw = hit32 == 0u ? below : 1u;
+      const bool join = lw == 0u;                          // the first free class: exactly one lane, or none (overflow)
+      uint32_t* const dst = join ? (L.keys + (c0 + li)) : my_trash;
+      *dst = (l << 16) | cnt0;                             // (class, rank inside the class) of position c0 + li
+      cnt0 += join ? 1u : 0u;
+      const u64 sel = join ? (1ull << (v & 63u)) : 0ull;
+      const uint32_t vw = v >> 6;                          // wave-uniform: a scalar branch picks the register pair, the arrays stay in registers
+#pragma unroll
+      for (uint32_t w = 0; w < MWT; ++w)
+        if (vw == w) { cls[w] |= sel; asm volatile("" ::: "memory"); }
+    };
+    u64 rowA[MWT], rowB[MWT];
+    {
+      const u64* g = L.adjc + (size_t)rdlane(vmine, 0u) * MWT;
+#pragma unroll
+      for (uint32_t w = 0; w < MWT; ++w) rowA[w] = g[w];
+    }
+    uint32_t li = 0;
+    for (; li + 2u <= cnt; li += 2u) {                     // two vertices per trip: the row buffers swap roles, nothing is copied
+      place(rowA, rowB, li);
+      place(rowB, rowA, li + 1u);
+    }
+    if (li < cnt) place(rowA, rowB, li);
+  }
+  const uint32_t incl0 = wave_incl_scan(cnt0), total0 = uni(__shfl(incl0, 63));
+  if (total0 != r) return false;                           // a vertex found no free class among 64
+  const uint32_t base0 = incl0 - cnt0;
+  __syncthreads();
+  for (uint32_t i = l; i < r + 63u - ((r + 63u) & 63u); i += 64u) {   // whole waves: the shuffles need every lane
+    const uint32_t rec = i < r ? L.keys[i] : 0u;
+    const uint32_t k = rec >> 16;
+    const uint32_t b = __shfl(base0, k & 63u);
+    if (i < r) {
+      const uint32_t pos = b + (rec & 0xFFFFu);
+      L.tmp[pos] = list[i];
+      L.C[pos] = k + 1u;
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = l; i < r; i += 64u) list[i] = L.tmp[i];
+  __syncthreads();
+  return true;
 }
 
 // ColorSort (maximum_clique.cpp:219-261) on list[0..r), writing colours into the shared array C by absolute
@@ -616,14 +696,14 @@ __device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, ui
   if (MW <= 8u) {                                          // graphs of up to 512 vertices: one lane per colour class
     bool done = false;
     switch (MW) {                                          // wave-uniform
-      case 1: done = colour_first_fit<1, false>(L, list, r) || colour_first_fit<1, true>(L, list, r); break;
-      case 2: done = colour_first_fit<2, false>(L, list, r) || colour_first_fit<2, true>(L, list, r); break;
-      case 3: done = colour_first_fit<3, false>(L, list, r) || colour_first_fit<3, true>(L, list, r); break;
-      case 4: done = colour_first_fit<4, false>(L, list, r) || colour_first_fit<4, true>(L, list, r); break;
-      case 5: done = colour_first_fit<5, false>(L, list, r) || colour_first_fit<5, true>(L, list, r); break;
-      case 6: done = colour_first_fit<6, false>(L, list, r) || colour_first_fit<6, true>(L, list, r); break;
-      case 7: done = colour_first_fit<7, false>(L, list, r) || colour_first_fit<7, true>(L, list, r); break;
-      default: done = colour_first_fit<8, false>(L, list, r) || colour_first_fit<8, true>(L, list, r); break;
+      case 1: done = colour_first_fit64<1>(L, list, r) || colour_first_fit<1, true>(L, list, r); break;
+      case 2: done = colour_first_fit64<2>(L, list, r) || colour_first_fit<2, true>(L, list, r); break;
+      case 3: done = colour_first_fit64<3>(L, list, r) || colour_first_fit<3, true>(L, list, r); break;
+      case 4: done = colour_first_fit64<4>(L, list, r) || colour_first_fit<4, true>(L, list, r); break;
+      case 5: done = colour_first_fit64<5>(L, list, r) || colour_first_fit<5, true>(L, list, r); break;
+      case 6: done = colour_first_fit64<6>(L, list, r) || colour_first_fit<6, true>(L, list, r); break;
+      case 7: done = colour_first_fit64<7>(L, list, r) || colour_first_fit<7, true>(L, list, r); break;
+      default: done = colour_first_fit64<8>(L, list, r) || colour_first_fit<8, true>(L, list, r); break;
     }
     if (done) return;                                      // else: more than 128 classes -> the generic loop below
   }
@@ -663,17 +743,23 @@ __device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, ui
 
 // FindClique + MaxCliqueDyn (maximum_clique.cpp:286-369) as an explicit state machine over one wave.
 // Returns QMax.size(); *err != 0 when the per-wave stack is too small.
+// vertices: the graph's vertex numbers in ascending order (nullptr: 0 .. m - 1). The search only ever compares vertex numbers and
+// uses them as row / bit indices, so a graph whose m vertices keep larger, ascending numbers (all below 64 MW) behaves exactly
+// like its renumbered copy. L.deg[i] = degree of the i-th vertex on entry.
 __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, uint16_t* gstack, uint32_t stack_cap,
-                                  int* err, uint32_t* steps_out, uint32_t* prof = nullptr) {
+                                  int* err, uint32_t* steps_out, uint32_t* prof = nullptr, const uint16_t* vertices = nullptr) {
   const uint32_t l = lane_id();
   const LevelStack stack = {L.lstack, L.lstack_cap, gstack};
   stack_cap += L.lstack_cap;
   const uint32_t MW = (m + 63u) / 64u;
-  // R = all vertices, DegreeSort(R); L.deg holds the degree of graph vertex g at index g
-  for (uint32_t i = l; i < m; i += 64u) L.cur[i] = (uint16_t)i;
+  // R = all vertices, DegreeSort(R); L.deg holds the degree of the i-th vertex at index i
+  uint32_t dmax = 0;
+  for (uint32_t i = l; i < m; i += 64u) { L.cur[i] = vertices ? vertices[i] : (uint16_t)i; dmax = max(dmax, L.deg[i]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o));
+  const uint32_t max_degree = uni(dmax);                 // = the degree of the sorted list's head (:352-355)
   __syncthreads();
   rank_sort_desc(L.cur, L.tmp, L.deg, m, L.keys);
-  const uint32_t max_degree = uni(L.deg[L.cur[0]]);
   __syncthreads();
   for (uint32_t i = l; i < m; i += 64u) L.C[i] = i < max_degree ? i + 1u : max_degree + 1u;     // :356-361
   for (uint32_t i = l; i < m + 2u; i += 64u) { L.S[i] = 0u; L.SOld[i] = 0u; }
@@ -827,8 +913,14 @@ __device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& 
   const ObjJob& job = A.job;
   const uint32_t W = job.W;
   int32_t result = (int32_t)cnt;
-  GateLds L = gate_carve<kExt>(lds_raw, m, A.lds_bytes, kExt ? A.adjc_scratch + (size_t)blockIdx.x * kAdjcScratchWords : nullptr);
   const uint32_t MW = (m + 63u) / 64u;
+  // An object of up to 512 matches whose consensus list needs as many 64-bit words as the object itself (MW == W: the usual
+  // case when the object is really there) keeps the object's vertex numbers: the induced graph is then the object's sample rows
+  // masked with F, a copy, instead of a column compaction that costs ~200 k cycles for 264 vertices; vertex numbers only ever
+  // serve as row / bit indices and in comparisons, and F is ascending, so the search cannot tell the difference.
+  const bool ident = !kExt && W <= 8u && MW == W && gate_lds_bytes(m) + 8u * (job.n - m) * MW <= A.lds_bytes;
+  GateLds L = gate_carve<kExt>(lds_raw, m, A.lds_bytes, kExt ? A.adjc_scratch + (size_t)blockIdx.x * kAdjcScratchWords : nullptr,
+                               ident ? job.n : m);
   const long long t_start = A.dbg ? clock64() : 0;   // phase stamps (diagnostics builds of the call only)
   // F in ascending order (:219) -> graph index = rank (:241-243)
   uint32_t base = 0;
@@ -853,7 +945,22 @@ __device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& 
   bad_index = __ballot(bad_index) != 0ull;           // never dereference an unchecked index
   if (bad_index && l == 0) { atomicExch(&A.status[0], 4u); A.status[6] = m; A.status[7] = it; }
   if (!bad_index && A.stop_level != 3u) {
-    if (W <= 8u) {
+    if (ident) {
+      if (l < W) L.mask[l] = F.w[0];                       // lane l holds word l of F (W <= 8 < 64)
+      __syncthreads();
+      for (uint32_t i = l; i < job.n * W; i += 64u) {
+        const uint32_t v = i / W, w = i - v * W;
+        const bool member = (L.mask[v >> 6] >> (v & 63u)) & 1ull;
+        L.adjc[i] = member ? (job.samp[i] & L.mask[w]) : 0ull;
+      }
+      __syncthreads();
+      for (uint32_t g = l; g < m; g += 64u) {
+        const u64* row = L.adjc + (size_t)L.flist[g] * MW;
+        uint32_t d = 0;
+        for (uint32_t w = 0; w < MW; ++w) d += (uint32_t)__popcll(row[w]);
+        L.deg[g] = d;
+      }
+    } else if (W <= 8u) {
       // n <= 512: lane = one row of the induced graph, its whole sample row (<= 16 dwords) in registers;
       // the members of F are walked once per 64 rows, one v_readlane + bit-field extract + shift-or each.
       // F is ascending, so the source dword only ever moves forward.
@@ -965,7 +1072,7 @@ __device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& 
     int err = 0;
     uint32_t steps = 0;
     uint32_t* prof = (A.dbg && A.dbg_stride >= 16u) ? A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 12u) : nullptr;
-    const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, &steps, prof);
+    const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, &steps, prof, ident ? L.flist : nullptr);
     if (A.dbg && l == 0 && A.dbg_stride >= 8u) {
       uint32_t* d = A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 6u);
       d[0] = (uint32_t)(t_flist - t_start); d[1] = (uint32_t)(t_adjc - t_flist);
