@@ -294,3 +294,69 @@ def test_l2_random_large_databases(ctx, seed):
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
     ctx.db_load(np.ascontiguousarray(desc, np.float32), pts, off)
     l2_same(ctx, desc, pts, off, q, k, float(rng.choice([0.5, 3.0, 1e9])) * spread * 11.3)
+
+
+@pytest.mark.parametrize("seed", _seeds(16))
+def test_lsh_mode_random_configurations(seed):
+    """todhip_set_lsh against oracle/lsh_oracle.c on random table counts, key sizes, probe depths, DB shapes (ragged, tie-heavy,
+    tiny) and k; a fresh context per case (the index belongs to the context)."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(36000 + seed))
+    n_obj = int(rng.integers(1, 6))
+    sizes = [int(rng.integers(0, 3000)) for _ in range(n_obj)]
+    if sum(sizes) == 0:
+        sizes[-1] = 3
+    n, nq, k = sum(sizes), int(rng.integers(1, 300)), int(rng.integers(1, 9))
+    tables, ks = int(rng.integers(1, 13)), int(rng.integers(1, 21))
+    level = int(rng.integers(0, min(3, ks) + 1))
+    if seed % 3 == 1:                                          # tie-heavy: few distinct descriptors, huge buckets
+        desc = np.zeros((n, 32), np.uint8); desc[:, 9] = rng.choice([0, 1, 3, 7, 255], n); desc[:, 20] = rng.choice([0, 16], n)
+        q = np.zeros((nq, 32), np.uint8); q[:, 9] = rng.choice([0, 1, 3, 7, 15], nq)
+    else:
+        desc = rng.integers(0, 256, (n, 32)).astype(np.uint8)
+        q = desc[rng.integers(0, n, nq)].copy()
+        for i in range(nq):
+            for b in rng.integers(0, 256, int(rng.integers(0, 20))):
+                q[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    pts = rng.random((n, 3)).astype(np.float32)
+    c = capi.Context(0)
+    if seed % 2:
+        c.set_lsh(tables, ks, level); c.db_load(desc, pts, off)
+    else:
+        c.db_load(desc, pts, off); c.set_lsh(tables, ks, level)
+    want, _ = O.lsh_knn_keys(desc, q, k, tables, ks, level)
+    d_q = torch.from_numpy(q).cuda()
+    keys = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    c.match_shard_device(d_q.data_ptr(), nq, k, 256, keys.data_ptr())
+    c.synchronize()
+    got = keys.cpu().numpy().view(np.uint64)
+    c.close()
+    assert np.array_equal(got, want), (tables, ks, level, k)
+
+
+@pytest.mark.parametrize("seed", _seeds(16))
+def test_verify_2d_random_scenes(ctx, seed):
+    """todhip_verify_2d against oracle/pnp_oracle.c on random scenes: 0-3 visible objects, 1-6 matches per keypoint, thresholds from
+    sub-pixel to huge, few and many hypotheses, other intrinsics; objects, consensus sets and poses must be equal bit for bit."""
+    rng = np.random.Generator(np.random.PCG64(37000 + seed))
+    n_obj = int(rng.integers(2, 12))
+    n_vis = int(rng.integers(0, min(3, n_obj) + 1))
+    vis_objs = rng.choice(n_obj, n_vis, replace=False)
+    fr = rng.dirichlet(np.ones(n_vis + 1))[:n_vis] * 0.8 if n_vis else []
+    visible = tuple((int(o), float(max(f, 0.05))) for o, f in zip(vis_objs, fr))
+    f = float(rng.choice([400.0, 525.0, 900.0]))
+    sc = synth.make_verify_scene(int(rng.integers(30, 900)), n_objects=n_obj, per_object=int(rng.integers(20, 500)), visible=visible,
+                                 matches_per_kp=int(rng.integers(1, 7)), seed=500 + seed, f=f, noise=float(rng.choice([0.0, 0.001, 0.004])))
+    K = np.array([[f, 0, 320.0], [0, f * float(rng.choice([1.0, 0.97])), 240.0], [0, 0, 1]], np.float32)
+    min_inl, n_iter = int(rng.integers(3, 30)), int(rng.choice([1, 7, 100, 600]))
+    err_px = float(rng.choice([0.3, 2.0, 5.0, 300.0]))
+    s = int(rng.integers(1, 1000))
+    rng_o, rng_g = O.rng_new(s), capi.rng_new(s)
+    rc, want, _ = O.verify_2d(sc["kp_xy"], K, sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], min_inl, n_iter, err_px, rng_o)
+    assert rc == 0
+    got = ctx.verify_2d(sc["kp_xy"], K, sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], min_inl, n_iter, err_px, rng_g)
+    assert rng_g.draws == rng_o.draws
+    assert [p["object"] for p in got] == [p["object"] for p in want]
+    for g, w in zip(got, want):
+        assert np.array_equal(g["inliers"], w["inliers"]) and np.array_equal(g["R"], w["R"]) and np.array_equal(g["t"], w["t"])
