@@ -490,10 +490,12 @@ __device__ __forceinline__ void degrees_in_list(const GateLds& L, const uint16_t
 // two-set form below.
 template <uint32_t MWT>
 __device__ __forceinline__ bool colour_first_fit64(const GateLds& L, uint16_t* list, uint32_t r) {
+  typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
   const uint32_t l = lane_id();
-  u64 cls[MWT];
-#pragma unroll
-  for (uint32_t w = 0; w < MWT; ++w) cls[w] = 0ull;
+  // class l's members as a bitset over graph vertices, 32-bit halves in ONE register tuple: the half that receives a vertex is
+  // picked with the hardware's register indexing (s_set_gpr_idx, the index v >> 5 is wave-uniform) -- three instructions to read,
+  // three to write, no branch tree and no per-word selects
+  u32x16 cls = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t cnt0 = 0u;                                      // members of class l so far
   uint32_t* const my_trash = L.trash + l;
   for (uint32_t c0 = 0; c0 < r; c0 += 64u) {
@@ -506,10 +508,9 @@ __device__ __forceinline__ bool colour_first_fit64(const GateLds& L, uint16_t* l
 #pragma unroll
         for (uint32_t w = 0; w < MWT; ++w) next[w] = g[w];
       }
-      u64 hit = 0ull;
+      uint32_t hit32 = 0u;
 #pragma unroll
-      for (uint32_t w = 0; w < MWT; ++w) hit |= row[w] & cls[w];
-      const uint32_t hit32 = (uint32_t)hit | (uint32_t)(hit >> 32);
+      for (uint32_t w = 0; w < MWT; ++w) hit32 |= ((uint32_t)row[w] & cls[2u * w]) | ((uint32_t)(row[w] >> 32) & cls[2u * w + 1u]);
       const u64 fm = __ballot(hit32 == 0u);                // classes without a neighbour of v
       const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
       const uint32_t lw = hit32 == 0u ? below : 1u;
@@ -517,11 +518,7 @@ __device__ __forceinline__ bool colour_first_fit64(const GateLds& L, uint16_t* l
       uint32_t* const dst = join ? (L.keys + (c0 + li)) : my_trash;
       *dst = (l << 16) | cnt0;                             // (class, rank inside the class) of position c0 + li
       cnt0 += join ? 1u : 0u;
-      const u64 sel = join ? (1ull << (v & 63u)) : 0ull;
-      const uint32_t vw = v >> 6;                          // wave-uniform: a scalar branch picks the register pair, the arrays stay in registers
-#pragma unroll
-      for (uint32_t w = 0; w < MWT; ++w)
-        if (vw == w) { cls[w] |= sel; asm volatile("" ::: "memory"); }
+      cls[v >> 5] |= join ? (1u << (v & 31u)) : 0u;
     };
     u64 rowA[MWT], rowB[MWT];
     {
