@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
     ap.add_argument("--stages", default="orb,match,verify", help="comma list of: orb,match,verify")
     ap.add_argument("--batch", type=int, default=16, help="frames per rank per step")
+    ap.add_argument("--verify-workers", type=int, default=0,
+                    help="verifier batches in flight in the chained pipeline (one context, stream and host thread each); 0 = 6: the verifier's "
+                         "ticks are lock-step over a batch and mostly wait for single-wave kernels, so batches overlap almost freely until the "
+                         "host threads run out (tools/chained_workers.sh: 2 -> 800, 4 -> 1440, 6 -> 1740, 8 -> 1450 frames/s)")
     ap.add_argument("--engine", choices=("auto", "valu", "mfma"), default="auto",
                     help="the exact Hamming search's engine: vector ALU (K4) or matrix cores (K4x); identical results")
     ap.add_argument("--exchange", choices=("all_to_all", "all_gather"), default="all_to_all",
@@ -154,7 +158,7 @@ class SyntheticPipeline:
         self.nq, self.k, self.radius, self.B, self.H, self.W = nq, k, radius, B, H, W
         self.iterations, self.min_inliers = iterations, min_inliers
         do_orb, do_verify = "orb" in stages, "verify" in stages
-        self.stream = main_stream or torch.cuda.Stream()
+        self.stream = main_stream or pooled_stream(torch, "match")
         self.ctx = capi.Context(device, self.stream.cuda_stream)
         self.ctx.set_matcher_engine(engine)
         self.shard = shard                                               # (rank, count): this device holds one shard of the rows
@@ -176,11 +180,11 @@ class SyntheticPipeline:
         self.outs = [dict(counts=torch.zeros(B * nq, dtype=torch.int32, device="cuda"),
                           matches=torch.zeros((B * nq * k, 4), dtype=torch.int32, device="cuda"),
                           xyz=torch.zeros((B * nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(self.D)]
-        self.ostream = torch.cuda.Stream(priority=-1)
+        self.ostream = pooled_stream(torch, "orb", 0, -1)
         self.octx = capi.Context(device, self.ostream.cuda_stream) if do_orb else None
         # two verifier workers (context + stream each) take alternate steps: the verifier is latency bound (host round trips,
         # single-wave clique searches), so two batches in flight fill each other's gaps
-        self.vstreams = [torch.cuda.Stream(priority=-1) for _ in range(verify_workers)] if do_verify else []
+        self.vstreams = [pooled_stream(torch, "verify", j, -1) for j in range(verify_workers)] if do_verify else []
         self.vctxs = [capi.Context(device, s.cuda_stream) for s in self.vstreams]
         self.orb_out = (torch.empty((B, nq, 2), device="cuda"), torch.empty((B, nq, 4), device="cuda"),
                         torch.empty((B, nq, 32), dtype=torch.uint8, device="cuda")) if do_orb else None
@@ -239,6 +243,19 @@ def launch_ms(c0, c1):
     return (c1.sum_match_kernel_ms - c0.sum_match_kernel_ms) / max(n, 1), n
 
 
+# Streams are a scarce resource: the runtime maps them onto 8 hardware queues (header), and a pipeline whose streams share queues
+# with another pipeline's idle ones runs its stages one behind the other (the chained block lost a quarter of its rate to the
+# headline pipeline's four idle streams). Pipelines that never run at the same time therefore draw from one pool, per role.
+_STREAMS = {}
+
+
+def pooled_stream(torch, role, index=0, priority=0):
+    key = (role, index)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(priority=priority)
+    return _STREAMS[key]
+
+
 # ------------------------------------------------------------------------------------------------------------ extras (N = 1)
 def run_chained(torch, capi, device, args):
     """Real dataflow: DB trained by todhip_model_* on rendered views of 200 textured planes (this library's own ORB
@@ -255,13 +272,14 @@ def run_chained(torch, capi, device, args):
     tctx.close()
     batches = scenes.make_detection_batches(textures, 4, B)
     H, W = scenes.H, scenes.W
-    mstream, ostream = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
-    vstreams = [torch.cuda.Stream(priority=-1) for _ in range(2)]
+    mstream, ostream = pooled_stream(torch, "match"), pooled_stream(torch, "orb", 0, -1)
+    NV = args.verify_workers if args.verify_workers > 0 else 6
+    vstreams = [pooled_stream(torch, "verify", j, -1) for j in range(NV)]
     mctx, octx = capi.Context(device, mstream.cuda_stream), capi.Context(device, ostream.cuda_stream)
     vctxs = [capi.Context(device, s.cuda_stream) for s in vstreams]
     mctx.set_matcher_engine(args.engine)
     spans = mctx.db_load(desc, pts, off)
-    D, P = 3, len(batches)
+    D, P = max(3, NV + 1), len(batches)
     R = 2 * D                                                             # ORB output ring: ORB runs D ahead of the matcher, the verifier D behind
     orb_ring = [dict(kp=torch.zeros((B, nq, 2), device="cuda"), aux=torch.zeros((B, nq, 4), device="cuda"),
                      desc=torch.zeros((B, nq, 32), dtype=torch.uint8, device="cuda"), n=[nq] * B) for _ in range(R)]
@@ -291,7 +309,7 @@ def run_chained(torch, capi, device, args):
     def verify(i):
         s, o, bt = orb_ring[i % R], outs[i % D], batches[i % P]
         rngs = (capi.Rng * B)(*[capi.rng_new(1) for _ in range(B)])
-        poses = vctxs[i % 2].verify_batch_device(B, s["kp"].data_ptr(), nq, 0, H, W, o["counts"].data_ptr(), o["matches"].data_ptr(),
+        poses = vctxs[i % NV].verify_batch_device(B, s["kp"].data_ptr(), nq, 0, H, W, o["counts"].data_ptr(), o["matches"].data_ptr(),
                                          o["xyz"].data_ptr(), k, spans, args.min_inliers, args.iterations, 0.01, rngs,
                                          depth=(bt["depth"].data_ptr(), False, scenes.K))
         for f, pl in enumerate(poses):
@@ -305,17 +323,17 @@ def run_chained(torch, capi, device, args):
                     stats["pose_ok"] += 1
         return sum(len(p) for p in poses)
 
-    pipe = StagePipeline(torch, orb=orb, match=match, verify=verify, wait_for=lambda i, ev: vstreams[i % 2].wait_event(ev), depth=D,
-                         verify_workers=2)
+    pipe = StagePipeline(torch, orb=orb, match=match, verify=verify, wait_for=lambda i, ev: vstreams[i % NV].wait_event(ev), depth=D,
+                         verify_workers=NV)
     setup_s = time.perf_counter() - t_setup
-    pipe.run(3)
+    pipe.run(max(3, 2 * D))                                               # fill the pipeline: D batches are in flight in steady state
     torch.cuda.synchronize()
     for key in stats:
         stats[key] = 0
     pipe.reset_stats()
     mctx.set_kernel_timing(True)
     c0 = mctx.counters()
-    steps = max(args.steps // 2, 5)
+    steps = max(args.steps, 8 * D)                                        # long enough that filling and draining D batches in flight is a few per cent
     secs = timed_regions(torch, pipe.run, torch.cuda.synchronize, steps, args.repeats)
     c1 = mctx.counters()
     k_ms, n_l = launch_ms(c0, c1)
@@ -325,6 +343,7 @@ def run_chained(torch, capi, device, args):
                    "library), per step todhip_orb_batch_device -> todhip_match_device -> todhip_verify_batch_device_depth on %d rendered "
                    "detection views, every stage reading the previous stage's device buffers" % (len(scenes.TRAIN_VIEWS), B),
            "db_rows": int(off[-1]), "db_objects": n_obj, "k": k, "radius": radius, "frames_per_step": B, "steps": steps,
+           "verifier_batches_in_flight": NV,
            "frames_per_s": spread(fps), "ms_per_step": statistics.median(secs) / steps * 1e3,
            "matcher_launch_ms": k_ms, "matcher_launches": n_l,
            "stage_ms_per_step": {key: 1e3 * v / (steps * args.repeats) for key, v in pipe.stage_s.items()},
@@ -565,7 +584,7 @@ def main():
 
     # one explicit stream for the matcher: libtodhip kernels, torch copies and (serial form) the RCCL collectives, which order
     # themselves against torch's current stream. The default stream's handle is 0 == "create your own" for todhip_create.
-    stream = torch.cuda.Stream()
+    stream = pooled_stream(torch, "match")
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     nq, k, B = args.nq, args.k, args.batch
