@@ -176,7 +176,7 @@ class SyntheticPipeline:
         self.KP_B = [batch_of(v, "kp_xy", np.float32) for v in range(self.period)]              # [B, Q, 2]
         self.CLOUD_B = [batch_of(v, "cloud", np.float32) for v in range(self.period)] if do_verify else []
         self.IMG_B = [batch_of(v, "image") for v in range(self.period)] if do_orb else []       # [B, H, W]
-        self.D = 3
+        self.D = max(3, verify_workers + 1)                              # a step's outputs stay untouched until its verifier call is done
         self.outs = [dict(counts=torch.zeros(B * nq, dtype=torch.int32, device="cuda"),
                           matches=torch.zeros((B * nq * k, 4), dtype=torch.int32, device="cuda"),
                           xyz=torch.zeros((B * nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(self.D)]
@@ -435,10 +435,11 @@ def run_configs(torch, capi, synth, device, args):
     """BASELINE.json configs other than the headline's (C3), each on one GPU: frames/s + the dominant kernel's time."""
     out = {}
 
-    def pipeline_block(name, desc, pts, off, frames, nq, k, radius, B, stages, steps, H=480, W=640, shard=None, match_fn=None, note=""):
+    def pipeline_block(name, desc, pts, off, frames, nq, k, radius, B, stages, steps, H=480, W=640, shard=None, match_fn=None, note="",
+                       verify_workers=2):
         sp = SyntheticPipeline(torch, capi, device, desc, pts, off, frames, nq, k, radius, B, stages, args.iterations, args.min_inliers,
-                               engine=args.engine, H=H, W=W, shard=shard, match_fn=match_fn)
-        sp.pipe.run(2)
+                               engine=args.engine, H=H, W=W, shard=shard, match_fn=match_fn, verify_workers=verify_workers)
+        sp.pipe.run(max(2, 2 * sp.D))
         torch.cuda.synchronize()
         sp.pipe.reset_stats()
         sp.ctx.set_kernel_timing(True)
@@ -494,8 +495,9 @@ def run_configs(torch, capi, synth, device, args):
     out["C5_single_gpu_share"] = pipeline_block(
         "C5, one rank's share of the 8-GPU job: per step ORB-2000 on 4 of the 32 1080p frames, the 32 x 2000 descriptors against this "
         "rank's 250k-row shard of the 2M-row DB (k=2, radius 35), merge + full verifier for its own 4 frames", d5, p5, o5, f5, nq5, 2, 35,
-        B5, ["orb", "match", "verify"], 10, H=1080, W=1920, shard=(0, world5), match_fn=match_c5,
-        note="no collectives on one GPU: the candidate exchange (32 x 2000 x 2 keys x 8 B per rank) is missing from this figure")
+        B5, ["orb", "match", "verify"], 40, H=1080, W=1920, shard=(0, world5), match_fn=match_c5, verify_workers=6,
+        note="no collectives on one GPU: the candidate exchange (32 x 2000 x 2 keys x 8 B per rank) is missing from this figure; "
+             "six verifier batches (of 4 frames) in flight")
     del d5, p5, f5, keys5
     # ---- C4: float descriptors, L2 brute force as a bf16 MFMA GEMM + exact refinement (matcher only: not a reference feature)
     d4, p4, o4 = synth.make_sift_db(100)
