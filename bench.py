@@ -20,8 +20,9 @@ starts exactly that as a child process (before anything touches the GPU) and exi
 
 One JSON line on rank 0. `roofline` is for the dominant kernel (the matcher's DB pass); `cpu_baseline` times the CPU
 oracle on a bounded sample of the same workload; `repeats` = the timed region run several times (value = the median);
-`chained`, `configs` (C1, C2, C4, C5 single-GPU share) and `adapter_path` (one frame at a time through the host-buffer
-calls the ecto cells make) are measured after the timed region, at N=1 only.
+`chained`, `configs` (C1, C2, C4, C5 single-GPU share), `adapter_path` (one frame at a time through the host-buffer
+calls the ecto cells make), `hbm_regime` and `n4` (the 2D-only verifier and the LSH mode at the headline frame shape) are
+measured after the timed region, at N=1 only.
 """
 import argparse
 import json
@@ -85,8 +86,8 @@ def parse():
     ap.add_argument("--min-inliers", type=int, default=8, help="min_inliers (conf/detection.ork:39)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", default="chained,configs,adapter,hbm", help="N=1 only, after the timed region: comma list of "
-                    "chained,configs,adapter,hbm ('' = none)")
+    ap.add_argument("--extras", default="chained,configs,adapter,hbm,n4", help="N=1 only, after the timed region: comma list of "
+                    "chained,configs,adapter,hbm,n4 ('' = none)")
     return ap.parse_args()
 
 
@@ -389,6 +390,62 @@ def run_adapter_path(torch, capi, device, desc, pts, off, frames, args):
             "ms_per_call": {key: 1e3 * v for key, v in med.items()},
             "ms_per_frame_spread": spread([1e3 * v for v in sorted(per_frame)[::max(len(per_frame) // 8, 1)]]),
             "poses_per_frame": n_poses / max(len(per_frame), 1)}
+
+
+def run_n4(torch, capi, device, desc, pts, off, frames, args):
+    """SURVEY 8(f) N4 at the headline frame shape, single frame, host buffers: the 2D-only branch (todhip_verify_2d, no cloud) and the
+    LSH-approximate mode at the reference configs' parameters, with its recall against the exact search."""
+    ctx = capi.Context(device)
+    ctx.set_matcher_engine(args.engine)
+    spans = ctx.db_load(desc, pts, off)
+    K = np.array([[525.0, 0, 320.0], [0, 525.0, 240.0], [0, 0, 1]], np.float32)            # synth.make_frame's camera
+    t2d, n2d, same_obj = [], 0, 0
+    exact = []
+    for r in range(3):
+        for fr in frames:
+            row_ptr, m, xyz = ctx.match(fr["q_desc"], args.k, args.radius)
+            if r == 0:
+                exact.append((row_ptr, m))
+            t0 = time.perf_counter()
+            poses = ctx.verify_2d(fr["kp_xy"], K, row_ptr, m, xyz, spans, args.min_inliers, 1000, 3.0, capi.rng_new(1))
+            if r > 0:
+                t2d.append(time.perf_counter() - t0); n2d += len(poses)
+    out = {"verify_2d": {"what": "todhip_verify_2d on the headline frames' matches: keypoints + camera matrix only (no cloud), 1000 P3P "
+                                 "hypotheses per object, reprojection threshold 3 px, host buffers", "ms_per_call": 1e3 * statistics.median(t2d),
+                         "poses_per_frame": n2d / max(len(t2d), 1)}}
+    lsh = {}
+    for name, (tables, ks, lvl) in (("detection.ork", (10, 16, 1)), ("detection.ros.ork", (8, 24, 2))):
+        t0 = time.perf_counter()
+        ctx.set_lsh(tables, ks, lvl)
+        ctx.synchronize()
+        t_build = time.perf_counter() - t0
+        ts, kept, want = [], 0, 0
+        for r in range(3):
+            for f, fr in enumerate(frames):
+                t0 = time.perf_counter()
+                row_ptr, m, _ = ctx.match(fr["q_desc"], args.k, args.radius)
+                if r > 0:
+                    ts.append(time.perf_counter() - t0)
+                else:                                                    # recall: matches of the exact search that the index also returns
+                    erp, em = exact[f]
+                    e = set(zip(em["queryIdx"].tolist(), em["imgIdx"].tolist(), em["trainIdx"].tolist()))
+                    g = set(zip(m["queryIdx"].tolist(), m["imgIdx"].tolist(), m["trainIdx"].tolist()))
+                    kept += len(e & g); want += len(e)
+        lsh[name] = {"n_tables": tables, "key_size": ks, "multi_probe_level": lvl, "index_build_ms": 1e3 * t_build,
+                     "ms_per_call": 1e3 * statistics.median(ts), "recall_of_the_exact_matches_within_radius": kept / max(want, 1)}
+    ctx.set_lsh(0)
+    ts = []
+    for r in range(3):
+        for fr in frames:
+            t0 = time.perf_counter()
+            ctx.match(fr["q_desc"], args.k, args.radius)
+            if r > 0:
+                ts.append(time.perf_counter() - t0)
+    out["lsh_mode"] = {"what": "todhip_match (host buffers, one 1000-descriptor frame) with todhip_set_lsh at the parameters of the reference's "
+                               "configs, against the exact search (the default) on the same context", "configs": lsh,
+                       "exact_ms_per_call": 1e3 * statistics.median(ts), "db_rows": int(off[-1])}
+    ctx.close()
+    return out
 
 
 def run_hbm_regime(torch, capi, device, args):
@@ -772,6 +829,8 @@ def main():
                 out["adapter_path"] = run_adapter_path(torch, capi, local_rank, desc, pts, off, frames, args)
             if "hbm" in extras:
                 out["hbm_regime"] = run_hbm_regime(torch, capi, local_rank, args)
+            if "n4" in extras:
+                out["n4"] = run_n4(torch, capi, local_rank, desc, pts, off, frames, args)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
                                                    args.iterations, args.min_inliers)
