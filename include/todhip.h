@@ -246,6 +246,12 @@ int todhip_verify_2d(todhip_ctx*, const float* kp_xy, uint32_t nq, const float* 
                      const todhip_verify_params*, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp,
                      uint32_t* n_inlier_kp);
 
+/* The same with the keypoints and the matcher's fixed-stride outputs in HBM (what todhip_match_device / todhip_merge_shards_device
+ * left there): d_kp_xy[nq*2] f32, d_counts[nq] u32, d_matches[nq*k], d_matches_xyz[nq*k*3]. Same result as the call above. */
+int todhip_verify_2d_device(todhip_ctx*, const void* d_kp_xy, uint32_t nq, const float* K9, const void* d_counts, const void* d_matches,
+                            const void* d_matches_xyz, uint32_t k, const float* spans, uint32_t n_objs, const todhip_verify_params*,
+                            todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp);
+
 /* ---- training ----------------------------------------------------------------- */
 /* Per-observation arithmetic of the reference's Trainer cell (src/training/Trainer.cpp:121-187, training.cpp:57-195):
  * ORB on the masked view (the reference uses cv::ORB defaults: 500 features, 8 levels, scale 1.2 -- :148-149),

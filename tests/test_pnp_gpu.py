@@ -83,3 +83,22 @@ def test_bad_arguments(ctx):
         ctx.verify_2d(sc["kp_xy"], K, sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 100, 0.0, capi.rng_new(1))
     with pytest.raises(capi.TodError):
         ctx.verify_2d(sc["kp_xy"], K, sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"][:1], 8, 100, 3.0, capi.rng_new(1))
+
+
+def test_device_form_after_the_device_matcher_equals_the_host_form(ctx):
+    """todhip_match_device -> todhip_verify_2d_device on the device buffers == todhip_match -> todhip_verify_2d through the host."""
+    import torch
+    desc, pts, off = synth.make_db(6, per_object=800)
+    fr = synth.make_frame(desc, pts, off, 500, frame=3, visible_object=4)
+    spans = ctx.db_load(desc, pts, off)
+    row_ptr, m, xyz = ctx.match(fr["q_desc"], 3, 35)
+    host = ctx.verify_2d(fr["kp_xy"], K, row_ptr, m, xyz, spans, 8, 400, 3.0, capi.rng_new(5))
+    d_q = torch.from_numpy(fr["q_desc"]).cuda(); d_kp = torch.from_numpy(fr["kp_xy"]).cuda()
+    cnt = torch.zeros(500, dtype=torch.int32, device="cuda"); mm = torch.zeros((1500, 4), dtype=torch.int32, device="cuda")
+    xx = torch.zeros((1500, 3), dtype=torch.float32, device="cuda")
+    ctx.match_device(d_q.data_ptr(), 500, 3, 35, cnt.data_ptr(), mm.data_ptr(), xx.data_ptr())
+    dev = ctx.verify_2d_device(d_kp.data_ptr(), 500, K, cnt.data_ptr(), mm.data_ptr(), xx.data_ptr(), 3, spans, 8, 400, 3.0, capi.rng_new(5))
+    assert len(host) == len(dev) == 1 and host[0]["object"] == dev[0]["object"] == 4
+    assert np.array_equal(host[0]["R"], dev[0]["R"]) and np.array_equal(host[0]["t"], dev[0]["t"]) and np.array_equal(host[0]["inliers"], dev[0]["inliers"])
+    assert np.abs(dev[0]["R"] - synth.pose_R()).max() < 0.03 and np.abs(dev[0]["t"] - synth.POSE_T).max() < 0.015
+

@@ -60,7 +60,7 @@ EXPORTS = [
     "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
     "todhip_match_l2", "todhip_match_l2_device",
     "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
-    "todhip_rescale_depth", "todhip_rescale_depth_device", "todhip_verify_2d", "todhip_set_lsh",
+    "todhip_rescale_depth", "todhip_rescale_depth_device", "todhip_verify_2d", "todhip_verify_2d_device", "todhip_set_lsh",
 ]
 
 _lib = None
@@ -283,6 +283,23 @@ class Context:
                                     matches.ctypes.data_as(C.c_void_p), _np_ptr(mxyz), _np_ptr(sp), C.c_uint32(len(sp)),
                                     C.byref(prm), C.byref(rng), poses, C.byref(n_poses), _np_ptr(inl), C.byref(n_inl))
         _check(rc, "todhip_verify_2d")
+        return [dict(object=int(poses[i].object), R=np.array(poses[i].R[:], np.float32).reshape(3, 3),
+                     t=np.array(poses[i].t[:], np.float32),
+                     inliers=inl[poses[i].inlier_begin:poses[i].inlier_end].copy()) for i in range(n_poses.value)]
+
+    def verify_2d_device(self, d_kp_xy, nq, K, d_counts, d_matches, d_xyz, k, spans, min_inliers, n_iter, err_px, rng, max_poses=64):
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        sp = np.ascontiguousarray(spans, np.float32)
+        prm = VerifyParams(min_inliers, n_iter, err_px)
+        poses = (Pose * max_poses)()
+        n_poses = C.c_uint32(max_poses)
+        cap = max(nq, 1) * max_poses
+        inl = np.zeros(cap, np.uint32)
+        n_inl = C.c_uint32(cap)
+        rc = lib().todhip_verify_2d_device(self._h, C.c_void_p(d_kp_xy), C.c_uint32(nq), _np_ptr(K9), C.c_void_p(d_counts),
+                                           C.c_void_p(d_matches), C.c_void_p(d_xyz), C.c_uint32(k), _np_ptr(sp), C.c_uint32(len(sp)),
+                                           C.byref(prm), C.byref(rng), poses, C.byref(n_poses), _np_ptr(inl), C.byref(n_inl))
+        _check(rc, "todhip_verify_2d_device")
         return [dict(object=int(poses[i].object), R=np.array(poses[i].R[:], np.float32).reshape(3, 3),
                      t=np.array(poses[i].t[:], np.float32),
                      inliers=inl[poses[i].inlier_begin:poses[i].inlier_end].copy()) for i in range(n_poses.value)]

@@ -494,3 +494,40 @@ extern "C" int todhip_verify_2d(todhip_ctx* ctx, const float* kp_xy, uint32_t nq
   ctx->counters.last_poses = np;
   return TODHIP_OK;
 }
+
+// Device-resident form: keypoints and the matcher's fixed-stride outputs (exactly what todhip_match_device / todhip_merge_shards_device
+// produced) are in HBM. The frame's matches are a few tens of KB: they are brought to the host, compacted to CSR and handed to the form
+// above -- the hypotheses and the refinement run on the GPU either way, and the result is the same call's.
+extern "C" int todhip_verify_2d_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const float* K9, const void* d_counts,
+                                       const void* d_matches, const void* d_matches_xyz, uint32_t k, const float* spans, uint32_t n_objs,
+                                       const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
+                                       uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  if (!ctx || !K9 || !prm || !rng || !n_poses || !n_inlier_kp || k == 0) return TODHIP_EINVAL;
+  if (nq && (!d_kp_xy || !d_counts || !d_matches || !d_matches_xyz)) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  std::vector<float> kp(2 * (size_t)nq), xyz_s(3 * (size_t)nq * k);
+  std::vector<uint32_t> counts(nq), row_ptr(nq + 1, 0u);
+  std::vector<todhip_dmatch> m_s((size_t)nq * k);
+  if (nq) {
+    hipStream_t st = ctx->stream;
+    TOD_HIP(hipMemcpyAsync(kp.data(), d_kp_xy, kp.size() * 4, hipMemcpyDeviceToHost, st));
+    TOD_HIP(hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, st));
+    TOD_HIP(hipMemcpyAsync(m_s.data(), d_matches, m_s.size() * sizeof(todhip_dmatch), hipMemcpyDeviceToHost, st));
+    TOD_HIP(hipMemcpyAsync(xyz_s.data(), d_matches_xyz, xyz_s.size() * 4, hipMemcpyDeviceToHost, st));
+    TOD_HIP(hipStreamSynchronize(st));
+  }
+  for (uint32_t q = 0; q < nq; ++q) {
+    if (counts[q] > k) return TODHIP_EINVAL;
+    row_ptr[q + 1] = row_ptr[q] + counts[q];
+  }
+  std::vector<todhip_dmatch> m(row_ptr[nq]);
+  std::vector<float> xyz(3 * (size_t)row_ptr[nq]);
+  for (uint32_t q = 0; q < nq; ++q)
+    for (uint32_t j = 0; j < counts[q]; ++j) {
+      m[row_ptr[q] + j] = m_s[(size_t)q * k + j];
+      std::memcpy(&xyz[3 * (size_t)(row_ptr[q] + j)], &xyz_s[3 * ((size_t)q * k + j)], 12);
+    }
+  return todhip_verify_2d(ctx, kp.data(), nq, K9, row_ptr.data(), m.data(), xyz.data(), spans, n_objs, prm, rng, poses, n_poses, inlier_kp,
+                          n_inlier_kp);
+}
+
