@@ -66,3 +66,37 @@ def test_train_then_detect_recovers_the_view_pose(theta_deg, shift):
     assert np.abs(poses[0]["R"] - R_true).max() < 0.02, (poses[0]["R"], R_true)
     assert np.abs(poses[0]["t"] - t_true).max() < 0.004, (poses[0]["t"], t_true)
     ctx.close()
+
+
+@pytest.mark.parametrize("theta_deg,shift", [(0.0, (0.0, 0.0)), (25.0, (30.0, -18.0)), (-70.0, (-25.0, 22.0))])
+def test_train_then_detect_from_pixels_alone_recovers_the_view_pose(theta_deg, shift):
+    """The same chain without any depth on the detection side: todhip_verify_2d (the PnP branch the reference leaves as a TODO,
+    GuessGenerator.cpp:147-152) on this library's own ORB keypoints and the trained model's 3D points. The recovered pose must be
+    the rendering pose; depth along the optical axis is the weak direction of a PnP solution, hence the wider tolerance on t_z."""
+    Z = 0.8
+    texture = synth.make_image(321)
+    ctx = capi.Context(0)
+    mask = np.zeros((H, W), np.uint8); mask[40:H - 40, 40:W - 40] = 255
+    depth = np.full((H, W), Z, np.float32)
+    model = capi.Model(ctx, 4000)
+    model.add_observation(texture, mask, depth, K, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), n_features=1500, n_levels=3,
+                          scale_factor=1.2)
+    desc, pts = model.finish(); model.close()
+    rng = np.random.Generator(np.random.PCG64(9))
+    d2 = rng.integers(0, 256, (2000, 32), dtype=np.uint8); p2 = (rng.random((2000, 3)) * 0.2).astype(np.float32)
+    off = np.array([0, len(d2), len(d2) + len(desc)], np.uint32)
+    spans = ctx.db_load(np.concatenate([d2, desc]), np.concatenate([p2, pts]), off)
+    theta = np.deg2rad(theta_deg)
+    view = _render(texture, theta, shift, 5)
+    kp, aux, qd = ctx.orb(view, 1000, 3, 1.2)
+    row_ptr, m, xyz = ctx.match(qd, 5, 55)
+    poses = ctx.verify_2d(kp, K, row_ptr, m, xyz, spans, 8, 1000, 3.0, capi.rng_new(1))
+    assert len(poses) == 1 and poses[0]["object"] == 1 and len(poses[0]["inliers"]) > 100
+    c, s = np.cos(theta), np.sin(theta)
+    R_true = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], np.float32)
+    t_true = np.array([shift[0] * Z / F, shift[1] * Z / F, 0.0], np.float32)
+    t_true = t_true + (np.eye(3, dtype=np.float32) - R_true) @ np.array([0, 0, Z], np.float32)
+    assert np.abs(poses[0]["R"] - R_true).max() < 0.02, (poses[0]["R"], R_true)
+    dt = np.abs(poses[0]["t"] - t_true)
+    assert dt[:2].max() < 0.004 and dt[2] < 0.02, (poses[0]["t"], t_true)
+    ctx.close()
