@@ -36,6 +36,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+_T0 = time.perf_counter()
+
+
+def progress(what):
+    """One line per phase on stderr (stdout carries the one JSON line only): a run that is still working says so."""
+    sys.stderr.write("bench.py [%6.1f s] %s\n" % (time.perf_counter() - _T0, what))
+    sys.stderr.flush()
 
 # The HIP runtime maps a process's streams onto 4 hardware queues unless told otherwise (tools/stream_concurrency.py: 4 by
 # default, 8 with more queues; beyond 8 busy queues the driver time-slices them and every launch stalls, so 8 it is).
@@ -510,6 +517,7 @@ def run_configs(torch, capi, synth, device, args):
         if note:
             blk["note"] = note
         sp.close()
+        progress("  config block done: %s" % name[:40])
         return blk
 
     # ---- C1: the reference's own case -- one frame, ORB-500, a 1-object DB, k = 5 (DescriptorMatcher.cpp:211), radius 35
@@ -633,6 +641,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    progress("building the synthetic workload")
     desc, pts, off = synth.make_db(args.objects)
     frames = [synth.make_frame(desc, pts, off, args.nq, frame=f, visible_object=(17 * f + 3) % args.objects)
               for f in range(args.frames)]
@@ -821,16 +830,22 @@ def main():
         if world > 1 or use_dist:
             out["cpu_baseline"] = None                                      # timed at N = 1 only (rank 0)
         else:
+            progress("headline done: %.0f frames/s" % out["value"])
             if "chained" in extras:
                 out["chained"] = run_chained(torch, capi, local_rank, args)
+                progress("chained done")
             if "configs" in extras:
                 out["configs"] = run_configs(torch, capi, synth, local_rank, args)
+                progress("configs done")
             if "adapter" in extras:
                 out["adapter_path"] = run_adapter_path(torch, capi, local_rank, desc, pts, off, frames, args)
+                progress("adapter path done")
             if "hbm" in extras:
                 out["hbm_regime"] = run_hbm_regime(torch, capi, local_rank, args)
+                progress("hbm regime done")
             if "n4" in extras:
                 out["n4"] = run_n4(torch, capi, local_rank, desc, pts, off, frames, args)
+                progress("n4 done")
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,
                                                    args.iterations, args.min_inliers)
