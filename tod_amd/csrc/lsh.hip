@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void lsh_count_kernel(const uint8_t* __restric
                                                         uint32_t n_tables, uint32_t key_size, uint32_t* __restrict__ off) {
   const uint32_t row = blockIdx.x * 256u + threadIdx.x;
   if (row >= n_rows) return;
-  uint8_t d[32];
+  alignas(16) uint8_t d[32];
   const uint4* src = reinterpret_cast<const uint4*>(db + (size_t)row * 32);
   *reinterpret_cast<uint4*>(d) = src[0]; *reinterpret_cast<uint4*>(d + 16) = src[1];
   const size_t stride = ((size_t)1 << key_size) + 1;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void lsh_scatter_kernel(const uint8_t* __restr
                                                           uint32_t* __restrict__ rows) {
   const uint32_t row = blockIdx.x * 256u + threadIdx.x;
   if (row >= n_rows) return;
-  uint8_t d[32];
+  alignas(16) uint8_t d[32];
   const uint4* src = reinterpret_cast<const uint4*>(db + (size_t)row * 32);
   *reinterpret_cast<uint4*>(d) = src[0]; *reinterpret_cast<uint4*>(d + 16) = src[1];
   const uint32_t key = key_of(d, pos, key_size);
