@@ -768,8 +768,12 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
   int all_steps = 1;
   // optional phase profile (diagnostics): cycles in intersection / degree re-sort / colouring, and their counts
   uint32_t pf_isect = 0, pf_sort = 0, pf_col = 0, pf_vfull = 0, pf_big = 0, pf_vbig = 0;
-  uint16_t* cur = L.cur;
-  uint16_t* nxt = L.nxt;
+  // A level's list lives where it will be kept: on the LDS part of the level stack when it fits there whole (the usual case:
+  // the lists of one root-to-leaf path add up to a few thousand entries) -- the child is built in place right behind its
+  // parent's list, nothing is copied down when the search descends and nothing is restored when it returns. A list that does not
+  // fit (the stack continues in global memory) is worked on in one of two LDS buffers and copied to / from the stack as before.
+  auto in_lds = [&](uint32_t b, uint32_t n) { return b + n <= stack.lds_cap; };
+  uint16_t* cur = in_lds(0u, m) ? stack.lds : L.cur;
   // The current level's frame -- list size, S[level], and where its list sits on the stack -- lives in scalar registers;
   // the LDS arrays are only touched when the level changes, and then all of a frame's words come back in ONE LDS round trip
   // (S, SOld, lbase, lsize, lcap are consecutive arrays of `ma` words: lane j reads array j at [level]). A lone wave pays
@@ -790,6 +794,9 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
         // Intersection(p, R, Rp), :209-217 -- order preserving compaction
         const u64* prow = L.adjc + (size_t)p * MW;
         const long long pt0 = prof ? clock64() : 0;
+        const uint32_t nb = base_cur + cap_cur;            // where the child's list goes on the stack
+        const bool in_place = in_lds(nb, sz);              // rp <= sz
+        uint16_t* const nxt = in_place ? stack.lds + nb : (cur == L.cur ? L.nxt : L.cur);
         uint32_t rp = 0;
         for (uint32_t i0 = 0; i0 < sz; i0 += 64u) {
           const uint32_t i = i0 + l;
@@ -824,15 +831,15 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
           if (all_steps > kStepCap) {
             ret = true;                                    // :318-319: returns without popping Q
           } else {
-            const uint32_t nb = base_cur + cap_cur;
             if (nb + rp > stack_cap) { *err = 1; break; }
-            for (uint32_t i = l; i < rp; i += 64u) stk_put(stack, nb + i, nxt[i]);
+            if (!in_place)
+              for (uint32_t i = l; i < rp; i += 64u) stk_put(stack, nb + i, nxt[i]);
             // leave this level: its frame goes to LDS; read the child's S / SOld in the same round trip
             const uint32_t child = frame_word(level + 1u);
             if (l == 0) { L.S[level] = S_cur; L.lsize[level] = sz; L.lbase[level] = base_cur; L.lcap[level] = cap_cur; }
             const uint32_t s_child = rdlane(child, 0u), sold_child = rdlane(child, 1u);
             ++level;
-            { uint16_t* t = cur; cur = nxt; nxt = t; }
+            cur = nxt;
             if (qmax >= minimal_size) {                    // :290-291 at the entry of the child: it returns at once; its S and
               // SOld stay as they were. Its frame must still be readable when the common return path below stores S
               if (l == 0) L.S[level] = s_child;
@@ -871,7 +878,12 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
     __syncthreads();
     const uint32_t fw = frame_word(level);                 // S, -, lbase, lsize, lcap of the caller: one round trip
     S_cur = rdlane(fw, 0u); base_cur = rdlane(fw, 2u); sz = rdlane(fw, 3u) - 1u; cap_cur = rdlane(fw, 4u);   // R.pop_back()
-    for (uint32_t i = l; i < sz; i += 64u) cur[i] = stk_get(stack, base_cur + i);
+    if (in_lds(base_cur, cap_cur)) {
+      cur = stack.lds + base_cur;                          // the caller's list is where it was built
+    } else {
+      cur = L.cur;
+      for (uint32_t i = l; i < sz; i += 64u) cur[i] = stk_get(stack, base_cur + i);
+    }
     __syncthreads();
   }
   if (steps_out) *steps_out = (uint32_t)all_steps;
