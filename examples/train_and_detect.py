@@ -63,6 +63,11 @@ def main():
         print("object %d: %d inlier keypoints\nR =\n%s\nt = %s" % (p["object"], len(p["inliers"]), np.round(p["R"], 4), np.round(p["t"], 4)))
     if poses:
         print("max |R - R_true| = %.4f, max |t - t_true| = %.4f m" % (np.abs(poses[0]["R"] - R_true).max(), np.abs(poses[0]["t"] - t_true).max()))
+    # --- the same detection from pixels alone (no depth, no cloud): the PnP branch, todhip_verify_2d
+    poses2 = ctx.verify_2d(kp, K, row_ptr, matches, xyz, spans, 8, 1000, 3.0, capi.rng_new(1))
+    for p in poses2:
+        print("2D only -- object %d: %d inlier keypoints, max |R - R_true| = %.4f, max |t - t_true| = %.4f m" %
+              (p["object"], len(p["inliers"]), np.abs(p["R"] - R_true).max(), np.abs(p["t"] - t_true).max()))
     ctx.close()
 
 
