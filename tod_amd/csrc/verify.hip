@@ -508,9 +508,19 @@ __device__ __forceinline__ bool colour_first_fit64(const GateLds& L, uint16_t* l
 #pragma unroll
         for (uint32_t w = 0; w < MWT; ++w) next[w] = g[w];
       }
-      uint32_t hit32 = 0u;
+      // (row & class) over all halves: one v_and_or per half. Left to itself the compiler builds and + and + or3 trees, three
+      // instructions per two halves, which is shallower but longer -- and a lone wave is bound by what it must issue, not by depth
+      uint32_t hit32 = (uint32_t)row[0] & cls[0];
+      {
+        const uint32_t rh = (uint32_t)(row[0] >> 32), ch = cls[1];
+        asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(hit32) : "v"(rh), "v"(ch));
+      }
 #pragma unroll
-      for (uint32_t w = 0; w < MWT; ++w) hit32 |= ((uint32_t)row[w] & cls[2u * w]) | ((uint32_t)(row[w] >> 32) & cls[2u * w + 1u]);
+      for (uint32_t w = 1; w < MWT; ++w) {
+        const uint32_t rl = (uint32_t)row[w], rh = (uint32_t)(row[w] >> 32), cl = cls[2u * w], ch = cls[2u * w + 1u];
+        asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(hit32) : "v"(rl), "v"(cl));
+        asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(hit32) : "v"(rh), "v"(ch));
+      }
       const u64 fm = __ballot(hit32 == 0u);                // classes without a neighbour of v
       const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
       const uint32_t lw = hit32 == 0u ? below : 1u;
