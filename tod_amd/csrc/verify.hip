@@ -496,15 +496,18 @@ __device__ __forceinline__ bool colour_first_fit64(const GateLds& L, uint16_t* l
   // picked with the hardware's register indexing (s_set_gpr_idx, the index v >> 5 is wave-uniform) -- three instructions to read,
   // three to write, no branch tree and no per-word selects
   u32x16 cls = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  uint32_t cnt0 = 0u;                                      // members of class l so far
+  uint32_t rec = l << 16;                                  // (class l, members of class l so far): what a joining vertex records
   uint32_t* const my_trash = L.trash + l;
   for (uint32_t c0 = 0; c0 < r; c0 += 64u) {
     const uint32_t cnt = min(64u, r - c0);
-    const uint32_t vmine = (c0 + l) < r ? (uint32_t)list[c0 + l] : 0u;
+    // lanes past the list hold its last vertex, so that the row prefetch one vertex ahead needs no clamp (lane 64 wraps to lane 0:
+    // any vertex will do, the row is never used); and every lane keeps the BYTE offset of its vertex's row next to the vertex
+    const uint32_t vmine = (uint32_t)list[min(c0 + l, r - 1u)];
+    const uint32_t voff = vmine * (MWT * 8u);
     auto place = [&](const u64 (&row)[MWT], u64 (&next)[MWT], uint32_t li) {
       const uint32_t v = rdlane(vmine, li);
       {
-        const u64* g = L.adjc + (size_t)rdlane(vmine, min(li + 1u, cnt - 1u)) * MWT;   // the chunk's last re-reads itself
+        const u64* g = reinterpret_cast<const u64*>(reinterpret_cast<const unsigned char*>(L.adjc) + rdlane(voff, (li + 1u) & 63u));
 #pragma unroll
         for (uint32_t w = 0; w < MWT; ++w) next[w] = g[w];
       }
@@ -526,8 +529,8 @@ __device__ __forceinline__ bool colour_first_fit64(const GateLds& L, uint16_t* l
       const uint32_t lw = hit32 == 0u ? below : 1u;
       const bool join = lw == 0u;                          // the first free class: exactly one lane, or none (overflow)
       uint32_t* const dst = join ? (L.keys + (c0 + li)) : my_trash;
-      *dst = (l << 16) | cnt0;                             // (class, rank inside the class) of position c0 + li
-      cnt0 += join ? 1u : 0u;
+      *dst = rec;                                          // (class, rank inside the class) of position c0 + li
+      rec += join ? 1u : 0u;
       cls[v >> 5] |= join ? (1u << (v & 31u)) : 0u;
     };
     u64 rowA[MWT], rowB[MWT];
@@ -543,6 +546,7 @@ __device__ __forceinline__ bool colour_first_fit64(const GateLds& L, uint16_t* l
     }
     if (li < cnt) place(rowA, rowB, li);
   }
+  const uint32_t cnt0 = rec & 0xFFFFu;                     // members of class l
   const uint32_t incl0 = wave_incl_scan(cnt0), total0 = uni(__shfl(incl0, 63));
   if (total0 != r) return false;                           // a vertex found no free class among 64
   const uint32_t base0 = incl0 - cnt0;
