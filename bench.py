@@ -64,8 +64,8 @@ LANEOPS_DENSE = 16                                  # 8 v_xor_b32 + 8 accumulati
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200, help="steps per timed region (200 x 16 frames at ~1.4 ms: 0.3 s per region)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=3, help="the timed region of --steps steps is run this many times; value = median")
     ap.add_argument("--objects", type=int, default=200, help="objects of 5000 descriptors (200 -> 1M rows)")
     ap.add_argument("--nq", type=int, default=1000)
@@ -341,7 +341,7 @@ def run_chained(torch, capi, device, args):
     pipe.reset_stats()
     mctx.set_kernel_timing(True)
     c0 = mctx.counters()
-    steps = max(args.steps, 8 * D)                                        # long enough that filling and draining D batches in flight is a few per cent
+    steps = min(max(args.steps, 8 * D), 120)                              # long enough that filling and draining D batches in flight is a few per cent
     secs = timed_regions(torch, pipe.run, torch.cuda.synchronize, steps, args.repeats)
     c1 = mctx.counters()
     k_ms, n_l = launch_ms(c0, c1)
