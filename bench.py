@@ -53,7 +53,7 @@ HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E
 MFMA_FP4_PEAK_TFLOPS = 10000.0                      # MI355X_MICROARCH.md: FP6/FP4 MFMA ~10 PF dense
 MFMA_BF16_PEAK_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: BF16 MFMA ~2.5 PF dense
 MFMA_BF16_MEASURED_TFLOPS = 1840.0                  # profiles/r02_mfma_bf16_peak_microbench.txt: bare loop, random bf16 operands, sustained
-L2_PASS2_US = 110.9                                 # profiles/r02_l2_kernel_stats.csv: l2_gemm_kernel<2, 4> at the C4 shape
+L2_PASS2_US = 115.0                                 # profiles/r02_l2_kernel_stats.csv: l2_gemm_kernel<2, 4> at the C4 shape (111-118 us across runs and boxes)
 FLOP_PER_PAIR = 512.0                               # a 256-bit Hamming distance on the matrix cores = 256 multiply-adds
 # 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) issue at 16 lanes/clk/SIMD on gfx950 (tools/valu_peak.hip,
 # profiles/r01_valu_peak_microbench.txt: 38-40 T lane-op/s): the roof of the vector-ALU engine (--engine valu)

@@ -71,9 +71,13 @@ __device__ __forceinline__ uint16_t bf16_rne(float x) {
 // frag != 0 (the DB image): a 32-row tile is stored in MFMA A-fragment order -- 8 segments (k-steps s) of 64 lanes x 16 bytes,
 // lane (h = l >> 5, r = l & 31) of segment s holding A[row r][k = 16 s + 8 h + j], j = 0..7 -- so that one wave-load of a
 // segment is 1 KB contiguous AND already the register image v_mfma_f32_32x32x16_bf16 wants: no LDS staging, no swizzle
+// query side (rmax2_bits != nullptr): eps(q) from |q|^2 and Rmax^2 is written too, and the query's shared candidate counter is zeroed
+// (two launches less per call)
 __global__ __launch_bounds__(256) void l2_prepare_kernel(const float* __restrict__ src, uint32_t n, uint32_t n_pad, float scale,
                                                          uint16_t* __restrict__ dst, float* __restrict__ norm2,
-                                                         uint32_t* __restrict__ max_norm2_bits, int frag) {
+                                                         uint32_t* __restrict__ max_norm2_bits, int frag,
+                                                         const uint32_t* __restrict__ rmax2_bits = nullptr, float* __restrict__ eps = nullptr,
+                                                         uint32_t* __restrict__ zero_cnt = nullptr) {
   const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
   if (row >= n_pad) return;
   float a = 0.f, b = 0.f;
@@ -87,18 +91,15 @@ __global__ __launch_bounds__(256) void l2_prepare_kernel(const float* __restrict
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (l == 0) {
-    norm2[row] = row < n ? s : 3.0e38f;                     // a padding row can never be a candidate
+    const float n2 = row < n ? s : 3.0e38f;                 // a padding row can never be a candidate
+    norm2[row] = n2;
     if (row < n && max_norm2_bits) atomicMax(max_norm2_bits, __float_as_uint(s));
+    if (rmax2_bits) {
+      const float nq = sqrtf(n2), rmax = sqrtf(__uint_as_float(*rmax2_bits));
+      eps[row] = 0.0079345703125f * nq * rmax + 6.103515625e-05f * (nq + rmax) * (nq + rmax);   // 2^-7 (1 + 2^-6), 2^-14
+      zero_cnt[row] = 0u;
+    }
   }
-}
-
-// eps(q) from |q|^2 (norm2 of the query image) and Rmax^2
-__global__ __launch_bounds__(256) void l2_eps_kernel(const float* __restrict__ qnorm2, uint32_t nq_pad,
-                                                     const uint32_t* __restrict__ max_norm2_bits, float* __restrict__ eps) {
-  const uint32_t q = blockIdx.x * 256u + threadIdx.x;
-  if (q >= nq_pad) return;
-  const float nq = sqrtf(qnorm2[q]), rmax = sqrtf(__uint_as_float(*max_norm2_bits));
-  eps[q] = 0.0079345703125f * nq * rmax + 6.103515625e-05f * (nq + rmax) * (nq + rmax);   // 2^-7 (1 + 2^-6), 2^-14
 }
 
 // Where pass 2 puts a lane's candidates. A lane is the only writer for (query, chunk, lane half): its first kSlot rows go to a
@@ -548,10 +549,8 @@ static int l2_keys(todhip_ctx* ctx, const float* d_q, uint32_t nq, uint32_t k, i
   float* qnorm = ws->q_eps.as<float>() + nq_pad;
   // queries: bf16 image pre-scaled by -2 (a power of two: no extra rounding), |q|^2, eps
   hipLaunchKernelGGL(l2_prepare_kernel, dim3((nq_pad + 3u) / 4u), dim3(256), 0, st, d_q, nq, nq_pad, -2.0f,
-                     ws->q_bf16.as<uint16_t>(), qnorm, (uint32_t*)nullptr, 0);
-  hipLaunchKernelGGL(l2_eps_kernel, dim3((nq_pad + 255u) / 256u), dim3(256), 0, st, qnorm, nq_pad, ws->scal.as<uint32_t>(),
-                     ws->q_eps.as<float>());
-  TOD_HIP(hipMemsetAsync(ws->cand_cnt.p, 0, (size_t)nq_pad * 4, st));
+                     ws->q_bf16.as<uint16_t>(), qnorm, (uint32_t*)nullptr, 0, (const uint32_t*)ws->scal.as<uint32_t>(), ws->q_eps.as<float>(),
+                     ws->cand_cnt.as<uint32_t>());
   const uint32_t k_eff = std::min(k, std::max(1u, n));
   auto gemm1 = k_eff <= 4u ? l2_gemm_kernel<1, 4> : l2_gemm_kernel<1, 8>;
   float* const d_seed = ws->thr.as<float>() + nq_pad;
