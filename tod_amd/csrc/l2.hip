@@ -241,8 +241,13 @@ __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restr
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_" width_ " %0, %1" :: "v"(voff_), "s"(gaddr_), "s"(lds_) : "memory", "m0")
   auto issue = [&](uint32_t tile, uint32_t slot) {
     tile = min(tile, t_end - 1u);                           // past the chunk: a harmless reload, the count per tile stays 9
-    const uint64_t g = (uint64_t)(db + (size_t)tile * tile_stride * (kTileRows * kDim));
-    const uint64_t gn = (uint64_t)(dbn + (size_t)tile * tile_stride * kTileRows);
+    // (the addresses are wave-uniform; readfirstlane says so in a way the "s" constraints below can rely on)
+    auto uniform64 = [](uint64_t v) {
+      return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    const uint64_t g = uniform64((uint64_t)(db + (size_t)tile * tile_stride * (kTileRows * kDim)));
+    const uint64_t gn = uniform64((uint64_t)(dbn + (size_t)tile * tile_stride * kTileRows));
     const uint32_t lds = ring_lds + slot * kRingSlotBytes;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot's previous tile has been read out
 #pragma unroll
