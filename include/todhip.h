@@ -252,6 +252,14 @@ int todhip_verify_2d_device(todhip_ctx*, const void* d_kp_xy, uint32_t nq, const
                             const void* d_matches_xyz, uint32_t k, const float* spans, uint32_t n_objs, const todhip_verify_params*,
                             todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp);
 
+/* A batch of n_frames frames in the launches of one (the layout of todhip_verify_batch_device: per-frame arrays back to back,
+ * rng[n_frames], poses of frame f at poses[pose_ptr[f] .. pose_ptr[f+1]), inlier_kp frame-local). Each frame's result equals the
+ * single-frame call's. */
+int todhip_verify_2d_batch_device(todhip_ctx*, uint32_t n_frames, const void* d_kp_xy, uint32_t nq, const float* K9, const void* d_counts,
+                                  const void* d_matches, const void* d_matches_xyz, uint32_t k, const float* spans, uint32_t n_objs,
+                                  const todhip_verify_params*, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
+                                  uint32_t* pose_ptr, uint32_t* inlier_kp, uint32_t* n_inlier_kp);
+
 /* ---- training ----------------------------------------------------------------- */
 /* Per-observation arithmetic of the reference's Trainer cell (src/training/Trainer.cpp:121-187, training.cpp:57-195):
  * ORB on the masked view (the reference uses cv::ORB defaults: 500 features, 8 levels, scale 1.2 -- :148-149),

@@ -102,3 +102,35 @@ def test_device_form_after_the_device_matcher_equals_the_host_form(ctx):
     assert np.array_equal(host[0]["R"], dev[0]["R"]) and np.array_equal(host[0]["t"], dev[0]["t"]) and np.array_equal(host[0]["inliers"], dev[0]["inliers"])
     assert np.abs(dev[0]["R"] - synth.pose_R()).max() < 0.03 and np.abs(dev[0]["t"] - synth.POSE_T).max() < 0.015
 
+
+def test_batch_of_frames_equals_frame_by_frame(ctx):
+    """todhip_match_device on 5 frames' descriptors -> todhip_verify_2d_batch_device == the single-frame host form per frame (objects,
+    poses, consensus sets bit for bit; every generator advanced by its one draw); one frame has no visible object, one pads with counts 0."""
+    import torch
+    desc, pts, off = synth.make_db(8, per_object=600)
+    nq, k, F = 400, 2, 5
+    frames = [synth.make_frame(desc, pts, off, nq, frame=20 + f, visible_object=(3 * f) % 8) for f in range(F)]
+    frames[3]["q_desc"] = np.random.Generator(np.random.PCG64(1)).integers(0, 256, (nq, 32), dtype=np.uint8)        # clutter only
+    spans = ctx.db_load(desc, pts, off)
+    d_q = torch.from_numpy(np.concatenate([fr["q_desc"] for fr in frames])).cuda()
+    d_kp = torch.from_numpy(np.concatenate([fr["kp_xy"] for fr in frames])).cuda()
+    cnt = torch.zeros(F * nq, dtype=torch.int32, device="cuda"); mm = torch.zeros((F * nq * k, 4), dtype=torch.int32, device="cuda")
+    xx = torch.zeros((F * nq * k, 3), dtype=torch.float32, device="cuda")
+    ctx.match_device(d_q.data_ptr(), F * nq, k, 35, cnt.data_ptr(), mm.data_ptr(), xx.data_ptr())
+    cnt.view(F, nq)[4, 300:] = 0                                                  # frame 4 has only 300 keypoints
+    rngs = (capi.Rng * F)(*[capi.rng_new(3 + f) for f in range(F)])
+    got = ctx.verify_2d_batch_device(F, d_kp.data_ptr(), nq, K, cnt.data_ptr(), mm.data_ptr(), xx.data_ptr(), k, spans, 8, 300, 3.0, rngs)
+    n_found = 0
+    for f, fr in enumerate(frames):
+        q = fr["q_desc"] if f != 4 else fr["q_desc"][:300]
+        kp = fr["kp_xy"] if f != 4 else fr["kp_xy"][:300]
+        row_ptr, m, xyz = ctx.match(q, k, 35)
+        rng = capi.rng_new(3 + f)
+        want = ctx.verify_2d(kp, K, row_ptr, m, xyz, spans, 8, 300, 3.0, rng)
+        assert rngs[f].draws == rng.draws == 1
+        assert [p["object"] for p in got[f]] == [p["object"] for p in want], f
+        for g, w in zip(got[f], want):
+            assert np.array_equal(g["R"], w["R"]) and np.array_equal(g["t"], w["t"]) and np.array_equal(g["inliers"], w["inliers"])
+        n_found += len(want)
+    assert got[3] == [] and n_found >= 3
+

@@ -60,7 +60,7 @@ EXPORTS = [
     "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
     "todhip_match_l2", "todhip_match_l2_device",
     "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
-    "todhip_rescale_depth", "todhip_rescale_depth_device", "todhip_verify_2d", "todhip_verify_2d_device", "todhip_set_lsh",
+    "todhip_rescale_depth", "todhip_rescale_depth_device", "todhip_verify_2d", "todhip_verify_2d_device", "todhip_verify_2d_batch_device", "todhip_set_lsh",
 ]
 
 _lib = None
@@ -303,6 +303,28 @@ class Context:
         return [dict(object=int(poses[i].object), R=np.array(poses[i].R[:], np.float32).reshape(3, 3),
                      t=np.array(poses[i].t[:], np.float32),
                      inliers=inl[poses[i].inlier_begin:poses[i].inlier_end].copy()) for i in range(n_poses.value)]
+
+    def verify_2d_batch_device(self, n_frames, d_kp_xy, nq, K, d_counts, d_matches, d_xyz, k, spans, min_inliers, n_iter, err_px, rngs,
+                               max_poses=16):
+        """rngs: ctypes array (Rng * n_frames). Returns a list (per frame) of lists of pose dicts."""
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        sp = np.ascontiguousarray(spans, np.float32)
+        prm = VerifyParams(min_inliers, n_iter, err_px)
+        cap_p = max_poses * n_frames
+        poses = (Pose * cap_p)()
+        n_poses = C.c_uint32(cap_p)
+        pose_ptr = (C.c_uint32 * (n_frames + 1))()
+        cap = max(nq, 1) * cap_p
+        inl = np.zeros(cap, np.uint32)
+        n_inl = C.c_uint32(cap)
+        rc = lib().todhip_verify_2d_batch_device(self._h, C.c_uint32(n_frames), C.c_void_p(d_kp_xy), C.c_uint32(nq), _np_ptr(K9),
+                                                 C.c_void_p(d_counts), C.c_void_p(d_matches), C.c_void_p(d_xyz), C.c_uint32(k), _np_ptr(sp),
+                                                 C.c_uint32(len(sp)), C.byref(prm), rngs, poses, C.byref(n_poses), pose_ptr, _np_ptr(inl),
+                                                 C.byref(n_inl))
+        _check(rc, "todhip_verify_2d_batch_device")
+        return [[dict(object=int(poses[i].object), R=np.array(poses[i].R[:], np.float32).reshape(3, 3), t=np.array(poses[i].t[:], np.float32),
+                      inliers=inl[poses[i].inlier_begin:poses[i].inlier_end].copy()) for i in range(pose_ptr[f], pose_ptr[f + 1])]
+                for f in range(n_frames)]
 
     def verify_device(self, d_kp_xy, nq, d_cloud, H, W, d_counts, d_matches, d_xyz, k, spans, min_inliers, n_iter,
                       err, rng, max_poses=64):

@@ -29,7 +29,7 @@ namespace {
 
 struct Cam { double fx, fy, cx, cy; };
 struct PoseD { double R[9], t[3]; };
-struct ObjSpanP { uint32_t begin, n, object; float span; };
+struct ObjSpanP { uint32_t begin, n, object; float span; uint32_t seed, frame; };   // one object of one frame of the batch
 struct ObjResult { uint32_t valid, n_inliers; float R[9], t[3]; };
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
@@ -218,14 +218,14 @@ __device__ int sample_poses(const Cam& cam, const float* kp_xy, const uint32_t* 
 // is the largest consensus set and among equals the first (hypothesis, root) -- what a sequential walk with `>` keeps
 __global__ __launch_bounds__(256) void pnp_hypotheses_kernel(const ObjSpanP* __restrict__ objs, const float* __restrict__ kp_xy,
                                                              const uint32_t* __restrict__ q_idx_all, const float* __restrict__ X_all, Cam cam,
-                                                             uint32_t seed, uint32_t n_hyp, double err2, unsigned long long* __restrict__ best) {
+                                                             uint32_t n_hyp, double err2, unsigned long long* __restrict__ best) {
   const ObjSpanP o = objs[blockIdx.y];
   const uint32_t hyp = blockIdx.x * 256u + threadIdx.x;
   const uint32_t* q_idx = q_idx_all + o.begin;
   const float* X = X_all + 3 * (size_t)o.begin;
   unsigned long long key = 0ull;
   uint32_t s3[3];
-  if (hyp < n_hyp && draw_sample(seed, o.object, hyp, o.n, kp_xy, q_idx, X, o.span, s3)) {
+  if (hyp < n_hyp && draw_sample(o.seed, o.object, hyp, o.n, kp_xy, q_idx, X, o.span, s3)) {
     PoseD sol[4];
     const int ns = sample_poses(cam, kp_xy, q_idx, X, s3, sol);
     for (int s = 0; s < ns; ++s) {
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void pnp_hypotheses_kernel(const ObjSpanP* __r
 // PNPR. One block of 64 lanes per active object (declared for 128 so that __syncthreads stays a real barrier).
 __global__ __launch_bounds__(128) void pnp_refine_kernel(const ObjSpanP* __restrict__ objs, const float* __restrict__ kp_xy,
                                                          const uint32_t* __restrict__ q_idx_all, const float* __restrict__ X_all, Cam cam,
-                                                         uint32_t seed, double err2, uint32_t min_inliers,
+                                                         double err2, uint32_t min_inliers,
                                                          const unsigned long long* __restrict__ best, uint8_t* __restrict__ flags_all,
                                                          ObjResult* __restrict__ results) {
   const ObjSpanP o = objs[blockIdx.x];
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(128) void pnp_refine_kernel(const ObjSpanP* __restr
   if (l == 0) {
     uint32_t s3[3];
     PoseD sol[4];
-    draw_sample(seed, o.object, code >> 2, o.n, kp_xy, q_idx, X, o.span, s3);
+    draw_sample(o.seed, o.object, code >> 2, o.n, kp_xy, q_idx, X, o.span, s3);
     sample_poses(cam, kp_xy, q_idx, X, s3, sol);
     s_pose = sol[code & 3u];
   }
@@ -410,36 +410,52 @@ void tod_pnp_ws_free(todhip_ctx* ctx) {
   ctx->pnp_ws = nullptr;
 }
 
-extern "C" int todhip_verify_2d(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float* K9, const uint32_t* row_ptr,
-                                const todhip_dmatch* matches, const float* matches_xyz, const float* spans, uint32_t n_objs,
-                                const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
-                                uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
-  if (!ctx || !K9 || !row_ptr || !prm || !rng || !n_poses || !n_inlier_kp || (nq && !kp_xy)) return TODHIP_EINVAL;
+// One batch: per frame host arrays (keypoints, CSR matches), one generator per frame. The objects of all frames go through the two
+// kernels together (a frame's keypoints sit at frame * nq in the device array, q_idx carries that offset); poses come back per frame.
+struct Frame2d { const float* kp_xy; const uint32_t* row_ptr; const todhip_dmatch* matches; const float* matches_xyz; };
+
+static int verify_2d_core(todhip_ctx* ctx, uint32_t F, const Frame2d* fr, uint32_t nq, const float* K9, const float* spans, uint32_t n_objs,
+                          const todhip_verify_params* prm, todhip_rng* rngs, todhip_pose* poses, uint32_t* n_poses, uint32_t* pose_ptr,
+                          uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
   if (!(prm->sensor_error > 0.f) || !(K9[0] > 0.f) || !(K9[4] > 0.f)) return TODHIP_EINVAL;
-  const uint32_t n_matches = row_ptr[nq];
-  if (n_matches && (!matches || !matches_xyz || !spans)) return TODHIP_EINVAL;
   if ((*n_poses && !poses) || (*n_inlier_kp && !inlier_kp)) return TODHIP_EINVAL;
-  for (uint32_t m = 0; m < n_matches; ++m)
-    if (matches[m].imgIdx < 0 || (uint32_t)matches[m].imgIdx >= n_objs) return TODHIP_EINVAL;
+  size_t n_all = 0;
+  for (uint32_t f = 0; f < F; ++f) {
+    const uint32_t nm = fr[f].row_ptr[nq];
+    if (nm && (!fr[f].matches || !fr[f].matches_xyz || !spans)) return TODHIP_EINVAL;
+    for (uint32_t m = 0; m < nm; ++m)
+      if (fr[f].matches[m].imgIdx < 0 || (uint32_t)fr[f].matches[m].imgIdx >= n_objs) return TODHIP_EINVAL;
+    n_all += nm;
+  }
+  if (n_all > 0xFFFFFFFFull || (uint64_t)F * nq > 0xFFFFFFFFull) return TODHIP_EINVAL;
   TOD_HIP(hipSetDevice(ctx->device));
-  const uint32_t seed = rng_next(*rng);                               // the one draw a frame costs
   const uint32_t cap_poses = *n_poses, cap_inl = *n_inlier_kp;
   *n_poses = 0; *n_inlier_kp = 0;
-  // ClusterPerObject (adjacency_ransac.cpp:176-205): per object, matches in CSR order
-  std::vector<uint32_t> cnt(n_objs + 1, 0u);
-  for (uint32_t m = 0; m < n_matches; ++m) cnt[(uint32_t)matches[m].imgIdx + 1]++;
-  for (uint32_t o = 0; o < n_objs; ++o) cnt[o + 1] += cnt[o];
-  std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1), q_idx(n_matches);
-  std::vector<float> X(3 * (size_t)n_matches);
-  for (uint32_t q = 0; q < nq; ++q)
-    for (uint32_t m = row_ptr[q]; m < row_ptr[q + 1]; ++m) {
-      const uint32_t at = fill[(uint32_t)matches[m].imgIdx]++;
-      q_idx[at] = q; std::memcpy(&X[3 * (size_t)at], matches_xyz + 3 * (size_t)m, 3 * sizeof(float));
-    }
+  if (pose_ptr) for (uint32_t f = 0; f <= F; ++f) pose_ptr[f] = 0;
+  // ClusterPerObject (adjacency_ransac.cpp:176-205) per frame: per object, matches in CSR order
+  std::vector<uint32_t> q_idx(n_all);
+  std::vector<float> X(3 * n_all), kp_all(2 * (size_t)F * nq);
   std::vector<ObjSpanP> active;
-  for (uint32_t o = 0; o < n_objs; ++o) {
-    const uint32_t n = cnt[o + 1] - cnt[o];
-    if (n >= 3u && n >= prm->min_inliers) active.push_back(ObjSpanP{cnt[o], n, o, spans[o]});
+  std::vector<uint32_t> cnt(n_objs + 1), fill(n_objs);
+  size_t base = 0;
+  for (uint32_t f = 0; f < F; ++f) {
+    const uint32_t seed = rng_next(rngs[f]);                           // the one draw a frame costs
+    if (nq) std::memcpy(&kp_all[2 * (size_t)f * nq], fr[f].kp_xy, (size_t)nq * 8);
+    const uint32_t nm = fr[f].row_ptr[nq];
+    std::fill(cnt.begin(), cnt.end(), 0u);
+    for (uint32_t m = 0; m < nm; ++m) cnt[(uint32_t)fr[f].matches[m].imgIdx + 1]++;
+    for (uint32_t o = 0; o < n_objs; ++o) cnt[o + 1] += cnt[o];
+    std::copy(cnt.begin(), cnt.end() - 1, fill.begin());
+    for (uint32_t q = 0; q < nq; ++q)
+      for (uint32_t m = fr[f].row_ptr[q]; m < fr[f].row_ptr[q + 1]; ++m) {
+        const size_t at = base + fill[(uint32_t)fr[f].matches[m].imgIdx]++;
+        q_idx[at] = f * nq + q; std::memcpy(&X[3 * at], fr[f].matches_xyz + 3 * (size_t)m, 3 * sizeof(float));
+      }
+    for (uint32_t o = 0; o < n_objs; ++o) {
+      const uint32_t n = cnt[o + 1] - cnt[o];
+      if (n >= 3u && n >= prm->min_inliers) active.push_back(ObjSpanP{(uint32_t)(base + cnt[o]), n, o, spans[o], seed, f});
+    }
+    base += nm;
   }
   if (active.empty() || prm->n_ransac_iterations == 0) return TODHIP_OK;
   if (!ctx->pnp_ws) ctx->pnp_ws = new PnpWs();
@@ -447,33 +463,33 @@ extern "C" int todhip_verify_2d(todhip_ctx* ctx, const float* kp_xy, uint32_t nq
   hipStream_t st = ctx->stream;
   const uint32_t na = (uint32_t)active.size();
   TOD_HIP(ws->objs.reserve(na * sizeof(ObjSpanP)));
-  TOD_HIP(ws->kp.reserve((size_t)nq * 8));
-  TOD_HIP(ws->q_idx.reserve((size_t)n_matches * 4));
-  TOD_HIP(ws->X.reserve((size_t)n_matches * 12));
+  TOD_HIP(ws->kp.reserve(kp_all.size() * 4));
+  TOD_HIP(ws->q_idx.reserve(n_all * 4));
+  TOD_HIP(ws->X.reserve(n_all * 12));
   TOD_HIP(ws->best.reserve((size_t)na * 8));
-  TOD_HIP(ws->flags.reserve(n_matches));
+  TOD_HIP(ws->flags.reserve(n_all));
   TOD_HIP(ws->results.reserve((size_t)na * sizeof(ObjResult)));
   TOD_HIP(hipMemcpyAsync(ws->objs.p, active.data(), na * sizeof(ObjSpanP), hipMemcpyHostToDevice, st));
-  TOD_HIP(hipMemcpyAsync(ws->kp.p, kp_xy, (size_t)nq * 8, hipMemcpyHostToDevice, st));
-  TOD_HIP(hipMemcpyAsync(ws->q_idx.p, q_idx.data(), (size_t)n_matches * 4, hipMemcpyHostToDevice, st));
-  TOD_HIP(hipMemcpyAsync(ws->X.p, X.data(), (size_t)n_matches * 12, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->kp.p, kp_all.data(), kp_all.size() * 4, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->q_idx.p, q_idx.data(), n_all * 4, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->X.p, X.data(), n_all * 12, hipMemcpyHostToDevice, st));
   TOD_HIP(hipMemsetAsync(ws->best.p, 0, (size_t)na * 8, st));
   const Cam cam{(double)K9[0], (double)K9[4], (double)K9[2], (double)K9[5]};
   const double err2 = (double)prm->sensor_error * (double)prm->sensor_error;
   hipLaunchKernelGGL(pnp_hypotheses_kernel, dim3((prm->n_ransac_iterations + 255u) / 256u, na), dim3(256), 0, st, ws->objs.as<ObjSpanP>(),
-                     ws->kp.as<float>(), ws->q_idx.as<uint32_t>(), ws->X.as<float>(), cam, seed, prm->n_ransac_iterations, err2,
+                     ws->kp.as<float>(), ws->q_idx.as<uint32_t>(), ws->X.as<float>(), cam, prm->n_ransac_iterations, err2,
                      ws->best.as<unsigned long long>());
   hipLaunchKernelGGL(pnp_refine_kernel, dim3(na), dim3(64), 0, st, ws->objs.as<ObjSpanP>(), ws->kp.as<float>(), ws->q_idx.as<uint32_t>(),
-                     ws->X.as<float>(), cam, seed, err2, prm->min_inliers, ws->best.as<unsigned long long>(), ws->flags.as<uint8_t>(),
+                     ws->X.as<float>(), cam, err2, prm->min_inliers, ws->best.as<unsigned long long>(), ws->flags.as<uint8_t>(),
                      ws->results.as<ObjResult>());
   TOD_HIP(hipGetLastError());
   std::vector<ObjResult> res(na);
-  std::vector<uint8_t> flags(n_matches);
+  std::vector<uint8_t> flags(n_all);
   TOD_HIP(hipMemcpyAsync(res.data(), ws->results.p, (size_t)na * sizeof(ObjResult), hipMemcpyDeviceToHost, st));
-  TOD_HIP(hipMemcpyAsync(flags.data(), ws->flags.p, n_matches, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipMemcpyAsync(flags.data(), ws->flags.p, n_all, hipMemcpyDeviceToHost, st));
   TOD_HIP(hipStreamSynchronize(st));
   uint32_t np = 0, ni = 0;
-  for (uint32_t a = 0; a < na; ++a) {
+  for (uint32_t a = 0; a < na; ++a) {                                   // frame major, objects ascending inside a frame
     if (!res[a].valid) continue;
     if (np >= cap_poses) return TODHIP_ECAPACITY;
     todhip_pose& out = poses[np];
@@ -481,34 +497,47 @@ extern "C" int todhip_verify_2d(todhip_ctx* ctx, const float* kp_xy, uint32_t nq
     std::memcpy(out.R, res[a].R, sizeof(out.R)); std::memcpy(out.t, res[a].t, sizeof(out.t));
     out.inlier_begin = ni;
     uint32_t last = 0xFFFFFFFFu;
-    for (uint32_t m = 0; m < active[a].n; ++m) {                       // keypoint indices, ascending, each once
-      const uint32_t q = q_idx[active[a].begin + m];
+    for (uint32_t m = 0; m < active[a].n; ++m) {                       // keypoint indices of the frame, ascending, each once
+      const uint32_t q = q_idx[active[a].begin + m] - active[a].frame * nq;
       if (!flags[active[a].begin + m] || q == last) continue;
       if (ni >= cap_inl) return TODHIP_ECAPACITY;
       inlier_kp[ni++] = last = q;
     }
     out.inlier_end = ni;
     ++np;
+    if (pose_ptr) pose_ptr[active[a].frame + 1] = np;
   }
+  if (pose_ptr) for (uint32_t f = 0; f < F; ++f) pose_ptr[f + 1] = std::max(pose_ptr[f + 1], pose_ptr[f]);   // frames without a pose
   *n_poses = np; *n_inlier_kp = ni;
   ctx->counters.last_poses = np;
   return TODHIP_OK;
 }
 
-// Device-resident form: keypoints and the matcher's fixed-stride outputs (exactly what todhip_match_device / todhip_merge_shards_device
-// produced) are in HBM. The frame's matches are a few tens of KB: they are brought to the host, compacted to CSR and handed to the form
-// above -- the hypotheses and the refinement run on the GPU either way, and the result is the same call's.
-extern "C" int todhip_verify_2d_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const float* K9, const void* d_counts,
-                                       const void* d_matches, const void* d_matches_xyz, uint32_t k, const float* spans, uint32_t n_objs,
-                                       const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
-                                       uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
-  if (!ctx || !K9 || !prm || !rng || !n_poses || !n_inlier_kp || k == 0) return TODHIP_EINVAL;
+extern "C" int todhip_verify_2d(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float* K9, const uint32_t* row_ptr,
+                                const todhip_dmatch* matches, const float* matches_xyz, const float* spans, uint32_t n_objs,
+                                const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
+                                uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  if (!ctx || !K9 || !row_ptr || !prm || !rng || !n_poses || !n_inlier_kp || (nq && !kp_xy)) return TODHIP_EINVAL;
+  const Frame2d fr = {kp_xy, row_ptr, matches, matches_xyz};
+  return verify_2d_core(ctx, 1, &fr, nq, K9, spans, n_objs, prm, rng, poses, n_poses, nullptr, inlier_kp, n_inlier_kp);
+}
+
+// Device-resident forms: keypoints and the matcher's fixed-stride outputs (exactly what todhip_match_device / todhip_merge_shards_device
+// produced, for n_frames * nq queries) are in HBM. The matches are a few tens of KB per frame: they are brought to the host, compacted to
+// CSR and handed to the core above -- hypotheses and refinement run on the GPU either way, and each frame's result is the single call's.
+extern "C" int todhip_verify_2d_batch_device(todhip_ctx* ctx, uint32_t n_frames, const void* d_kp_xy, uint32_t nq, const float* K9,
+                                             const void* d_counts, const void* d_matches, const void* d_matches_xyz, uint32_t k,
+                                             const float* spans, uint32_t n_objs, const todhip_verify_params* prm, todhip_rng* rng,
+                                             todhip_pose* poses, uint32_t* n_poses, uint32_t* pose_ptr, uint32_t* inlier_kp,
+                                             uint32_t* n_inlier_kp) {
+  if (!ctx || !K9 || !prm || !rng || !n_poses || !n_inlier_kp || k == 0 || n_frames == 0) return TODHIP_EINVAL;
   if (nq && (!d_kp_xy || !d_counts || !d_matches || !d_matches_xyz)) return TODHIP_EINVAL;
   TOD_HIP(hipSetDevice(ctx->device));
-  std::vector<float> kp(2 * (size_t)nq), xyz_s(3 * (size_t)nq * k);
-  std::vector<uint32_t> counts(nq), row_ptr(nq + 1, 0u);
-  std::vector<todhip_dmatch> m_s((size_t)nq * k);
-  if (nq) {
+  const size_t nqa = (size_t)n_frames * nq;
+  std::vector<float> kp(2 * nqa), xyz_s(3 * nqa * k);
+  std::vector<uint32_t> counts(nqa);
+  std::vector<todhip_dmatch> m_s(nqa * k);
+  if (nqa) {
     hipStream_t st = ctx->stream;
     TOD_HIP(hipMemcpyAsync(kp.data(), d_kp_xy, kp.size() * 4, hipMemcpyDeviceToHost, st));
     TOD_HIP(hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, st));
@@ -516,18 +545,33 @@ extern "C" int todhip_verify_2d_device(todhip_ctx* ctx, const void* d_kp_xy, uin
     TOD_HIP(hipMemcpyAsync(xyz_s.data(), d_matches_xyz, xyz_s.size() * 4, hipMemcpyDeviceToHost, st));
     TOD_HIP(hipStreamSynchronize(st));
   }
-  for (uint32_t q = 0; q < nq; ++q) {
-    if (counts[q] > k) return TODHIP_EINVAL;
-    row_ptr[q + 1] = row_ptr[q] + counts[q];
-  }
-  std::vector<todhip_dmatch> m(row_ptr[nq]);
-  std::vector<float> xyz(3 * (size_t)row_ptr[nq]);
-  for (uint32_t q = 0; q < nq; ++q)
-    for (uint32_t j = 0; j < counts[q]; ++j) {
-      m[row_ptr[q] + j] = m_s[(size_t)q * k + j];
-      std::memcpy(&xyz[3 * (size_t)(row_ptr[q] + j)], &xyz_s[3 * ((size_t)q * k + j)], 12);
+  std::vector<std::vector<uint32_t>> row_ptr(n_frames, std::vector<uint32_t>(nq + 1, 0u));
+  std::vector<std::vector<todhip_dmatch>> m(n_frames);
+  std::vector<std::vector<float>> xyz(n_frames);
+  std::vector<Frame2d> fr(n_frames);
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    for (uint32_t q = 0; q < nq; ++q) {
+      const uint32_t c = counts[(size_t)f * nq + q];
+      if (c > k) return TODHIP_EINVAL;
+      row_ptr[f][q + 1] = row_ptr[f][q] + c;
     }
-  return todhip_verify_2d(ctx, kp.data(), nq, K9, row_ptr.data(), m.data(), xyz.data(), spans, n_objs, prm, rng, poses, n_poses, inlier_kp,
-                          n_inlier_kp);
+    m[f].resize(row_ptr[f][nq]); xyz[f].resize(3 * (size_t)row_ptr[f][nq]);
+    for (uint32_t q = 0; q < nq; ++q)
+      for (uint32_t j = 0; j < counts[(size_t)f * nq + q]; ++j) {
+        const size_t src = ((size_t)f * nq + q) * k + j;
+        m[f][row_ptr[f][q] + j] = m_s[src];
+        m[f][row_ptr[f][q] + j].queryIdx = (int32_t)q;                  // the matcher numbered the batch's queries through; per frame here
+        std::memcpy(&xyz[f][3 * (size_t)(row_ptr[f][q] + j)], &xyz_s[3 * src], 12);
+      }
+    fr[f] = Frame2d{kp.data() + 2 * (size_t)f * nq, row_ptr[f].data(), m[f].data(), xyz[f].data()};
+  }
+  return verify_2d_core(ctx, n_frames, fr.data(), nq, K9, spans, n_objs, prm, rng, poses, n_poses, pose_ptr, inlier_kp, n_inlier_kp);
 }
 
+extern "C" int todhip_verify_2d_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const float* K9, const void* d_counts,
+                                       const void* d_matches, const void* d_matches_xyz, uint32_t k, const float* spans, uint32_t n_objs,
+                                       const todhip_verify_params* prm, todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses,
+                                       uint32_t* inlier_kp, uint32_t* n_inlier_kp) {
+  return todhip_verify_2d_batch_device(ctx, 1, d_kp_xy, nq, K9, d_counts, d_matches, d_matches_xyz, k, spans, n_objs, prm, rng, poses, n_poses,
+                                       nullptr, inlier_kp, n_inlier_kp);
+}
