@@ -25,6 +25,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "ctx.h"
@@ -58,7 +59,11 @@ __global__ __launch_bounds__(256) void copy_words_kernel(Slots<CopyArgs> S) {
 }
 
 inline bool tod_debug() { static const bool on = getenv("TODHIP_DEBUG") != nullptr; return on; }   // read once
-#define TOD_DBG(...) do { if (tod_debug()) { fprintf(stderr, "[todhip] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+inline double dbg_us() {
+  static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+#define TOD_DBG(...) do { if (tod_debug()) { fprintf(stderr, "[todhip %.0f] ", dbg_us()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 // ------------------------------------------------------------------------------------------------ K6
 __global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs> S) {
@@ -403,7 +408,8 @@ __device__ __forceinline__ u64 rdlane64(u64 v, uint32_t lane) {
   return ((u64)rdlane((uint32_t)(v >> 32), lane) << 32) | rdlane((uint32_t)v, lane);
 }
 
-constexpr uint32_t kRegChunks = 8;                         // register paths cover lists of up to 512 vertices
+constexpr uint32_t kRegChunks = 8;                         // the column compaction's register path covers graphs of up to 512 vertices
+constexpr uint32_t kSortChunks = 16;                       // DegreeSort's register path: lists of up to 1024 vertices
 
 // DegreeSort (maximum_clique.cpp:263-284): (degree inside the list, vertex) ascending, then reversed.
 // deg[] must hold the degree of list[i] at position i. Rank by counting; keys are unique.
@@ -421,7 +427,7 @@ __device__ __forceinline__ void rank_sort_regs(uint16_t* list, const uint32_t* d
   }
 #pragma unroll
   for (uint32_t cj = 0; cj < NCH; ++cj) {
-    const uint32_t cnt = min(64u, r - cj * 64u);           // r > 64 (NCH - 1): every chunk has members
+    const uint32_t cnt = cj * 64u < r ? min(64u, r - cj * 64u) : 0u;   // (the last chunk of a merged case may be empty)
     for (uint32_t lj = 0; lj < cnt; ++lj) {
       const uint32_t kj = rdlane(kreg[cj], lj);
 #pragma unroll
@@ -435,6 +441,9 @@ __device__ __forceinline__ void rank_sort_regs(uint16_t* list, const uint32_t* d
   __syncthreads();
 }
 
+// kWide: the instantiation for objects of 513..1024 matches (eval_kernel<true>); the narrow one carries none of its code, so that
+// the registers of the common case are allocated as if the wide case did not exist (it costs 6 % otherwise)
+template <bool kWide>
 __device__ __forceinline__ void rank_sort_desc(uint16_t* list, uint16_t* tmp, const uint32_t* deg, uint32_t r, uint32_t* keys) {
   const uint32_t l = lane_id();
   if (r <= kRegChunks * 64u) {
@@ -449,6 +458,19 @@ __device__ __forceinline__ void rank_sort_desc(uint16_t* list, uint16_t* tmp, co
       default: rank_sort_regs<8>(list, deg, r); break;
     }
     return;
+  }
+  if constexpr (kWide) {
+    if (r <= kSortChunks * 64u) {
+      switch ((r + 63u) / 64u) {                           // wave-uniform
+        case 9: rank_sort_regs<9>(list, deg, r); break;
+        case 10: rank_sort_regs<10>(list, deg, r); break;
+        case 11: rank_sort_regs<11>(list, deg, r); break;
+        case 12: rank_sort_regs<12>(list, deg, r); break;
+        case 13: case 14: rank_sort_regs<14>(list, deg, r); break;
+        default: rank_sort_regs<16>(list, deg, r); break;
+      }
+      return;
+    }
   }
   for (uint32_t i = l; i < r; i += 64u) keys[i] = (deg[i] << 16) | list[i];
   __syncthreads();
@@ -490,12 +512,12 @@ __device__ __forceinline__ void degrees_in_list(const GateLds& L, const uint16_t
 // two-set form below.
 template <uint32_t MWT>
 __device__ __forceinline__ bool colour_first_fit64(const GateLds& L, uint16_t* list, uint32_t r) {
-  typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+  typedef uint32_t u32x16 __attribute__((ext_vector_type(MWT <= 8u ? 16 : 32)));   // (2 MWT halves; the tuple sizes the hardware indexes)
   const uint32_t l = lane_id();
   // class l's members as a bitset over graph vertices, 32-bit halves in ONE register tuple: the half that receives a vertex is
   // picked with the hardware's register indexing (s_set_gpr_idx, the index v >> 5 is wave-uniform) -- three instructions to read,
   // three to write, no branch tree and no per-word selects
-  u32x16 cls = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  u32x16 cls = {};
   uint32_t rec = l << 16;                                  // (class l, members of class l so far): what a joining vertex records
   uint32_t* const my_trash = L.trash + l;
   for (uint32_t c0 = 0; c0 < r; c0 += 64u) {
@@ -683,6 +705,7 @@ __device__ __forceinline__ bool colour_first_fit(const GateLds& L, uint16_t* lis
   return true;
 }
 
+template <bool kWide>
 __device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, uint32_t r, uint32_t MW, uint32_t qmax, uint32_t qsz) {
   const uint32_t l = lane_id();
   const int min_k = max(1, (int)qmax - (int)qsz + 1);
@@ -718,7 +741,23 @@ __device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, ui
     }
     if (done) return;                                      // else: more than 128 classes -> the generic loop below
   }
-  // generic class-by-class colouring (graphs beyond 512 vertices, or more than 128 classes)
+  if constexpr (kWide) {
+    if (MW > 8u && MW <= 16u) {                            // up to 1024 vertices: the same, with a 32-register class tuple
+      bool done = false;
+      switch (MW) {                                        // wave-uniform
+        case 9: done = colour_first_fit64<9>(L, list, r) || colour_first_fit<9, true>(L, list, r); break;
+        case 10: done = colour_first_fit64<10>(L, list, r) || colour_first_fit<10, true>(L, list, r); break;
+        case 11: done = colour_first_fit64<11>(L, list, r) || colour_first_fit<11, true>(L, list, r); break;
+        case 12: done = colour_first_fit64<12>(L, list, r) || colour_first_fit<12, true>(L, list, r); break;
+        case 13: done = colour_first_fit64<13>(L, list, r) || colour_first_fit<13, true>(L, list, r); break;
+        case 14: done = colour_first_fit64<14>(L, list, r) || colour_first_fit<14, true>(L, list, r); break;
+        case 15: done = colour_first_fit64<15>(L, list, r) || colour_first_fit<15, true>(L, list, r); break;
+        default: done = colour_first_fit64<16>(L, list, r) || colour_first_fit<16, true>(L, list, r); break;
+      }
+      if (done) return;
+    }
+  }
+  // generic class-by-class colouring (graphs beyond 1024 vertices, or more than 128 classes)
   const uint32_t nchunks = (r + 63u) / 64u;
   u64 uncol = 0ull;                                        // lane c holds positions [64c, 64c + 64)
   if (l < nchunks) uncol = (l * 64u + 64u <= r) ? ~0ull : ((1ull << (r - l * 64u)) - 1ull);
@@ -757,6 +796,16 @@ __device__ __forceinline__ void colour_sort(const GateLds& L, uint16_t* list, ui
 // vertices: the graph's vertex numbers in ascending order (nullptr: 0 .. m - 1). The search only ever compares vertex numbers and
 // uses them as row / bit indices, so a graph whose m vertices keep larger, ascending numbers (all below 64 MW) behaves exactly
 // like its renumbered copy. L.deg[i] = degree of the i-th vertex on entry.
+// kGate: the caller only asks whether the clique FindClique(minimal_size) returns is LARGER than minimal_size
+// (sac_model_registration_graph.h:260-262). FindClique stops at the first leaf with |Q| >= minimal_size, and that leaf's size is
+// decided long before it is reached: once Q holds minimal_size vertices and their common neighbourhood Rp is not empty, the
+// recursion can only go down -- the child's first candidate always passes |Q| + c > |QMax| (|QMax| < minimal_size <= |Q|, or the
+// search had returned), so an (minimal_size + 1)-th vertex is pushed, and from there every path ends in a leaf of at least that
+// size before anything is popped. (While |QMax| < minimal_size, that is: after the first such leaf the reference unwinds through
+// the ancestors' remaining candidates, which can no longer change QMax -- the gate stops there too.) The only other exit is the step cap (:318), at most |Rp| + 1 steps away: if the cap cannot be
+// reached within them the answer is known and the rest of the descent (typically 20-45 more levels, each colouring a list of
+// several hundred vertices) is not walked; the returned size is then a lower bound, |Q| + 1. Otherwise: the search as it is.
+template <bool kWide, bool kGate>
 __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_t minimal_size, uint16_t* gstack, uint32_t stack_cap,
                                   int* err, uint32_t* steps_out, uint32_t* prof = nullptr, const uint16_t* vertices = nullptr) {
   const uint32_t l = lane_id();
@@ -770,7 +819,7 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
   for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, o));
   const uint32_t max_degree = uni(dmax);                 // = the degree of the sorted list's head (:352-355)
   __syncthreads();
-  rank_sort_desc(L.cur, L.tmp, L.deg, m, L.keys);
+  rank_sort_desc<kWide>(L.cur, L.tmp, L.deg, m, L.keys);
   __syncthreads();
   for (uint32_t i = l; i < m; i += 64u) L.C[i] = i < max_degree ? i + 1u : max_degree + 1u;     // :356-361
   for (uint32_t i = l; i < m + 2u; i += 64u) { L.S[i] = 0u; L.SOld[i] = 0u; }
@@ -825,16 +874,19 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
         __syncthreads();
         const long long pt1 = prof ? clock64() : 0;
         pf_isect += (uint32_t)(pt1 - pt0);
+        if constexpr (kGate) {
+          if (rp > 0u && qmax < minimal_size && qsz >= minimal_size && (uint32_t)all_steps + rp + 1u <= (uint32_t)kStepCap) { qmax = qsz + 1u; break; }
+        }
         if (rp > 0u) {
           // :313 is (double)S[level] / all_steps_ < 0.025. With all_steps <= 100001 a quotient other than 1/40
           // differs from 1/40 by more than 1e-7, and 1/40 itself rounds to the literal: the test is 40 S < all_steps
           if ((uint64_t)S_cur * 40ull < (uint64_t)all_steps) {
             degrees_in_list(L, nxt, rp, MW);
-            rank_sort_desc(nxt, L.tmp, L.deg, rp, L.keys);
+            rank_sort_desc<kWide>(nxt, L.tmp, L.deg, rp, L.keys);
           }
           const long long pt2 = prof ? clock64() : 0;
           pf_sort += (uint32_t)(pt2 - pt1);
-          colour_sort(L, nxt, rp, MW, qmax, qsz);
+          colour_sort<kWide>(L, nxt, rp, MW, qmax, qsz);
           if (prof) {
             const uint32_t dt = (uint32_t)(clock64() - pt2);
             pf_col += dt;
@@ -870,7 +922,12 @@ __device__ __forceinline__ uint32_t clique_search(GateLds L, uint32_t m, uint32_
         } else {
           if (qsz > qmax) {                                // :322-326
             qmax = qsz;
-            if (qmax >= minimal_size) ret = true;
+            if (qmax >= minimal_size) {
+              // (what follows in the reference is the unwinding: every ancestor still expands its remaining candidates, whose
+              // children return at once (:290); a leaf there has |Q| < |QMax|, so QMax is final -- the gate needs no more)
+              if constexpr (kGate) break;
+              ret = true;
+            }
           }
           if (!ret) --qsz;                                 // Q.pop_back(), :329
         }
@@ -929,7 +986,7 @@ struct EvalArgs {
 
 // The gate of one hypothesis (sac_model_registration_graph.h:219-265): induced sample sub-graph of F, degree test,
 // maximum clique. Returns the consensus count to report (cnt, 0 = rejected, INT_MIN = error).
-template <bool kExt>
+template <bool kExt, bool kWide>
 __device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& F, uint32_t m, uint32_t it, uint32_t cnt,
                                              unsigned char* lds_raw, uint16_t* stack) {
   const uint32_t l = lane_id();
@@ -937,11 +994,11 @@ __device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& 
   const uint32_t W = job.W;
   int32_t result = (int32_t)cnt;
   const uint32_t MW = (m + 63u) / 64u;
-  // An object of up to 512 matches whose consensus list needs as many 64-bit words as the object itself (MW == W: the usual
+  // An object of up to 1024 matches whose consensus list needs as many 64-bit words as the object itself (MW == W: the usual
   // case when the object is really there) keeps the object's vertex numbers: the induced graph is then the object's sample rows
   // masked with F, a copy, instead of a column compaction that costs ~200 k cycles for 264 vertices; vertex numbers only ever
   // serve as row / bit indices and in comparisons, and F is ascending, so the search cannot tell the difference.
-  const bool ident = !kExt && W <= 8u && MW == W && gate_lds_bytes(m) + 8u * (job.n - m) * MW <= A.lds_bytes;
+  const bool ident = !kExt && W <= (kWide ? 16u : 8u) && MW == W && gate_lds_bytes(m) + 8u * (job.n - m) * MW <= A.lds_bytes;
   GateLds L = gate_carve<kExt>(lds_raw, m, A.lds_bytes, kExt ? A.adjc_scratch + (size_t)blockIdx.x * kAdjcScratchWords : nullptr,
                                ident ? job.n : m);
   const long long t_start = A.dbg ? clock64() : 0;   // phase stamps (diagnostics builds of the call only)
@@ -969,7 +1026,7 @@ __device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& 
   if (bad_index && l == 0) { atomicExch(&A.status[0], 4u); A.status[6] = m; A.status[7] = it; }
   if (!bad_index && A.stop_level != 3u) {
     if (ident) {
-      if (l < W) L.mask[l] = F.w[0];                       // lane l holds word l of F (W <= 8 < 64)
+      if (l < W) L.mask[l] = F.w[0];                       // lane l holds word l of F (W <= 16 < 64)
       __syncthreads();
       for (uint32_t i = l; i < job.n * W; i += 64u) {
         const uint32_t v = i / W, w = i - v * W;
@@ -1095,7 +1152,7 @@ __device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& 
     int err = 0;
     uint32_t steps = 0;
     uint32_t* prof = (A.dbg && A.dbg_stride >= 16u) ? A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 12u) : nullptr;
-    const uint32_t q = clique_search(L, m, kGateMinimal, stack, A.stack_cap, &err, &steps, prof, ident ? L.flist : nullptr);
+    const uint32_t q = clique_search<kWide, true>(L, m, kGateMinimal, stack, A.stack_cap, &err, &steps, prof, ident ? L.flist : nullptr);
     if (A.dbg && l == 0 && A.dbg_stride >= 8u) {
       uint32_t* d = A.dbg + (size_t)it * A.dbg_stride + (A.dbg_stride - 6u);
       d[0] = (uint32_t)(t_flist - t_start); d[1] = (uint32_t)(t_adjc - t_flist);
@@ -1115,6 +1172,8 @@ __device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& 
 
 // launched with 64 threads; the bound is deliberately larger so that hipcc keeps __syncthreads() as a real,
 // convergent s_barrier (with a 64-thread bound it drops the barrier and may split the lanes of the wave)
+// kWide = false: objects of up to 512 matches (job.W <= 8), the launch's every slot; true: any size
+template <bool kWide>
 __global__ __launch_bounds__(128) void eval_kernel(Slots<EvalArgs> SL) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const EvalArgs& A = SL.a[blockIdx.y];
@@ -1165,8 +1224,8 @@ __global__ __launch_bounds__(128) void eval_kernel(Slots<EvalArgs> SL) {
         }
       } else {
         // third tier: adjacency matrix in global scratch
-        result = gate_lds_bytes(m) > A.lds_bytes ? gate_eval<true>(A, F, m, it, cnt, lds_raw, stack)
-                                                 : gate_eval<false>(A, F, m, it, cnt, lds_raw, stack);
+        result = gate_lds_bytes(m) > A.lds_bytes ? gate_eval<true, kWide>(A, F, m, it, cnt, lds_raw, stack)
+                                                 : gate_eval<false, kWide>(A, F, m, it, cnt, lds_raw, stack);
       }
     }
     if (l == 0) {
@@ -1195,7 +1254,7 @@ __global__ __launch_bounds__(128) void clique_test_kernel(const u64* adj, uint32
   __syncthreads();
   int err = 0;
   uint32_t steps = 0;
-  const uint32_t q = clique_search(L, m, minimal_size, stack, stack_cap, &err, &steps);
+  const uint32_t q = clique_search<true, false>(L, m, minimal_size, stack, stack_cap, &err, &steps);
   if (l == 0) { out[0] = q; out[1] = (uint32_t)err; out[2] = steps; }
 }
 
@@ -1697,7 +1756,11 @@ struct VerifyWs {
 
 // one workspace per frame slot of a batch; slot 0 also serves the single-frame entry points and the test hooks
 struct StreamCache;
-struct VerifyPool { std::vector<VerifyWs*> slots; std::vector<StreamCache*> streams; };
+struct VerifyPool {
+  std::vector<VerifyWs*> slots; std::vector<StreamCache*> streams;
+  std::vector<hipStream_t> side;                            // flights of a batch (Engine::run_ticks), created on first use
+  std::vector<hipEvent_t> side_ev;
+};
 
 constexpr uint32_t kEvalLdsSmall = 48u * 1024u;
 constexpr uint32_t kEvalLdsBig = 160u * 1024u - 512u;
@@ -1751,7 +1814,7 @@ struct StreamCache {
     const uint64_t want = std::max<uint64_t>(n, 2 * dev_valid);
     extend_to(want);
     if (dev.cap < want * sizeof(uint32_t)) {                // grow: DevBuf::reserve drops the old contents, upload all again
-      hipError_t e = hipStreamSynchronize(st);              // kernels of earlier ticks may still read the old buffer
+      hipError_t e = hipDeviceSynchronize();                // kernels of earlier ticks and of flights on other streams may still read it
       if (e != hipSuccess) return e;
       e = dev.reserve((size_t)want * 2 * sizeof(uint32_t));
       if (e != hipSuccess) return e;
@@ -1759,6 +1822,9 @@ struct StreamCache {
     }
     hipError_t e = hipMemcpyAsync(dev.as<uint32_t>() + dev_valid, vals.data() + dev_valid, (size_t)(want - dev_valid) * sizeof(uint32_t),
                                   hipMemcpyHostToDevice, st);
+    // complete before anyone is told the stream reaches this far: slots that share the cache may read it from another stream
+    // (the copy doubles the valid length, so a context in steady state never gets here)
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) dev_valid = want;
     return e;
   }
@@ -1773,7 +1839,9 @@ struct StreamCache {
 int set_big_lds_once(todhip_ctx* ctx) {
   static std::atomic<bool> done{false};                   // contexts may be driven from several host threads
   if (!done.load(std::memory_order_acquire)) {
-    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kEvalLdsBig));
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kEvalLdsBig));
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clique_test_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
@@ -1838,6 +1906,7 @@ struct Slot {
   ObjJob job = {};
   uint32_t n_all = 0;
   bool pending_invalidate = false;
+  bool in_flight = false;                                 // its current tick runs on a side stream (run_ticks)
   // window-size hint for the next object's first draw window: what the previous objects of this frame consumed when their
   // getSamples gave up (1000 failing attempts, ~4-9k draws). Frames with many stray matches hold runs of such objects; a
   // first window sized for a healthy object (576) made each of them crawl through three windows = three ticks
@@ -1853,7 +1922,7 @@ struct Launches {
   std::vector<DrawArgs> draw, draw_small; std::vector<ChainArgs> chain;
   // the rnd pointers of the draw lists are resolved at launch time: a later slot of the same tick may grow (move)
   // the shared stream buffer
-  std::vector<std::pair<StreamCache*, uint64_t>> draw_src, draw_small_src; std::vector<EvalArgs> eval_small, eval_big;
+  std::vector<std::pair<StreamCache*, uint64_t>> draw_src, draw_small_src; std::vector<EvalArgs> eval_small, eval_big, eval_direct;
   std::vector<GrowthArgs> growth;
 };
 
@@ -2049,7 +2118,14 @@ struct Engine {
         L.eval_big.push_back(A);
       } else {
         L.zero.push_back({nullptr, d_small + 8, 12u});
-        L.eval_small.push_back(A);
+        // A few hypotheses of an object whose consensus lists (about all of its valid matches when the object is really there)
+        // will not fit the 48 KB carve: straight to a whole CU's LDS instead of a first pass that only finds that out
+        if (r.it_drawn - r.it_begin <= 16u && gate_lds_bytes(r.nvalid) + 4096u > kEvalLdsSmall) {
+          A.lds_bytes = kEvalLdsBig;
+          L.eval_direct.push_back(A);
+        } else {
+          L.eval_small.push_back(A);
+        }
       }
       export_small(s);
       s.ph = second ? PH_EVAL2_WAIT : PH_EVAL_WAIT;
@@ -2280,7 +2356,7 @@ struct Engine {
     return std::min(kEvalLdsSmall, std::max(8192u, (want + 1023u) & ~1023u));
   }
 
-  void launch_all() {
+  void launch_all(hipStream_t st) {
     auto words = [](const CopyArgs& a) { return dim3(std::max(1u, std::min(64u, (a.n + 255u) / 256u))); };
     L.copy_in.insert(L.copy_in.end(), L.zero.begin(), L.zero.end());   // both precede every other kernel of the tick: one launch
     launch_list(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
@@ -2309,9 +2385,24 @@ struct Engine {
       uint32_t lds = 8192u;
       for (const EvalArgs& a : L.eval_small) lds = std::max(lds, a.lds_bytes);
       for (EvalArgs& a : L.eval_small) a.lds_bytes = lds;
-      launch_list(st, eval_kernel, L.eval_small, 64, lds, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+      // objects of more than 512 matches go to the kernel's wide instantiation (their own launch)
+      std::vector<EvalArgs> narrow, wide;
+      for (const EvalArgs& a : L.eval_small) (a.job.W <= 8u ? narrow : wide).push_back(a);
+      launch_list(st, eval_kernel<false>, narrow, 64, lds, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+      launch_list(st, eval_kernel<true>, wide, 64, lds, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
     }
-    launch_list(st, eval_kernel, L.eval_big, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
+    {
+      std::vector<EvalArgs> narrow, wide;
+      for (const EvalArgs& a : L.eval_direct) (a.job.W <= 8u ? narrow : wide).push_back(a);
+      launch_list(st, eval_kernel<false>, narrow, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+      launch_list(st, eval_kernel<true>, wide, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+    }
+    {
+      std::vector<EvalArgs> narrow, wide;
+      for (const EvalArgs& a : L.eval_big) (a.job.W <= 8u ? narrow : wide).push_back(a);
+      launch_list(st, eval_kernel<false>, narrow, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
+      launch_list(st, eval_kernel<true>, wide, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
+    }
     launch_list(st, growth_kernel, L.growth, 256, 0, 0, [](const GrowthArgs&) { return dim3(1); });
     launch_list(st, copy_words_kernel, L.copy_out, 256, 0, 1, words);
     L = Launches();
@@ -2342,28 +2433,125 @@ struct Engine {
     }
     return rc_run;
   }
+  // A tick = every ready slot issues the kernels of its next phase; the lists are launched once for all of them, the host
+  // waits and every slot consumes its results. Lock-step is cheap while the phases are short, but one slot's clique gate
+  // over a few hundred vertices (a single wave for ~1 ms) would hold up the 15 others whose next step takes 30 us, and the
+  // frames of a batch reach their big object at different ticks. Heavy phases therefore leave the lock-step: they are launched
+  // on one of a few side streams ("flights") and their slots rejoin when the flight's event has fired; the other slots keep
+  // ticking on the context's stream meanwhile. Nothing here changes what a slot computes or in which order it consumes it.
+  static constexpr uint32_t kHeavyN = 96;                  // matches of an object from which its evaluation / growth is a flight
+  struct Flight { hipStream_t st; hipEvent_t ev; std::vector<Slot*> slots; bool busy = false; };
+  static bool heavy(const Slot& s) { return (s.ph == PH_EVAL || s.ph == PH_EVAL2 || s.ph == PH_GROWTH) && s.job.n >= kHeavyN; }
+  static uint32_t n_side_streams() {
+    static const uint32_t n = [] {
+      const char* e = getenv("TODHIP_VERIFY_FLIGHTS");
+      const long v = e ? strtol(e, nullptr, 10) : 8;
+      return (uint32_t)std::min<long>(std::max<long>(v, 0), 16);
+    }();
+    return n;
+  }
+  void describe(char* what, size_t cap) const {
+    snprintf(what, cap, "lookup %zu adj %zu prep %zu draw %zu+%zu chain %zu eval %zu+%zu growth %zu inval %zu", L.lookup.size(),
+             L.adj.size(), L.prep.size(), L.draw.size(), L.draw_small.size(), L.chain.size(), L.eval_small.size() + L.eval_direct.size(),
+             L.eval_big.size(), L.growth.size(), L.inval.size());
+  }
   int run_ticks(std::vector<Slot*>& slots) {
+    std::vector<Flight> flights;
+    if (slots.size() > 1) {
+      VerifyPool* pool = pool_of(ctx);
+      while (pool->side.size() < n_side_streams()) {
+        hipStream_t s2; hipEvent_t e2;
+        int prio = 0;                                       // as the context's stream: the caller chose it against its other work
+        if (hipStreamGetPriority(st, &prio) != hipSuccess) prio = 0;
+        TOD_HIP(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio));
+        if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(s2); return TODHIP_EHIP; }
+        pool->side.push_back(s2); pool->side_ev.push_back(e2);
+      }
+      for (size_t i = 0; i < std::min<size_t>(pool->side.size(), n_side_streams()); ++i) flights.push_back({pool->side[i], pool->side_ev[i], {}, false});
+    }
+    auto drain = [&]() { for (Flight& f : flights) if (f.busy) { (void)hipEventSynchronize(f.ev); f.busy = false; } };
+#define LOOP_HIP(expr) do { if ((expr) != hipSuccess) { drain(); return TODHIP_EHIP; } } while (0)
+    std::vector<Slot*> main_slots, heavy_now;
     while (true) {
-      bool any = false;
-      for (Slot* s : slots)
-        if (s->ph != PH_DONE) { issue(*s); any = any || s->ph != PH_DONE; }
-      if (!any) break;
+      // flights that have landed: their slots consume and are ready again
+      for (Flight& f : flights) {
+        if (!f.busy) continue;
+        const hipError_t q = hipEventQuery(f.ev);
+        if (q == hipErrorNotReady) continue;
+        LOOP_HIP(q);
+        f.busy = false;
+        TOD_DBG("flight of %zu slot(s) landed", f.slots.size());
+        for (Slot* s : f.slots) { s->in_flight = false; if (s->ph != PH_DONE) consume(*s); }
+        f.slots.clear();
+      }
+      size_t n_free = 0;
+      bool any_busy = false;
+      for (const Flight& f : flights) { n_free += !f.busy; any_busy = any_busy || f.busy; }
+      main_slots.clear(); heavy_now.clear();
+      bool any_live = false;
+      // Heavy phases fly only when that lets something else go on meanwhile: other slots with light phases to tick through, or
+      // flights already in the air. When all the ready slots arrive at a heavy phase together (frames with one object each, all of
+      // a size), one launch for all of them on the context's stream is the cheapest form there is.
+      bool mixed = any_busy;
+      if (!flights.empty() && !mixed) {
+        bool some_heavy = false, some_light = false;
+        for (Slot* s : slots) {
+          if (s->ph == PH_DONE || s->in_flight) continue;
+          if (heavy(*s)) some_heavy = true; else some_light = true;
+        }
+        mixed = some_heavy && some_light;
+      }
+      for (Slot* s : slots) {
+        if (s->ph == PH_DONE || s->in_flight) continue;
+        any_live = true;
+        if (mixed && heavy(*s)) { if (n_free) heavy_now.push_back(s); continue; }   // no flight free: it waits for one
+        issue(*s);
+        if (s->ph != PH_DONE) main_slots.push_back(s);
+      }
+      if (!any_live && !any_busy) break;
       char what[128] = "";
       std::chrono::steady_clock::time_point t0;
-      if (tod_debug()) {                                    // TODHIP_DEBUG=1: what a tick launches and how long it takes
-        snprintf(what, sizeof(what), "lookup %zu adj %zu prep %zu draw %zu+%zu chain %zu eval %zu+%zu growth %zu inval %zu", L.lookup.size(),
-                 L.adj.size(), L.prep.size(), L.draw.size(), L.draw_small.size(), L.chain.size(), L.eval_small.size(),
-                 L.eval_big.size(), L.growth.size(), L.inval.size());
-        t0 = std::chrono::steady_clock::now();
+      if (tod_debug()) { describe(what, sizeof(what)); t0 = std::chrono::steady_clock::now(); }
+      if (!main_slots.empty()) { launch_all(st); LOOP_HIP(hipGetLastError()); }
+      else L = Launches();
+      if (!heavy_now.empty()) {
+        const size_t per = (heavy_now.size() + n_free - 1) / n_free;
+        size_t next = 0;
+        for (Flight& f : flights) {
+          if (f.busy || next >= heavy_now.size()) continue;
+          for (size_t i = 0; i < per && next < heavy_now.size(); ++i, ++next) {
+            Slot* s = heavy_now[next];
+            issue(*s);
+            if (s->ph != PH_DONE) { s->in_flight = true; f.slots.push_back(s); }
+          }
+          if (f.slots.empty()) { L = Launches(); continue; }
+          if (tod_debug()) { char w2[128]; describe(w2, sizeof(w2)); TOD_DBG("flight of %zu slot(s): %s", f.slots.size(), w2); }
+          launch_all(f.st);
+          LOOP_HIP(hipGetLastError());
+          LOOP_HIP(hipEventRecord(f.ev, f.st));
+          f.busy = true; any_busy = true;
+        }
       }
-      launch_all();
-      TOD_HIP(hipGetLastError());
-      TOD_HIP(hipStreamSynchronize(st));
-      if (tod_debug())
-        TOD_DBG("tick %.1f us: %s", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
-      for (Slot* s : slots)
-        if (s->ph != PH_DONE) consume(*s);
+      if (!main_slots.empty()) {
+        LOOP_HIP(hipStreamSynchronize(st));
+        if (tod_debug())
+          TOD_DBG("tick %.1f us: %s", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+        for (Slot* s : main_slots)
+          if (s->ph != PH_DONE) consume(*s);
+      } else if (any_busy) {                                 // nothing but flights: wait for the first one to land
+        bool landed = false;
+        while (!landed) {
+          for (Flight& f : flights) {
+            if (!f.busy) continue;
+            const hipError_t q = hipEventQuery(f.ev);
+            if (q == hipSuccess) { landed = true; break; }
+            if (q != hipErrorNotReady) LOOP_HIP(q);
+          }
+          if (!landed) std::this_thread::yield();
+        }
+      }
     }
+#undef LOOP_HIP
     for (Slot* s : slots)
       if (s->rc != TODHIP_OK) return s->rc;
     return TODHIP_OK;
@@ -2378,6 +2566,8 @@ void tod_verify_ws_free(todhip_ctx* ctx) {
   VerifyPool* p = reinterpret_cast<VerifyPool*>(ctx->verify_ws);
   for (VerifyWs* ws : p->slots) { ws->release(); delete ws; }
   for (StreamCache* c : p->streams) { c->dev.release(); delete c; }
+  for (hipEvent_t e : p->side_ev) (void)hipEventDestroy(e);
+  for (hipStream_t s2 : p->side) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
   delete p;
   ctx->verify_ws = nullptr;
 }
@@ -2674,7 +2864,8 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   A.adjc_scratch = nullptr;
   A.dbg = dbg ? ws->table.as<uint32_t>() : nullptr; A.dbg_stride = dbg_stride; A.stop_level = stop_level;
   if (n_triples > kMaxEvalWaves) return TODHIP_EINVAL;
-  launch_list(st, eval_kernel, std::vector<EvalArgs>{A}, 64, kEvalLdsSmall, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+  if (W <= 8u) launch_list(st, eval_kernel<false>, std::vector<EvalArgs>{A}, 64, kEvalLdsSmall, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+  else launch_list(st, eval_kernel<true>, std::vector<EvalArgs>{A}, 64, kEvalLdsSmall, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
   TOD_HIP(hipGetLastError());
   TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   TOD_HIP(hipStreamSynchronize(st));
@@ -2684,7 +2875,8 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
     TOD_HIP(ws->adjc_scratch.reserve((size_t)n_def * kAdjcScratchWords * sizeof(u64)));
     A.adjc_scratch = ws->adjc_scratch.as<u64>();
     TOD_HIP(hipMemsetAsync(d_small + 8, 0, sizeof(uint32_t), st));
-    launch_list(st, eval_kernel, std::vector<EvalArgs>{A}, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
+    if (W <= 8u) launch_list(st, eval_kernel<false>, std::vector<EvalArgs>{A}, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
+    else launch_list(st, eval_kernel<true>, std::vector<EvalArgs>{A}, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
     TOD_HIP(hipGetLastError());
     TOD_HIP(hipMemcpyAsync(h_small + 12, d_small + 12, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     TOD_HIP(hipStreamSynchronize(st));

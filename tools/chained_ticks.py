@@ -25,6 +25,8 @@ for B in (1, 16):
     env = dict(os.environ, TODHIP_DEBUG="1")
     p = subprocess.run([sys.executable, __file__, "child", str(B)], env=env, capture_output=True, text=True)
     log = p.stderr.split("=== REP 1")[-1]
+    if os.environ.get("CHAINED_TICKS_RAW"):
+        open(os.environ["CHAINED_TICKS_RAW"] + ".B%d" % B, "w").write(log)
     ticks = re.findall(r"tick ([0-9.]+) us: (.*)", log)
     total = re.findall(r"=== TOTAL ([0-9.]+) ms", log)
     by = collections.defaultdict(lambda: [0, 0.0])
