@@ -39,7 +39,8 @@ namespace {
 // batch (each at its own point of its own RANSAC state machine) share launches, so a batch costs the launches and
 // host round trips of one frame.
 constexpr uint32_t kMaxSlots = 16;                         // 16 x 200 B of EvalArgs stays under the 4 KB kernarg limit
-template <class A> struct Slots { A a[kMaxSlots]; };
+constexpr uint32_t kManySlots = 40;                        // kernels with ~100 B of arguments per slot (4 KB of kernarg in all)
+template <class A, uint32_t N = kMaxSlots> struct Slots { A a[N]; };
 
 struct AdjArgs { ObjJob job; float span, err; };
 struct JobArgs { ObjJob job; };
@@ -66,7 +67,7 @@ inline double dbg_us() {
 #define TOD_DBG(...) do { if (tod_debug()) { fprintf(stderr, "[todhip %.0f] ", dbg_us()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 // ------------------------------------------------------------------------------------------------ K6
-__global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs> S) {
+__global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs, kManySlots> S) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.z].job;
   const float span = S.a[blockIdx.z].span, err = S.a[blockIdx.z].err;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs> S) {
   }
 }
 
-__global__ __launch_bounds__(256) void finite_kernel(Slots<JobArgs> S) {
+__global__ __launch_bounds__(256) void finite_kernel(Slots<JobArgs, kManySlots> S) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.y].job;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void finite_kernel(Slots<JobArgs> S) {
 // its own third level is empty, so it returns before drawing), i.e. every edge is paid for exactly once, at whichever
 // endpoint is picked first. A triangle-free object therefore advances the stream by exactly 1000 (|valid| + |E|) draws
 // (getSamples' 1000 attempts, :141-168) and yields nothing: the host skips its draw table and chain walk altogether.
-__global__ __launch_bounds__(256) void round_prep_kernel(Slots<PrepArgs> S) {
+__global__ __launch_bounds__(256) void round_prep_kernel(Slots<PrepArgs, kManySlots> S) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.y].job;
   uint32_t* const stats = S.a[blockIdx.y].stats;
@@ -1927,11 +1928,12 @@ struct Launches {
 };
 
 // launch `kern` over the argument sets of v, kMaxSlots at a time; extent(a) = blocks one set needs in x (and y)
-template <class A, class Kern, class Extent>
+template <uint32_t N = kMaxSlots, class A, class Kern, class Extent>
 void launch_list(hipStream_t st, Kern kern, const std::vector<A>& v, uint32_t block, uint32_t lds, int slot_dim, Extent extent) {
-  for (size_t i0 = 0; i0 < v.size(); i0 += kMaxSlots) {
-    const uint32_t n = (uint32_t)std::min<size_t>(kMaxSlots, v.size() - i0);
-    Slots<A> S;
+  static_assert(sizeof(Slots<A, N>) <= 4096, "kernel arguments are limited to 4 KB");
+  for (size_t i0 = 0; i0 < v.size(); i0 += N) {
+    const uint32_t n = (uint32_t)std::min<size_t>(N, v.size() - i0);
+    Slots<A, N> S;
     std::memset(&S, 0, sizeof(S));
     uint32_t gx = 1, gy = 1;
     for (uint32_t i = 0; i < n; ++i) {
@@ -2366,9 +2368,9 @@ struct Engine {
                 [](const ScatterArgs& a) { return dim3((uint32_t)(((size_t)a.nq * a.k + 255u) / 256u)); });
     launch_list(st, cluster_group_kernel, L.group, 256, 0, 1, [](const GroupArgs& a) { return dim3((a.n_all + 255u) / 256u); });
     launch_list(st, invalidate_kernel, L.inval, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
-    launch_list(st, finite_kernel, L.finite, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
-    launch_list(st, adjacency_kernel, L.adj, 256, 0, 2, [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
-    launch_list(st, round_prep_kernel, L.prep, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+    launch_list<kManySlots>(st, finite_kernel, L.finite, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+    launch_list<kManySlots>(st, adjacency_kernel, L.adj, 256, 0, 2, [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
+    launch_list<kManySlots>(st, round_prep_kernel, L.prep, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
     for (size_t i = 0; i < L.draw.size(); ++i) L.draw[i].rnd = L.draw_src[i].first->dev.as<uint32_t>() + L.draw_src[i].second;
     for (size_t i = 0; i < L.draw_small.size(); ++i)
       L.draw_small[i].rnd = L.draw_small_src[i].first->dev.as<uint32_t>() + L.draw_small_src[i].second;
@@ -2445,7 +2447,7 @@ struct Engine {
   static uint32_t n_side_streams() {
     static const uint32_t n = [] {
       const char* e = getenv("TODHIP_VERIFY_FLIGHTS");
-      const long v = e ? strtol(e, nullptr, 10) : 8;
+      const long v = e ? strtol(e, nullptr, 10) : 2;
       return (uint32_t)std::min<long>(std::max<long>(v, 0), 16);
     }();
     return n;
@@ -2804,7 +2806,7 @@ int todhip_test_adjacency(todhip_ctx* ctx, const float* train, const float* quer
   job.n = n; job.W = W;
   job.train = ws->train.as<float>(); job.query = ws->query.as<float>(); job.kpxy = ws->kpxy.as<float>();
   job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
-  launch_list(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
+  launch_list<kManySlots>(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
               [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
   TOD_HIP(hipGetLastError());
   TOD_HIP(hipMemcpyAsync(phys, ws->phys.p, (size_t)n * W * 8, hipMemcpyDeviceToHost, st));
@@ -2851,10 +2853,10 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   uint32_t* d_small = ws->small.as<uint32_t>();
   uint32_t* h_small = ws->h_small.as<uint32_t>();
   TOD_HIP(hipMemsetAsync(d_small, 0, 64 * sizeof(uint32_t), st));
-  launch_list(st, finite_kernel, std::vector<JobArgs>{{job}}, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
-  launch_list(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
+  launch_list<kManySlots>(st, finite_kernel, std::vector<JobArgs>{{job}}, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+  launch_list<kManySlots>(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
               [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
-  launch_list(st, round_prep_kernel, std::vector<PrepArgs>{{job, d_small + 5}}, 256, 0, 1,
+  launch_list<kManySlots>(st, round_prep_kernel, std::vector<PrepArgs>{{job, d_small + 5}}, 256, 0, 1,
               [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
   EvalArgs A;
   A.job = job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = 0; A.it_end = n_triples;
