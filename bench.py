@@ -75,9 +75,9 @@ def parse():
     ap.add_argument("--stages", default="orb,match,verify", help="comma list of: orb,match,verify")
     ap.add_argument("--batch", type=int, default=16, help="frames per rank per step")
     ap.add_argument("--verify-workers", type=int, default=0,
-                    help="verifier batches in flight in the chained pipeline (one context, stream and host thread each); 0 = 6: the verifier's "
-                         "ticks are lock-step over a batch and mostly wait for single-wave kernels, so batches overlap almost freely until the "
-                         "host threads run out (tools/chained_workers.sh: 2 -> 800, 4 -> 1440, 6 -> 1740, 8 -> 1450 frames/s)")
+                    help="verifier batches in flight in the chained and C5 pipelines (one context, stream and host thread each); 0 = 4: the "
+                         "verifier mostly waits for single-wave kernels, so batches overlap almost freely -- until the process has more busy "
+                         "streams than the eight hardware queues (tools/chained_flights.sh: 1 -> 2250, 3 -> 3550, 4 -> 4200, 5 -> 2500 frames/s)")
     ap.add_argument("--engine", choices=("auto", "valu", "mfma"), default="auto",
                     help="the exact Hamming search's engine: vector ALU (K4) or matrix cores (K4x); identical results")
     ap.add_argument("--exchange", choices=("all_to_all", "all_gather"), default="all_to_all",
@@ -281,7 +281,7 @@ def run_chained(torch, capi, device, args):
     batches = scenes.make_detection_batches(textures, 4, B)
     H, W = scenes.H, scenes.W
     mstream, ostream = pooled_stream(torch, "match"), pooled_stream(torch, "orb", 0, -1)
-    NV = args.verify_workers if args.verify_workers > 0 else 6
+    NV = args.verify_workers if args.verify_workers > 0 else 4
     vstreams = [pooled_stream(torch, "verify", j, -1) for j in range(NV)]
     mctx, octx = capi.Context(device, mstream.cuda_stream), capi.Context(device, ostream.cuda_stream)
     vctxs = [capi.Context(device, s.cuda_stream) for s in vstreams]
@@ -546,6 +546,7 @@ def run_configs(torch, capi, synth, device, args):
     for f, fr in enumerate(f5):
         fr["image"] = synth.make_image(f, H=1080, W=1920, n_rect=8000)
     keys5 = {}
+    NV5 = args.verify_workers if args.verify_workers > 0 else 4
 
     def match_c5(sp, i, n_steps):
         if "q_all" not in keys5:
@@ -560,9 +561,9 @@ def run_configs(torch, capi, synth, device, args):
     out["C5_single_gpu_share"] = pipeline_block(
         "C5, one rank's share of the 8-GPU job: per step ORB-2000 on 4 of the 32 1080p frames, the 32 x 2000 descriptors against this "
         "rank's 250k-row shard of the 2M-row DB (k=2, radius 35), merge + full verifier for its own 4 frames", d5, p5, o5, f5, nq5, 2, 35,
-        B5, ["orb", "match", "verify"], 40, H=1080, W=1920, shard=(0, world5), match_fn=match_c5, verify_workers=6,
+        B5, ["orb", "match", "verify"], 40, H=1080, W=1920, shard=(0, world5), match_fn=match_c5, verify_workers=NV5,
         note="no collectives on one GPU: the candidate exchange (32 x 2000 x 2 keys x 8 B per rank) is missing from this figure; "
-             "six verifier batches (of 4 frames) in flight")
+             "%d verifier batches (of 4 frames) in flight" % NV5)
     del d5, p5, f5, keys5
     # ---- C4: float descriptors, L2 brute force as a bf16 MFMA GEMM + exact refinement (matcher only: not a reference feature)
     d4, p4, o4 = synth.make_sift_db(100)

@@ -25,6 +25,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -1759,9 +1760,42 @@ struct VerifyWs {
 struct StreamCache;
 struct VerifyPool {
   std::vector<VerifyWs*> slots; std::vector<StreamCache*> streams;
-  std::vector<hipStream_t> side;                            // flights of a batch (Engine::run_ticks), created on first use
-  std::vector<hipEvent_t> side_ev;
+  std::vector<hipEvent_t> side_ev;                          // one per flight of a batch (Engine::run_ticks), created on first use
 };
+// The flights' streams belong to the process, not to a context: a process has eight hardware queues for all of its streams
+// (DESIGN 7), the runtime deals streams onto them round robin, and every further stream -- busy or not -- makes it likelier that two
+// busy ones share a queue. Contexts driven from several host threads share these few: a flight takes a stream for itself
+// (`taken`) and gives it back when it has landed; a context that finds none free keeps its heavy phase in the lock-step -- with
+// several batches in flight on contexts of their own the batches overlap each other anyway.
+struct SideStreams {
+  struct PerDevice {
+    std::vector<hipStream_t> st;
+    std::atomic<bool> taken[16];
+    PerDevice() { for (auto& t : taken) t.store(false); }
+  };
+  std::mutex mu;
+  std::map<int, PerDevice> by_device;
+  hipError_t get(int device, uint32_t n, std::vector<hipStream_t>& out, PerDevice** pd) {
+    std::lock_guard<std::mutex> g(mu);
+    PerDevice& d = by_device[device];
+    while (d.st.size() < n) {
+      int least = 0, greatest = 0;                          // latency-bound work: the highest priority there is
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+      hipStream_t s2;
+      const hipError_t e = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, greatest);
+      if (e != hipSuccess) return e;
+      d.st.push_back(s2);
+    }
+    out.assign(d.st.begin(), d.st.begin() + n);
+    *pd = &d;
+    return hipSuccess;
+  }
+};
+SideStreams g_side_streams;
+// batches being verified right now, over all contexts of the process: with three or more in the air the hardware queues are
+// already kept busy by each other's ticks and a flight only adds a stream to wait behind (bench `chained`, 4 workers: 4060
+// frames/s in lock-step, 3740 with flights; 1 worker: 1490 / 2230, 2 workers: 2400 / 2900)
+std::atomic<int> g_batches_in_air{0};
 
 constexpr uint32_t kEvalLdsSmall = 48u * 1024u;
 constexpr uint32_t kEvalLdsBig = 160u * 1024u - 512u;
@@ -2442,7 +2476,7 @@ struct Engine {
   // on one of a few side streams ("flights") and their slots rejoin when the flight's event has fired; the other slots keep
   // ticking on the context's stream meanwhile. Nothing here changes what a slot computes or in which order it consumes it.
   static constexpr uint32_t kHeavyN = 96;                  // matches of an object from which its evaluation / growth is a flight
-  struct Flight { hipStream_t st; hipEvent_t ev; std::vector<Slot*> slots; bool busy = false; };
+  struct Flight { hipStream_t st; hipEvent_t ev; std::vector<Slot*> slots; bool busy = false; std::atomic<bool>* taken = nullptr; };
   static bool heavy(const Slot& s) { return (s.ph == PH_EVAL || s.ph == PH_EVAL2 || s.ph == PH_GROWTH) && s.job.n >= kHeavyN; }
   static uint32_t n_side_streams() {
     static const uint32_t n = [] {
@@ -2459,19 +2493,25 @@ struct Engine {
   }
   int run_ticks(std::vector<Slot*>& slots) {
     std::vector<Flight> flights;
-    if (slots.size() > 1) {
+    struct InAir { InAir() { n = g_batches_in_air.fetch_add(1) + 1; } ~InAir() { g_batches_in_air.fetch_sub(1); } int n; } in_air;
+    if (slots.size() > 1 && in_air.n <= 2) {
       VerifyPool* pool = pool_of(ctx);
-      while (pool->side.size() < n_side_streams()) {
-        hipStream_t s2; hipEvent_t e2;
-        int prio = 0;                                       // as the context's stream: the caller chose it against its other work
-        if (hipStreamGetPriority(st, &prio) != hipSuccess) prio = 0;
-        TOD_HIP(hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, prio));
-        if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(s2); return TODHIP_EHIP; }
-        pool->side.push_back(s2); pool->side_ev.push_back(e2);
+      std::vector<hipStream_t> side;
+      SideStreams::PerDevice* pd = nullptr;
+      TOD_HIP(g_side_streams.get(ctx->device, n_side_streams(), side, &pd));
+      while (pool->side_ev.size() < side.size()) {
+        hipEvent_t e2;
+        TOD_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        pool->side_ev.push_back(e2);
       }
-      for (size_t i = 0; i < std::min<size_t>(pool->side.size(), n_side_streams()); ++i) flights.push_back({pool->side[i], pool->side_ev[i], {}, false});
+      for (size_t i = 0; i < side.size(); ++i) flights.push_back({side[i], pool->side_ev[i], {}, false, &pd->taken[i]});
     }
-    auto drain = [&]() { for (Flight& f : flights) if (f.busy) { (void)hipEventSynchronize(f.ev); f.busy = false; } };
+    std::vector<Flight*> free_now;                          // streams taken for this iteration's heavy slots
+    auto drain = [&]() {
+      for (Flight* fp : free_now) if (!fp->busy) fp->taken->store(false);
+      free_now.clear();
+      for (Flight& f : flights) if (f.busy) { (void)hipEventSynchronize(f.ev); f.busy = false; f.taken->store(false); }
+    };
 #define LOOP_HIP(expr) do { if ((expr) != hipSuccess) { drain(); return TODHIP_EHIP; } } while (0)
     std::vector<Slot*> main_slots, heavy_now;
     while (true) {
@@ -2482,13 +2522,13 @@ struct Engine {
         if (q == hipErrorNotReady) continue;
         LOOP_HIP(q);
         f.busy = false;
+        f.taken->store(false);
         TOD_DBG("flight of %zu slot(s) landed", f.slots.size());
         for (Slot* s : f.slots) { s->in_flight = false; if (s->ph != PH_DONE) consume(*s); }
         f.slots.clear();
       }
-      size_t n_free = 0;
       bool any_busy = false;
-      for (const Flight& f : flights) { n_free += !f.busy; any_busy = any_busy || f.busy; }
+      for (const Flight& f : flights) any_busy = any_busy || f.busy;
       main_slots.clear(); heavy_now.clear();
       bool any_live = false;
       // Heavy phases fly only when that lets something else go on meanwhile: other slots with light phases to tick through, or
@@ -2503,10 +2543,21 @@ struct Engine {
         }
         mixed = some_heavy && some_light;
       }
+      // streams this context can have right now (another context may hold them): taken here, given back when unused or landed
+      free_now.clear();
+      if (mixed)
+        for (Flight& f : flights) {
+          bool expected = false;
+          if (!f.busy && f.taken->compare_exchange_strong(expected, true)) free_now.push_back(&f);
+        }
+      const size_t n_free = free_now.size();
       for (Slot* s : slots) {
         if (s->ph == PH_DONE || s->in_flight) continue;
         any_live = true;
-        if (mixed && heavy(*s)) { if (n_free) heavy_now.push_back(s); continue; }   // no flight free: it waits for one
+        if (mixed && heavy(*s) && (n_free || any_busy)) {   // no stream to be had, but one of ours is in the air: it waits for that
+          if (n_free) heavy_now.push_back(s);
+          continue;
+        }
         issue(*s);
         if (s->ph != PH_DONE) main_slots.push_back(s);
       }
@@ -2519,8 +2570,9 @@ struct Engine {
       if (!heavy_now.empty()) {
         const size_t per = (heavy_now.size() + n_free - 1) / n_free;
         size_t next = 0;
-        for (Flight& f : flights) {
-          if (f.busy || next >= heavy_now.size()) continue;
+        for (Flight* fp : free_now) {
+          Flight& f = *fp;
+          if (next >= heavy_now.size()) continue;
           for (size_t i = 0; i < per && next < heavy_now.size(); ++i, ++next) {
             Slot* s = heavy_now[next];
             issue(*s);
@@ -2534,6 +2586,8 @@ struct Engine {
           f.busy = true; any_busy = true;
         }
       }
+      for (Flight* fp : free_now) if (!fp->busy) fp->taken->store(false);   // taken but not needed
+      free_now.clear();
       if (!main_slots.empty()) {
         LOOP_HIP(hipStreamSynchronize(st));
         if (tod_debug())
@@ -2569,7 +2623,6 @@ void tod_verify_ws_free(todhip_ctx* ctx) {
   for (VerifyWs* ws : p->slots) { ws->release(); delete ws; }
   for (StreamCache* c : p->streams) { c->dev.release(); delete c; }
   for (hipEvent_t e : p->side_ev) (void)hipEventDestroy(e);
-  for (hipStream_t s2 : p->side) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
   delete p;
   ctx->verify_ws = nullptr;
 }
