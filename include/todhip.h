@@ -307,6 +307,12 @@ int todhip_test_adjacency(todhip_ctx*, const float* train_xyz, const float* quer
  * (test/test_maximum_clique.cpp:7-53). out3 = {clique size, internal error flag, search steps}. */
 int todhip_test_clique(todhip_ctx*, uint32_t m, const uint32_t* edges, uint32_t n_edges, uint32_t minimal_size,
                        uint32_t* out3);
+/* The same graph through the form of the search the verifier's gate runs: sac_model_registration_graph.h:260-262 only asks whether
+ * the clique FindClique(minimal_size) returns is larger than minimal_size, which is decided once Q holds minimal_size vertices
+ * with a common neighbour (or at the first leaf of at least that size) -- the search stops there. out3[0] = that clique's size
+ * when it is <= minimal_size, a lower bound > minimal_size otherwise; out3[2] = steps actually walked. */
+int todhip_test_clique_gate(todhip_ctx*, uint32_t m, const uint32_t* edges, uint32_t n_edges, uint32_t minimal_size,
+                            uint32_t* out3);
 
 /* FillAdjacency + selectWithinDistance (sac_model_registration_graph.h:171-269) for given sample triples
  * (samples_ order): counts[t] = consensus size, 0 when the clique gate rejects. stop_level 1 skips the clique

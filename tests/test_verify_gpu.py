@@ -55,6 +55,26 @@ def test_clique_random_graphs_equal_oracle(ctx, minimal):
     assert not bad, bad[:10]
 
 
+def test_gate_form_of_the_search_decides_as_the_full_search_does(ctx):
+    """The verifier's gate runs the search only until `clique larger than minimal_size` is decided. On random graphs whose first
+    leaf of >= 7 vertices has 7, 8 or many more (densities 0.3 .. 0.97), and with every minimal size from 3 to 12: the decision
+    equals the full FindClique(minimal_size)'s, the size is exact when it is <= minimal_size, and the gate walks fewer steps."""
+    bad, decided_no, decided_yes, saved = [], 0, 0, 0
+    for seed in range(160):
+        n = [12, 20, 33, 64, 65, 100, 130, 200, 257, 400][seed % 10]
+        p = [0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 0.97][seed % 8]
+        minimal = [7, 7, 3, 5, 9, 12][seed % 6]
+        edges = synth.random_graph_edges(n, p, 900 + seed)
+        o_size, _, _, o_steps = O.clique(n, edges, minimal_size=minimal)
+        size, err, steps = ctx.test_clique(n, edges, minimal, gate=True)
+        ok = err == 0 and (size > minimal) == (o_size > minimal) and steps <= o_steps and (size == o_size if o_size <= minimal else size <= o_size)
+        if not ok:
+            bad.append((seed, n, p, minimal, size, o_size, steps, o_steps, err))
+        decided_yes += o_size > minimal; decided_no += o_size <= minimal; saved += o_steps - steps
+    assert not bad, bad[:10]
+    assert decided_yes >= 40 and decided_no >= 20 and saved > 0, (decided_yes, decided_no, saved)
+
+
 # ------------------------------------------------------------------------------------------ FillAdjacency
 def _clusters_of(sc):
     """ClusterPerObject on the host (plain gather) -> {obj: (train, query, qidx)}"""
@@ -301,6 +321,15 @@ def test_large_dense_object_uses_big_lds_pass(ctx):
     assert len(poses) == 1 and len(poses[0]["inliers"]) > 500
 
 
+@pytest.mark.parametrize("n_kp,per_object,frac,seed", [(1100, 900, 0.55, 81), (1500, 1200, 0.60, 82), (1800, 1400, 0.55, 83)])
+def test_objects_of_513_to_1024_matches_take_the_wide_register_paths(ctx, n_kp, per_object, frac, seed):
+    """600 / 900 / ~1000 consistent matches on one object (9 .. 16 words of 64 vertices): eval_kernel<true> -- the object's vertex
+    numbers kept, 32-register class tuples in the colouring, DegreeSort in registers -- must equal the oracle like every other size"""
+    sc = synth.make_verify_scene(n_kp, n_objects=2, per_object=per_object, visible=((1, frac),), matches_per_kp=1, seed=seed, nan_frac=0.0)
+    poses, rounds = _compare_frame(ctx, sc, 8, 40)
+    assert len(poses) == 1 and 512 < len(poses[0]["inliers"]) <= 1024, len(poses[0]["inliers"])
+
+
 def test_very_large_object_falls_back_to_global_adjacency(ctx):
     """~1500 consistent matches: the induced graph exceeds one CU's LDS, so the gate keeps its adjacency matrix in
     global scratch (third tier). Slow, but the result must still equal the oracle."""
@@ -464,6 +493,42 @@ def test_batch_larger_than_one_launch_group(ctx):
         assert rngs[f].draws == want[f][1] and len(got[f]) == len(want[f][0])
         for a, b in zip(got[f], want[f][0]):
             assert a["object"] == b["object"] and np.array_equal(a["inliers"], b["inliers"]) and np.array_equal(a["R"], b["R"])
+
+
+def test_batch_of_heavy_and_light_frames_equals_frame_by_frame(ctx):
+    """Frames that reach their big object at different ticks, frames with nothing but small objects and an empty frame in one
+    batch: the heavy phases leave the lock-step for side streams (Engine::run_ticks) while the others keep ticking. Whatever the
+    schedule, every frame's poses, consensus sets and generator must equal the single-frame call's."""
+    import torch
+    k, nq = 3, 400
+    vis = [((1, 0.45),), ((6, 0.40), (2, 0.04)), (), ((3, 0.30), (5, 0.30)), ((7, 0.5),), ((0, 0.03), (4, 0.03), (6, 0.03)), ((2, 0.35),), ()]
+    base = [synth.make_verify_scene(nq, visible=v, seed=600 + i, matches_per_kp=3, n_objects=8) for i, v in enumerate(vis)]
+    packed = [_pack_scene(s, k) for s in base]
+    F = 12
+    idx = [(5 * f) % len(base) for f in range(F)]
+    d_kp = torch.from_numpy(np.stack([base[i]["kp_xy"] for i in idx]).astype(np.float32)).cuda()
+    d_cloud = torch.from_numpy(np.stack([base[i]["cloud"] for i in idx]).astype(np.float32)).cuda()
+    d_counts = torch.from_numpy(np.stack([packed[i][0] for i in idx])).cuda()
+    d_m = torch.from_numpy(np.stack([packed[i][1] for i in idx])).cuda()
+    d_xyz = torch.from_numpy(np.stack([packed[i][2] for i in idx])).cuda()
+    d_counts[F - 1] = 0                                                           # a frame without a single match
+    torch.cuda.synchronize()
+    spans = base[0]["spans"]
+    want = []
+    for f in range(F):
+        r = capi.rng_new(7 + f)
+        want.append((ctx.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), 480, 640, d_counts[f].data_ptr(),
+                                       d_m[f].data_ptr(), d_xyz[f].data_ptr(), k, spans, 8, 400, 0.01, r), r))
+    for rep in range(2):                                                          # (the second call finds every buffer warm)
+        rngs = (capi.Rng * F)(*[capi.rng_new(7 + f) for f in range(F)])
+        got = ctx.verify_batch_device(F, d_kp.data_ptr(), nq, d_cloud.data_ptr(), 480, 640, d_counts.data_ptr(), d_m.data_ptr(),
+                                      d_xyz.data_ptr(), k, spans, 8, 400, 0.01, rngs)
+        assert sum(len(p) for p in got) >= 6 and got[F - 1] == []
+        for f in range(F):
+            assert rngs[f].draws == want[f][1].draws and list(rngs[f].s) == list(want[f][1].s) and len(got[f]) == len(want[f][0]), f
+            for a, b in zip(got[f], want[f][0]):
+                assert a["object"] == b["object"] and np.array_equal(a["inliers"], b["inliers"]) and np.array_equal(a["R"], b["R"])
+    assert max(len(p["inliers"]) for f in range(F) for p in got[f]) >= 96         # some object was heavy enough to fly
 
 
 @pytest.mark.parametrize("n_obj", [40, 200])

@@ -54,7 +54,7 @@ EXPORTS = [
     "todhip_version", "todhip_create", "todhip_destroy", "todhip_stream", "todhip_last_hip_error",
     "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_set_ratio_test", "todhip_db_load", "todhip_db_info",
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device", "todhip_merge_shards_device_on",
-    "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_orb_masked", "todhip_test_clique",
+    "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_orb_masked", "todhip_test_clique", "todhip_test_clique_gate",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
     "todhip_orb_device", "todhip_verify_device_depth", "todhip_orb_batch_device",
     "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
@@ -443,11 +443,11 @@ class Context:
         _check(rc, "todhip_test_consensus")
         return counts, dbg
 
-    def test_clique(self, m, edges, minimal_size=0xFFFFFFFF):
+    def test_clique(self, m, edges, minimal_size=0xFFFFFFFF, gate=False):
         e = np.ascontiguousarray(np.asarray(edges, np.uint32).reshape(-1, 2))
         out = np.zeros(3, np.uint32)
-        rc = lib().todhip_test_clique(self._h, C.c_uint32(m), _np_ptr(e), C.c_uint32(len(e)),
-                                      C.c_uint32(minimal_size), _np_ptr(out))
+        fn = lib().todhip_test_clique_gate if gate else lib().todhip_test_clique
+        rc = fn(self._h, C.c_uint32(m), _np_ptr(e), C.c_uint32(len(e)), C.c_uint32(minimal_size), _np_ptr(out))
         _check(rc, "todhip_test_clique")
         return int(out[0]), int(out[1]), int(out[2])
 

@@ -1239,6 +1239,7 @@ __global__ __launch_bounds__(128) void eval_kernel(Slots<EvalArgs> SL) {
 
 // stand-alone clique search on an explicit graph (the reference's test/test_maximum_clique.cpp shape):
 // adj = m x MW bit matrix in global memory. One block of 64 threads.
+template <bool kGate>
 __global__ __launch_bounds__(128) void clique_test_kernel(const u64* adj, uint32_t m, uint32_t minimal_size,
                                                          uint16_t* stack, uint32_t stack_cap, uint32_t lds_bytes,
                                                          uint32_t* out) {
@@ -1256,7 +1257,7 @@ __global__ __launch_bounds__(128) void clique_test_kernel(const u64* adj, uint32
   __syncthreads();
   int err = 0;
   uint32_t steps = 0;
-  const uint32_t q = clique_search<true, false>(L, m, minimal_size, stack, stack_cap, &err, &steps);
+  const uint32_t q = clique_search<true, kGate>(L, m, minimal_size, stack, stack_cap, &err, &steps);
   if (l == 0) { out[0] = q; out[1] = (uint32_t)err; out[2] = steps; }
 }
 
@@ -1878,7 +1879,9 @@ int set_big_lds_once(todhip_ctx* ctx) {
                                 (int)kEvalLdsBig));
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kEvalLdsBig));
-    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clique_test_kernel),
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clique_test_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clique_test_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kEvalLdsBig));
@@ -2948,8 +2951,8 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
 
 // Test hook: the clique search on an explicit graph (edges as pairs), FindClique(minimal_size).
 // out3 = {clique size, error flag, steps}. Mirrors the reference's gtest shape (test/test_maximum_clique.cpp).
-int todhip_test_clique(todhip_ctx* ctx, uint32_t m, const uint32_t* edges, uint32_t n_edges, uint32_t minimal_size,
-                       uint32_t* out3) {
+static int test_clique_impl(todhip_ctx* ctx, uint32_t m, const uint32_t* edges, uint32_t n_edges, uint32_t minimal_size,
+                            uint32_t* out3, bool gate) {
   if (!ctx || !out3 || m == 0 || m > 1024 || (n_edges && !edges)) return TODHIP_EINVAL;
   TOD_HIP(hipSetDevice(ctx->device));
   int rc = set_big_lds_once(ctx);
@@ -2969,12 +2972,29 @@ int todhip_test_clique(todhip_ctx* ctx, uint32_t m, const uint32_t* edges, uint3
   TOD_HIP(hipMemcpyAsync(ws->clique_adj.p, adj.data(), adj.size() * 8, hipMemcpyHostToDevice, ctx->stream));
   if (gate_lds_bytes(m) > kEvalLdsBig) return TODHIP_ESCRATCH;
   const uint32_t lds = gate_lds_bytes(m) <= kEvalLdsSmall ? kEvalLdsSmall : kEvalLdsBig;   // the two LDS tiers of eval_kernel
-  hipLaunchKernelGGL(clique_test_kernel, dim3(1), dim3(64), lds, ctx->stream, ws->clique_adj.as<u64>(), m, minimal_size,
-                     ws->stacks.as<uint16_t>(), kStackCap, lds, ws->small.as<uint32_t>());
+  if (gate)
+    hipLaunchKernelGGL(clique_test_kernel<true>, dim3(1), dim3(64), lds, ctx->stream, ws->clique_adj.as<u64>(), m, minimal_size,
+                       ws->stacks.as<uint16_t>(), kStackCap, lds, ws->small.as<uint32_t>());
+  else
+    hipLaunchKernelGGL(clique_test_kernel<false>, dim3(1), dim3(64), lds, ctx->stream, ws->clique_adj.as<u64>(), m, minimal_size,
+                       ws->stacks.as<uint16_t>(), kStackCap, lds, ws->small.as<uint32_t>());
   TOD_HIP(hipGetLastError());
   TOD_HIP(hipMemcpyAsync(out3, ws->small.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
   TOD_HIP(hipStreamSynchronize(ctx->stream));
   return TODHIP_OK;
+}
+
+int todhip_test_clique(todhip_ctx* ctx, uint32_t m, const uint32_t* edges, uint32_t n_edges, uint32_t minimal_size,
+                       uint32_t* out3) {
+  return test_clique_impl(ctx, m, edges, n_edges, minimal_size, out3, false);
+}
+
+// The same graph through the form of the search the verifier's gate runs (clique_search<., kGate = true>): it stops as soon as
+// "is the clique FindClique(minimal_size) returns larger than minimal_size" is decided, so out3[0] is that clique's size only
+// when it is <= minimal_size, and a lower bound > minimal_size otherwise; out3[2] counts the steps actually walked.
+int todhip_test_clique_gate(todhip_ctx* ctx, uint32_t m, const uint32_t* edges, uint32_t n_edges, uint32_t minimal_size,
+                            uint32_t* out3) {
+  return test_clique_impl(ctx, m, edges, n_edges, minimal_size, out3, true);
 }
 
 }  // extern "C"
