@@ -186,7 +186,9 @@ int todhip_verify_device_depth(todhip_ctx*, const void* d_kp_xy, uint32_t nq, co
  * d_matches_xyz[n_frames*nq*k*3] -- what todhip_match_device yields for n_frames*nq queries); a frame with fewer
  * than nq keypoints pads with counts 0. rng[n_frames]: one generator per frame (decision D4), each advanced as
  * the single-frame call would. Poses of frame f: poses[pose_ptr[f] .. pose_ptr[f+1]) (pose_ptr[n_frames+1]);
- * inlier_begin/end index the shared inlier_kp array. Each frame's result equals the single-frame call's. */
+ * inlier_begin/end index the shared inlier_kp array. Each frame's result equals the single-frame call's.
+ * Frames of a batch that are out of step have their heavy phases (clique gate, growth of objects with >= 96 matches) launched on
+ * up to two process-wide side streams (TODHIP_VERIFY_FLIGHTS, 0 = none); the call returns when everything has finished. */
 int todhip_verify_batch_device(todhip_ctx*, uint32_t n_frames, const void* d_kp_xy, uint32_t nq, const void* d_cloud_xyz,
                                uint32_t H, uint32_t W, const void* d_counts, const void* d_matches, const void* d_matches_xyz,
                                uint32_t k, const float* spans, uint32_t n_objs, const todhip_verify_params*, todhip_rng* rng,
