@@ -669,12 +669,16 @@ def main():
 
     sp = SyntheticPipeline(torch, capi, local_rank, desc, pts, off, my_frames, nq, k, args.radius, B, stages, args.iterations,
                            args.min_inliers, engine=args.engine, shard=(rank, world) if sharded_db else None,
-                           match_fn=match_sharded if sharded_db else None, main_stream=stream)
+                           match_fn=match_sharded if sharded_db else None, main_stream=stream,
+                           # one verifier batch in flight when the step has collectives: the overlapped exchange brings a stream of its
+                           # own, and with five busy streams the matcher's short kernels between two DB passes run 5-10x slower
+                           # (tools/dist1_exp2.sh: RCCL on one rank, 9.8k frames/s with two workers, 10.9k with one; plain path 11.6k)
+                           verify_workers=int(os.environ.get("TOD_BENCH_HEADLINE_VW", "1" if sharded_db and not args.serial_exchange else "2")))
     sp.pipe.next_orb = overlap
     info = sp.info
     check = None
     if sharded_db:
-        cstream = torch.cuda.Stream(priority=-1) if overlap else stream
+        cstream = torch.cuda.Stream(priority=int(os.environ.get("TOD_BENCH_COMM_PRIO", "-1"))) if overlap else stream
         ops = sharded.GpuOps(sp.ctx, stream, cstream, backend, k, args.radius)
         sm_box["sm"] = sharded.ShardedMatcher(ops, world, rank, B, nq, k, exchange=args.exchange, overlap=overlap)
         # self-check before anything is timed: step 0's merged matches of THIS rank's frames == the result of a replica that
@@ -814,7 +818,7 @@ def main():
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
                        "poses_per_frame_rank0": (sp.pipe.n_poses - poses0) / n_fr,
                        "frames_per_rank_per_step": B,
-                       "pipeline": "3 stages, each one batched call per step: ORB | matcher | verifier (two verifier workers on alternate steps)" +
+                       "pipeline": "3 stages, each one batched call per step: ORB | matcher | verifier (%s)" % ("two verifier workers on alternate steps" if len(sp.vstreams) == 2 else "%d verifier worker(s)" % len(sp.vstreams)) +
                                    ("; collectives + merge on a 4th stream, overlapping the neighbouring DB passes" if overlap else ""),
                        "stage_ms_per_step": {key: 1e3 * v / max(n_timed_steps, 1) for key, v in sp.pipe.stage_s.items()},
                        "orb": "ORB-%d, 3 levels, scale 1.2 on the 8(d) synthetic image; %.0f keypoints/frame" %
