@@ -8,8 +8,10 @@
 //
 // All images of a 640x480 pyramid are a few hundred KB: every kernel is latency/launch bound, not bandwidth
 // bound; the per-level work is a fixed sequence of small launches with no host round trip until the final count.
-// A batch of frames rides in the last grid dimension of every launch (frame f owns slice f of every workspace
-// buffer), so a batch costs the launches of one frame.
+// A batch of frames AND the pyramid levels ride in the last grid dimension of every launch: (level l, frame f) is "virtual
+// frame" l F + f and owns slice l F + f of every workspace buffer and its own row of control words, the per-level geometry
+// comes from a small table in the kernel arguments (LevelTab). A batch of any size and any number of levels therefore costs
+// 13 + (levels - 1) launches (round 1 and most of round 2: 2 + 11 per level), blocks beyond a smaller level's extent leave at once.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -28,7 +30,7 @@ struct Cand { int x, y, score; float harris; };
 
 // control words of one level and one frame (device): what the selection kernels hand to each other without a
 // host round trip; [8 + l] = keypoints of level l
-enum { W_NCAND = 0, W_NSEL1 = 1, W_THR = 2, W_NEED_EQ = 3, W_NEQ = 4, W_NGT = 5, W_HIST = 32 };
+enum { W_NCAND = 0, W_NSEL1 = 1, W_THR = 2, W_NEED_EQ = 3, W_NEQ = 4, W_NGT = 5, W_WANT = 6, W_HIST = 32 };
 constexpr uint32_t kCtlWords = 512;
 
 // same generator as the CPU restatement: seeded xorshift, points inside radius 13
@@ -59,6 +61,14 @@ void disc_umax(int* umax) {
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// geometry of the pyramid levels; want[l] == 0: the level yields nothing (too small, or no features asked of it)
+struct LevelTab {
+  uint32_t n_levels, F;
+  const uint8_t* img[kMaxLevels];                          // level l of frame 0 (frame stride: the level-0 pixel count)
+  uint32_t h[kMaxLevels], w[kMaxLevels], want[kMaxLevels];
+  float scale[kMaxLevels];
+};
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const uint8_t* __restrict__ src, uint32_t stride, uint8_t* dst,
                                                         uint32_t h, uint32_t w, size_t src_fs, size_t dst_fs) {
@@ -127,12 +137,15 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* __restrict__ img, ui
 // its 1-pixel halo into LDS (the score image never goes to memory), then suppresses and appends. The candidate order
 // is fixed later by the ranking kernels, so appends are aggregated per wave (one counter atomic per wave).
 constexpr int kNmsTileW = 64, kNmsTileH = 16;
-__global__ __launch_bounds__(256) void fast_nms_kernel(const uint8_t* __restrict__ img, uint32_t h, uint32_t w, Cand* cand,
-                                                       uint32_t cap, uint32_t* counter, uint32_t* hist,
+__global__ __launch_bounds__(256) void fast_nms_kernel(LevelTab T, Cand* cand, uint32_t cap, uint32_t* counter, uint32_t* hist,
                                                        const uint8_t* __restrict__ mask, uint32_t H0, uint32_t W0, size_t fs) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
-  img += blockIdx.z * fs; cand += (size_t)blockIdx.z * cap; counter += blockIdx.z * kCtlWords; hist += blockIdx.z * kCtlWords;
-  if (mask) mask += blockIdx.z * fs;
+  const uint32_t v = blockIdx.z, lvl = v / T.F, f = v - lvl * T.F;
+  const uint32_t h = T.h[lvl], w = T.w[lvl];
+  if (T.want[lvl] == 0u || blockIdx.x * (uint32_t)kNmsTileW >= w || blockIdx.y * (uint32_t)kNmsTileH >= h) return;   // block-uniform
+  const uint8_t* __restrict__ img = T.img[lvl] + f * fs;
+  cand += (size_t)v * cap; counter += v * kCtlWords; hist += v * kCtlWords;
+  if (mask) mask += f * fs;
   __shared__ int s_score[(kNmsTileH + 2) * (kNmsTileW + 2)];
   __shared__ uint32_t s_hist[256];
   const int x0 = (int)blockIdx.x * kNmsTileW, y0 = (int)blockIdx.y * kNmsTileH;
@@ -187,18 +200,13 @@ __device__ __forceinline__ unsigned long long key_of(const Cand& c, bool by_harr
   return ((unsigned long long)hi << 32) | ((unsigned long long)(uint32_t)c.y << 16) | (uint32_t)c.x;
 }
 
-// zero the per-level control words and the score histogram of every frame (level counts at [8..) stay)
-__global__ __launch_bounds__(256) void level_reset_kernel(uint32_t* ctl) {
-  uint32_t* c = ctl + blockIdx.x * kCtlWords;
-  if (threadIdx.x < 8u) c[threadIdx.x] = 0u;
-  c[W_HIST + threadIdx.x] = 0u;
-}
-
 // "keep the 2n best by FAST score" only defines a SET (the Harris ranking re-orders it), so a 256-bin histogram
 // gives the score threshold T: everything above T is kept, and of the candidates at exactly T the first
 // keep - count(> T) in (y, x) order.
-__global__ __launch_bounds__(64) void fast_threshold_kernel(uint32_t* ctl, uint32_t cand_cap, uint32_t keep) {
+__global__ __launch_bounds__(64) void fast_threshold_kernel(LevelTab T, uint32_t* ctl, uint32_t cand_cap) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const uint32_t want = T.want[blockIdx.x / T.F], keep = 2u * want;
+  if (want == 0u) return;
   ctl += blockIdx.x * kCtlWords;
   const uint32_t l = threadIdx.x;                          // one wave per frame: lane l owns score bins 4 l .. 4 l + 3
   const uint32_t n = min(ctl[W_NCAND], cand_cap);
@@ -225,12 +233,15 @@ __global__ __launch_bounds__(64) void fast_threshold_kernel(uint32_t* ctl, uint3
     ctl[W_THR] = thr; ctl[W_NEED_EQ] = (n > keep) ? need : 0u;
     ctl[W_NSEL1] = min(n, keep);
     ctl[W_NGT] = 0u; ctl[W_NEQ] = 0u;
+    ctl[W_WANT] = want;                                    // what the Harris ranking keeps (rank_tiled_kernel's keep_ptr)
   }
 }
 
-__global__ __launch_bounds__(256) void split_kernel(const Cand* __restrict__ cand, uint32_t* ctl, uint32_t keep, Cand* sel1,
+__global__ __launch_bounds__(256) void split_kernel(LevelTab T, const Cand* __restrict__ cand, uint32_t* ctl, Cand* sel1,
                                                     Cand* eq, uint32_t cand_cap, uint32_t sel1_cap) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const uint32_t keep = 2u * T.want[blockIdx.y / T.F];
+  if (keep == 0u) return;
   cand += (size_t)blockIdx.y * cand_cap; eq += (size_t)blockIdx.y * cand_cap; sel1 += (size_t)blockIdx.y * sel1_cap;
   ctl += blockIdx.y * kCtlWords;
   const uint32_t n = ctl[W_NCAND];
@@ -269,14 +280,15 @@ constexpr uint32_t kRankTile = 2048;
 __global__ __launch_bounds__(256) void rank_tiled_kernel(const Cand* __restrict__ in, const uint32_t* __restrict__ n_ptr,
                                                          const uint32_t* __restrict__ keep_ptr, uint32_t keep_val,
                                                          int by_harris, Cand* out, const uint32_t* __restrict__ off_ptr,
-                                                         uint32_t* n_out, uint32_t in_fs, uint32_t out_fs) {
+                                                         uint32_t* n_out, uint32_t in_fs, uint32_t out_fs, uint32_t n_out_F) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   __shared__ unsigned long long keys[kRankTile];
   in += (size_t)blockIdx.y * in_fs; out += (size_t)blockIdx.y * out_fs;      // frame: buffers by their strides,
   n_ptr += blockIdx.y * kCtlWords;                                           // control words by kCtlWords
   if (keep_ptr) keep_ptr += blockIdx.y * kCtlWords;
   if (off_ptr) off_ptr += blockIdx.y * kCtlWords;
-  if (n_out) n_out += blockIdx.y * kCtlWords;
+  // n_out_F != 0: the counts go to row (frame) of n_out, word (level): blockIdx.y = level * n_out_F + frame
+  if (n_out) n_out += n_out_F ? (blockIdx.y % n_out_F) * kCtlWords + blockIdx.y / n_out_F : blockIdx.y * kCtlWords;
   const uint32_t n = *n_ptr;
   const uint32_t keep = keep_ptr ? *keep_ptr : keep_val;
   const uint32_t off = off_ptr ? *off_ptr : 0u;
@@ -297,10 +309,13 @@ __global__ __launch_bounds__(256) void rank_tiled_kernel(const Cand* __restrict_
   if (i < n && rank < keep) out[off + rank] = me;
 }
 
-__global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__ img, uint32_t w, Cand* cand,
-                                                     const uint32_t* __restrict__ n_ptr, size_t fs, uint32_t cand_fs) {
+__global__ __launch_bounds__(256) void harris_kernel(LevelTab T, Cand* cand, const uint32_t* __restrict__ n_ptr, size_t fs,
+                                                     uint32_t cand_fs) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
-  img += blockIdx.y * fs; cand += (size_t)blockIdx.y * cand_fs; n_ptr += blockIdx.y * kCtlWords;
+  const uint32_t lvl = blockIdx.y / T.F, f = blockIdx.y - lvl * T.F, w = T.w[lvl];
+  if (T.want[lvl] == 0u) return;
+  const uint8_t* __restrict__ img = T.img[lvl] + f * fs;
+  cand += (size_t)blockIdx.y * cand_fs; n_ptr += blockIdx.y * kCtlWords;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= *n_ptr) return;
   const int x = cand[i].x, y = cand[i].y, W = (int)w;
@@ -320,9 +335,12 @@ __global__ __launch_bounds__(256) void harris_kernel(const uint8_t* __restrict__
 
 __constant__ int c_gauss7[7] = {18, 33, 49, 56, 49, 33, 18};
 
-__global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst, size_t fs) {
+__global__ __launch_bounds__(256) void blur_h_kernel(LevelTab T, uint8_t* dst, size_t fs) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
-  src += blockIdx.y * fs; dst += blockIdx.y * fs;
+  const uint32_t lvl = blockIdx.y / T.F, f = blockIdx.y - lvl * T.F, h = T.h[lvl], w = T.w[lvl];
+  if (T.want[lvl] == 0u) return;
+  const uint8_t* __restrict__ src = T.img[lvl] + f * fs;
+  dst += blockIdx.y * fs;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
   const int x = (int)(i % w), y = (int)(i / w);
@@ -331,8 +349,10 @@ __global__ __launch_bounds__(256) void blur_h_kernel(const uint8_t* __restrict__
   for (int k = -3; k <= 3; ++k) s += c_gauss7[k + 3] * src[(size_t)y * w + clampi(x + k, 0, (int)w - 1)];
   dst[i] = (uint8_t)((s + 128) >> 8);
 }
-__global__ __launch_bounds__(256) void blur_v_kernel(const uint8_t* __restrict__ src, uint32_t h, uint32_t w, uint8_t* dst, size_t fs) {
+__global__ __launch_bounds__(256) void blur_v_kernel(LevelTab T, const uint8_t* __restrict__ src, uint8_t* dst, size_t fs) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
+  const uint32_t lvl = blockIdx.y / T.F, h = T.h[lvl], w = T.w[lvl];
+  if (T.want[lvl] == 0u) return;
   src += blockIdx.y * fs; dst += blockIdx.y * fs;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= h * w) return;
@@ -344,9 +364,9 @@ __global__ __launch_bounds__(256) void blur_v_kernel(const uint8_t* __restrict__
 }
 
 struct DescribeArgs {
-  const uint8_t* img; const uint8_t* blur; uint32_t w;
-  const Cand* sel; const uint32_t* n_sel;       // this level's selection
-  const uint32_t* level_counts; uint32_t level; // output base = sum of the earlier levels' counts
+  const uint8_t* img; const uint8_t* blur; uint32_t w;   // img, w, level, scale: filled in from the level table by the kernel
+  const Cand* sel;                              // the levels' selections (virtual-frame slices)
+  const uint32_t* level_counts; uint32_t level; // per frame: word l = keypoints of level l; output base = sum of the earlier levels' counts
   float scale; uint32_t cap;
   const int8_t* pattern; int umax[kHalfPatch + 2];
   float* kp_xy; float* kp_aux; uint8_t* desc;
@@ -354,16 +374,18 @@ struct DescribeArgs {
 };
 
 // one wave per keypoint: integer moments over the radius-15 disc (lane = row), then 4 tests per lane
-__global__ __launch_bounds__(256) void describe_kernel(DescribeArgs A) {
+__global__ __launch_bounds__(256) void describe_kernel(LevelTab T, DescribeArgs A) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   {
-    const uint32_t f = blockIdx.y;
-    A.img += f * A.fs; A.blur += f * A.fs; A.sel += (size_t)f * A.sel_fs;
-    A.n_sel += f * kCtlWords; A.level_counts += f * kCtlWords;
+    const uint32_t v = blockIdx.y, lvl = v / T.F, f = v - lvl * T.F;
+    if (T.want[lvl] == 0u) return;
+    A.img = T.img[lvl] + f * A.fs; A.w = T.w[lvl]; A.level = lvl; A.scale = T.scale[lvl];
+    A.blur += v * A.fs; A.sel += (size_t)v * A.sel_fs;
+    A.level_counts += f * kCtlWords;
     A.kp_xy += (size_t)f * A.cap * 2; A.kp_aux += (size_t)f * A.cap * 4; A.desc += (size_t)f * A.cap * 32;
   }
   const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), l = threadIdx.x & 63u;
-  if (i >= *A.n_sel) return;
+  if (i >= A.level_counts[A.level]) return;
   uint32_t base = 0;
   for (uint32_t j = 0; j < A.level; ++j) base += A.level_counts[j];
   const uint32_t o = base + i;
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(256) void copy_out_kernel(const uint32_t* __restric
 }
 
 struct OrbWs {
-  DevBuf img[2], blur, tmp, score, cand, eq, sel1, sel2, small, pattern, in_img, kp_xy, kp_aux, desc, o_xy, o_aux, o_desc, maskbuf;
+  DevBuf pyr, blur, tmp, score, cand, eq, sel1, sel2, small, pattern, in_img, kp_xy, kp_aux, desc, o_xy, o_aux, o_desc, maskbuf;
   HostBuf h_out;
   bool pattern_is_default = false;
   // the per-frame launch sequence is static for a given geometry: captured once per context, replayed. It reads
@@ -470,13 +492,16 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, size_t gray_fs, const uin
   const size_t px = (size_t)H * W;
   const uint32_t cand_cap = (uint32_t)(px / 4 + 64);
   const uint32_t sel1_cap = 2u * n_features + 16u, sel2_cap = n_features + 16u;
-  TOD_HIP(ws->img[0].reserve(F * px)); TOD_HIP(ws->img[1].reserve(F * px));
-  TOD_HIP(ws->blur.reserve(F * px)); TOD_HIP(ws->tmp.reserve(F * px));
-  TOD_HIP(ws->cand.reserve((size_t)F * cand_cap * sizeof(Cand)));
-  TOD_HIP(ws->eq.reserve((size_t)F * cand_cap * sizeof(Cand)));
-  TOD_HIP(ws->sel1.reserve((size_t)F * sel1_cap * sizeof(Cand)));
-  TOD_HIP(ws->sel2.reserve((size_t)F * sel2_cap * sizeof(Cand)));
-  TOD_HIP(ws->small.reserve((size_t)(F + 1) * kCtlWords * sizeof(uint32_t)));   // + one row of per-frame totals
+  const size_t V = (size_t)n_levels * F;                    // virtual frames: (level, frame) pairs, level major
+  if (V > 65535u) return TODHIP_EINVAL;
+  TOD_HIP(ws->pyr.reserve(V * px));
+  TOD_HIP(ws->blur.reserve(V * px)); TOD_HIP(ws->tmp.reserve(V * px));
+  TOD_HIP(ws->cand.reserve(V * cand_cap * sizeof(Cand)));
+  TOD_HIP(ws->eq.reserve(V * cand_cap * sizeof(Cand)));
+  TOD_HIP(ws->sel1.reserve(V * sel1_cap * sizeof(Cand)));
+  TOD_HIP(ws->sel2.reserve(V * sel2_cap * sizeof(Cand)));
+  // control words: one row per virtual frame, then one row per frame for the level counts (word 8 + l), then the totals
+  TOD_HIP(ws->small.reserve((V + F + 1) * kCtlWords * sizeof(uint32_t)));
   TOD_HIP(ws->pattern.reserve(1024));
   TOD_HIP(ws->h_out.reserve((size_t)F * sizeof(uint32_t) + 64));
   TOD_HIP(ws->o_xy.reserve((size_t)F * cap * 8)); TOD_HIP(ws->o_aux.reserve((size_t)F * cap * 16));
@@ -493,20 +518,21 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, size_t gray_fs, const uin
   }
   uint32_t per_level[kMaxLevels];
   features_per_level(n_features, n_levels, scale_factor, per_level);
-  uint32_t* d_small = ws->small.as<uint32_t>();           // per frame: level control words (W_*), [8 + l] level counts
-  uint32_t* d_totals = d_small + (size_t)F * kCtlWords;
-  TOD_HIP(hipMemsetAsync(d_small, 0, (size_t)(F + 1) * kCtlWords * sizeof(uint32_t), st));
+  uint32_t* d_small = ws->small.as<uint32_t>();           // per virtual frame: the level's control words (W_*)
+  uint32_t* d_cnt = d_small + V * kCtlWords;              // per frame: [8 + l] = keypoints of level l
+  uint32_t* d_totals = d_cnt + (size_t)F * kCtlWords;
+  TOD_HIP(hipMemsetAsync(d_small, 0, (V + F + 1) * kCtlWords * sizeof(uint32_t), st));
   const uint32_t px_blocks = (uint32_t)((px + 255) / 256);
   if (stride == W && (F == 1 || gray_fs == px))            // densely packed input: one device-to-device copy
-    TOD_HIP(hipMemcpyAsync(ws->img[0].p, d_gray, (size_t)F * px, hipMemcpyDeviceToDevice, st));
+    TOD_HIP(hipMemcpyAsync(ws->pyr.p, d_gray, (size_t)F * px, hipMemcpyDeviceToDevice, st));
   else
-    hipLaunchKernelGGL(copy_rows_kernel, dim3(px_blocks, F), dim3(256), 0, st, d_gray, stride, ws->img[0].as<uint8_t>(), H, W,
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(px_blocks, F), dim3(256), 0, st, d_gray, stride, ws->pyr.as<uint8_t>(), H, W,
                        gray_fs, px);
   if (d_mask) {
     hipLaunchKernelGGL(copy_rows_kernel, dim3(px_blocks, F), dim3(256), 0, st, d_mask, W, ws->maskbuf.as<uint8_t>(), H, W, px, px);
     d_mask = ws->maskbuf.as<uint8_t>();
   }
-  OrbWs::Key key = {H, W, n_features, n_levels, cap, F, scale_factor, d_kp_xy, d_kp_aux, d_desc, ws->img[0].p, d_mask};
+  OrbWs::Key key = {H, W, n_features, n_levels, cap, F, scale_factor, d_kp_xy, d_kp_aux, d_desc, ws->pyr.p, d_mask};
   static const bool use_graph = getenv("TODHIP_ORB_NO_GRAPH") == nullptr;
   const bool reuse = use_graph && ws->graph_exec && std::memcmp(&key, &ws->key, sizeof(key)) == 0;
   if (!reuse) {
@@ -515,44 +541,48 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, size_t gray_fs, const uin
     // thread-local capture: other host threads keep using the runtime while this one records
     if (use_graph) TOD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     {
-      DescribeArgs D;
-      disc_umax(D.umax);
-      uint32_t ph = H, pw = W;
-      int cur = 0;
+      // the pyramid first (level l from level l - 1), then every kernel once for all levels and frames
+      LevelTab T;
+      std::memset(&T, 0, sizeof(T));
+      T.n_levels = n_levels; T.F = F;
+      uint32_t ph = H, pw = W, want_max = 0;
       for (uint32_t lvl = 0; lvl < n_levels; ++lvl) {
         float scale = 1.f;
         for (uint32_t i = 0; i < lvl; ++i) scale = scale * scale_factor;
         const uint32_t w = (uint32_t)rintf((float)W / scale), h = (uint32_t)rintf((float)H / scale);
+        uint8_t* img = ws->pyr.as<uint8_t>() + (size_t)lvl * F * px;
         if (lvl > 0) {
-          hipLaunchKernelGGL(resize_kernel, dim3((h * w + 255u) / 256u, F), dim3(256), 0, st, ws->img[cur].as<uint8_t>(), ph, pw,
-                             ws->img[cur ^ 1].as<uint8_t>(), h, w, px);
-          cur ^= 1; ph = h; pw = w;
+          hipLaunchKernelGGL(resize_kernel, dim3((h * w + 255u) / 256u, F), dim3(256), 0, st, img - (size_t)F * px, ph, pw, img, h, w, px);
+          ph = h; pw = w;
         }
-        if (h <= 2u * kEdge || w <= 2u * kEdge) continue;     // level count stays 0
-        const uint8_t* img = ws->img[cur].as<uint8_t>();
-        const uint32_t want = per_level[lvl];
-        if (want == 0) continue;
-        hipLaunchKernelGGL(level_reset_kernel, dim3(F), dim3(256), 0, st, d_small);
-        hipLaunchKernelGGL(fast_nms_kernel, dim3((w + kNmsTileW - 1) / kNmsTileW, (h + kNmsTileH - 1) / kNmsTileH, F), dim3(256), 0, st,
-                           img, h, w, ws->cand.as<Cand>(), cand_cap, d_small, d_small + W_HIST, d_mask, H, W, px);
-        hipLaunchKernelGGL(fast_threshold_kernel, dim3(F), dim3(64), 0, st, d_small, cand_cap, 2u * want);
-        hipLaunchKernelGGL(split_kernel, dim3((cand_cap + 255u) / 256u, F), dim3(256), 0, st, ws->cand.as<Cand>(), d_small, 2u * want,
+        T.img[lvl] = img; T.h[lvl] = h; T.w[lvl] = w; T.scale[lvl] = scale;
+        T.want[lvl] = (h <= 2u * kEdge || w <= 2u * kEdge) ? 0u : per_level[lvl];     // too small: the level count stays 0
+        want_max = std::max(want_max, T.want[lvl]);
+      }
+      if (want_max > 0) {
+        const uint32_t Vg = (uint32_t)V;
+        hipLaunchKernelGGL(fast_nms_kernel, dim3((W + kNmsTileW - 1) / kNmsTileW, (H + kNmsTileH - 1) / kNmsTileH, Vg), dim3(256), 0, st,
+                           T, ws->cand.as<Cand>(), cand_cap, d_small, d_small + W_HIST, d_mask, H, W, px);
+        hipLaunchKernelGGL(fast_threshold_kernel, dim3(Vg), dim3(64), 0, st, T, d_small, cand_cap);
+        hipLaunchKernelGGL(split_kernel, dim3((cand_cap + 255u) / 256u, Vg), dim3(256), 0, st, T, ws->cand.as<Cand>(), d_small,
                            ws->sel1.as<Cand>(), ws->eq.as<Cand>(), cand_cap, sel1_cap);
         // ties at the threshold: the first need_eq of them in (y, x) order, placed behind the count(> T) sure ones
-        hipLaunchKernelGGL(rank_tiled_kernel, dim3((cand_cap + 255u) / 256u, F), dim3(256), 0, st, ws->eq.as<Cand>(), d_small + W_NEQ,
-                           d_small + W_NEED_EQ, 0u, 0, ws->sel1.as<Cand>(), d_small + W_NGT, (uint32_t*)nullptr, cand_cap, sel1_cap);
-        hipLaunchKernelGGL(harris_kernel, dim3((2u * want + 255u) / 256u, F), dim3(256), 0, st, img, w, ws->sel1.as<Cand>(),
+        hipLaunchKernelGGL(rank_tiled_kernel, dim3((cand_cap + 255u) / 256u, Vg), dim3(256), 0, st, ws->eq.as<Cand>(), d_small + W_NEQ,
+                           d_small + W_NEED_EQ, 0u, 0, ws->sel1.as<Cand>(), d_small + W_NGT, (uint32_t*)nullptr, cand_cap, sel1_cap, 0u);
+        hipLaunchKernelGGL(harris_kernel, dim3((2u * want_max + 255u) / 256u, Vg), dim3(256), 0, st, T, ws->sel1.as<Cand>(),
                            d_small + W_NSEL1, px, sel1_cap);
-        hipLaunchKernelGGL(rank_tiled_kernel, dim3((2u * want + 255u) / 256u, F), dim3(256), 0, st, ws->sel1.as<Cand>(), d_small + W_NSEL1,
-                           (const uint32_t*)nullptr, want, 1, ws->sel2.as<Cand>(), (const uint32_t*)nullptr, d_small + 8 + lvl,
-                           sel1_cap, sel2_cap);
-        hipLaunchKernelGGL(blur_h_kernel, dim3((h * w + 255u) / 256u, F), dim3(256), 0, st, img, h, w, ws->tmp.as<uint8_t>(), px);
-        hipLaunchKernelGGL(blur_v_kernel, dim3((h * w + 255u) / 256u, F), dim3(256), 0, st, ws->tmp.as<uint8_t>(), h, w,
-                           ws->blur.as<uint8_t>(), px);
-        D.img = img; D.blur = ws->blur.as<uint8_t>(); D.w = w; D.sel = ws->sel2.as<Cand>(); D.n_sel = d_small + 8 + lvl;
-        D.level_counts = d_small + 8; D.level = lvl; D.scale = scale; D.cap = cap; D.pattern = ws->pattern.as<int8_t>();
+        hipLaunchKernelGGL(rank_tiled_kernel, dim3((2u * want_max + 255u) / 256u, Vg), dim3(256), 0, st, ws->sel1.as<Cand>(),
+                           d_small + W_NSEL1, d_small + W_WANT, 0u, 1, ws->sel2.as<Cand>(), (const uint32_t*)nullptr, d_cnt + 8,
+                           sel1_cap, sel2_cap, F);
+        hipLaunchKernelGGL(blur_h_kernel, dim3(px_blocks, Vg), dim3(256), 0, st, T, ws->tmp.as<uint8_t>(), px);
+        hipLaunchKernelGGL(blur_v_kernel, dim3(px_blocks, Vg), dim3(256), 0, st, T, ws->tmp.as<uint8_t>(), ws->blur.as<uint8_t>(), px);
+        DescribeArgs D;
+        std::memset(&D, 0, sizeof(D));
+        disc_umax(D.umax);
+        D.blur = ws->blur.as<uint8_t>(); D.sel = ws->sel2.as<Cand>();
+        D.level_counts = d_cnt + 8; D.cap = cap; D.pattern = ws->pattern.as<int8_t>();
         D.kp_xy = d_kp_xy; D.kp_aux = d_kp_aux; D.desc = d_desc; D.fs = px; D.sel_fs = sel2_cap;
-        hipLaunchKernelGGL(describe_kernel, dim3((want + 3u) / 4u, F), dim3(256), 0, st, D);
+        hipLaunchKernelGGL(describe_kernel, dim3((want_max + 3u) / 4u, Vg), dim3(256), 0, st, T, D);
       }
     }
     if (use_graph) {
@@ -565,7 +595,7 @@ int orb_device(todhip_ctx* ctx, const uint8_t* d_gray, size_t gray_fs, const uin
     }
   }
   if (use_graph) TOD_HIP(hipGraphLaunch(ws->graph_exec, st));
-  hipLaunchKernelGGL(copy_out_kernel, dim3((8u * cap + 255u) / 256u, F), dim3(256), 0, st, d_small + 8, n_levels, cap, d_kp_xy, d_kp_aux,
+  hipLaunchKernelGGL(copy_out_kernel, dim3((8u * cap + 255u) / 256u, F), dim3(256), 0, st, d_cnt + 8, n_levels, cap, d_kp_xy, d_kp_aux,
                      reinterpret_cast<const uint32_t*>(d_desc), u_kp_xy, u_kp_aux, reinterpret_cast<uint32_t*>(u_desc), d_totals);
   TOD_HIP(hipGetLastError());
   uint32_t* h_totals = ws->h_out.as<uint32_t>();
@@ -588,7 +618,7 @@ int tod_orb_device(todhip_ctx* ctx, const uint8_t* d_gray, const uint8_t* d_mask
 void tod_orb_ws_free(todhip_ctx* ctx) {
   if (!ctx->orb_ws) return;
   OrbWs* ws = reinterpret_cast<OrbWs*>(ctx->orb_ws);
-  DevBuf* bufs[] = {&ws->img[0], &ws->img[1], &ws->blur, &ws->tmp, &ws->score, &ws->cand, &ws->eq, &ws->sel1, &ws->sel2,
+  DevBuf* bufs[] = {&ws->pyr, &ws->blur, &ws->tmp, &ws->score, &ws->cand, &ws->eq, &ws->sel1, &ws->sel2,
                     &ws->small, &ws->pattern, &ws->in_img, &ws->kp_xy, &ws->kp_aux, &ws->desc, &ws->o_xy, &ws->o_aux, &ws->o_desc,
                     &ws->maskbuf};
   for (DevBuf* b : bufs) b->release();
