@@ -984,6 +984,8 @@ struct EvalArgs {
   uint32_t* dbg;                  // optional: per iteration dbg_stride words {cnt, m, F members...}
   uint32_t dbg_stride;
   uint32_t stop_level;            // 0 = full evaluation, 1 = stop before the clique search (diagnostics)
+  const uint32_t* n_items_dev;    // optional: only the first *n_items_dev items exist (an evaluation launched in the tick of the walk
+                                  // that draws its iterations: ChainOut::n_done)
 };
 
 // The gate of one hypothesis (sac_model_registration_graph.h:219-265): induced sample sub-graph of F, degree test,
@@ -1184,7 +1186,8 @@ __global__ __launch_bounds__(128) void eval_kernel(Slots<EvalArgs> SL) {
   const ObjJob& job = A.job;
   const uint32_t W = job.W;
   uint16_t* stack = A.stacks + (size_t)blockIdx.x * A.stack_cap;
-  const uint32_t n_items = A.from_deferred ? A.n_deferred : (A.it_end - A.it_begin);
+  uint32_t n_items = A.from_deferred ? A.n_deferred : (A.it_end - A.it_begin);
+  if (A.n_items_dev) n_items = min(n_items, uni(*A.n_items_dev));
   {                                                        // one block = one hypothesis
     const uint32_t item = blockIdx.x;
     if (item >= n_items) return;
@@ -1906,8 +1909,7 @@ struct DepthInput { const void* d_depth; int is_u16; float fx, fy, cx, cy; };
 // each non-empty list once (all slots in one grid), synchronizes once, and lets every slot consume its results
 // (the ransac.h:95-135 bookkeeping is replayed on the host so that pow/log are libm's).
 enum Phase { PH_CLUSTER, PH_CLUSTER_WAIT, PH_GROUP, PH_PREPALL, PH_PREPALL_WAIT, PH_OBJECT, PH_ROUND, PH_PREP_WAIT, PH_DRAW,
-             PH_DRAW_WAIT, PH_EVAL,
-             PH_EVAL_WAIT, PH_EVAL2, PH_EVAL2_WAIT, PH_GROWTH, PH_GROWTH_WAIT, PH_DONE };
+             PH_DRAW_WAIT, PH_EVAL2, PH_EVAL2_WAIT, PH_GROWTH, PH_GROWTH_WAIT, PH_DONE };
 
 struct RoundState {                                       // computeModel (ransac.h:80-143) in flight
   uint64_t consumed = 0;                                  // draws used by completed getSamples calls of this round
@@ -2048,6 +2050,40 @@ struct Engine {
     begin_batch(s);
   }
 
+  // the evaluation of iterations [it_lo, it_hi) (first pass), or of the deferred ones (second pass: graphs that need the whole
+  // LDS of a CU, or global scratch). zero_status: first evaluation launch of the batch (the deferred list and the counters
+  // accumulate over the windows of one batch)
+  void push_eval(Slot& s, bool second, uint32_t it_lo, uint32_t it_hi, const uint32_t* n_items_dev, bool zero_status) {
+    VerifyWs* ws = s.ws;
+    uint32_t* d_small = ws->small.as<uint32_t>();
+    RoundState& r = s.r;
+    EvalArgs A;
+    A.job = s.job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = it_lo; A.it_end = it_hi;
+    A.counts = ws->m_counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
+    A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>();
+    A.stack_cap = kStackCap; A.lds_bytes = second ? kEvalLdsBig : eval_lds_small(s.job.n); A.from_deferred = second ? 1u : 0u;
+    A.n_deferred = second ? r.n_def : 0u;
+    SLOT_HIP(ws->stacks.reserve((size_t)std::max(std::max(it_hi - it_lo, r.n_def), 64u) * kStackCap * sizeof(uint16_t)));
+    A.stacks = ws->stacks.as<uint16_t>();
+    A.adjc_scratch = nullptr; A.dbg = nullptr; A.dbg_stride = 0; A.stop_level = 0; A.n_items_dev = n_items_dev;
+    if (second) {
+      SLOT_HIP(ws->adjc_scratch.reserve((size_t)r.n_def * kAdjcScratchWords * sizeof(u64)));
+      A.adjc_scratch = ws->adjc_scratch.as<u64>();
+      L.zero.push_back({nullptr, d_small + 8, 1u});
+      L.eval_big.push_back(A);
+      return;
+    }
+    if (zero_status) L.zero.push_back({nullptr, d_small + 8, 12u});
+    // A few hypotheses of an object whose consensus lists (about all of its valid matches when the object is really there)
+    // will not fit the 48 KB carve: straight to a whole CU's LDS instead of a first pass that only finds that out
+    if (it_hi - it_lo <= 16u && gate_lds_bytes(r.nvalid) + 4096u > kEvalLdsSmall) {
+      A.lds_bytes = kEvalLdsBig;
+      L.eval_direct.push_back(A);
+    } else {
+      L.eval_small.push_back(A);
+    }
+  }
+
   // ---- issue: queue the kernels of the slot's next phase
   void issue(Slot& s) {
     VerifyWs* ws = s.ws;
@@ -2134,40 +2170,17 @@ struct Engine {
       ChainArgs ca = {ws->table.as<DrawEntry>(), r.S, r.want - r.got, r.attempts_carry, r.it_begin + r.got,
                       ws->iter_samples.as<uint32_t>(), ws->m_pos.as<uint32_t>(), reinterpret_cast<ChainOut*>(d_small + 1)};
       L.chain.push_back(ca);
+      // the evaluation of the iterations this walk draws rides in the same tick: its grid covers everything still wanted, and
+      // the kernel takes the number that really exist from the walk's ChainOut. One host round trip less per evaluation batch.
+      push_eval(s, false, r.it_begin + r.got, r.it_begin + r.want, d_small + 1, r.got == 0u);
       export_small(s);
       s.ph = PH_DRAW_WAIT;
       return;
     }
-    if (s.ph == PH_EVAL || s.ph == PH_EVAL2) {
-      RoundState& r = s.r;
-      const bool second = s.ph == PH_EVAL2;
-      EvalArgs A;
-      A.job = s.job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = r.it_begin; A.it_end = r.it_drawn;
-      A.counts = ws->m_counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
-      A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>(); A.stacks = ws->stacks.as<uint16_t>();
-      A.stack_cap = kStackCap; A.lds_bytes = second ? kEvalLdsBig : eval_lds_small(s.job.n); A.from_deferred = second ? 1u : 0u;
-      A.n_deferred = second ? r.n_def : 0u;
-      SLOT_HIP(ws->stacks.reserve((size_t)std::max(r.it_drawn - r.it_begin, 64u) * kStackCap * sizeof(uint16_t)));
-      A.stacks = ws->stacks.as<uint16_t>();
-      A.adjc_scratch = nullptr; A.dbg = nullptr; A.dbg_stride = 0; A.stop_level = 0;
-      if (second) {                                         // graphs that need the whole LDS of a CU, or global scratch
-        SLOT_HIP(ws->adjc_scratch.reserve((size_t)r.n_def * kAdjcScratchWords * sizeof(u64)));
-        A.adjc_scratch = ws->adjc_scratch.as<u64>();
-        L.zero.push_back({nullptr, d_small + 8, 1u});
-        L.eval_big.push_back(A);
-      } else {
-        L.zero.push_back({nullptr, d_small + 8, 12u});
-        // A few hypotheses of an object whose consensus lists (about all of its valid matches when the object is really there)
-        // will not fit the 48 KB carve: straight to a whole CU's LDS instead of a first pass that only finds that out
-        if (r.it_drawn - r.it_begin <= 16u && gate_lds_bytes(r.nvalid) + 4096u > kEvalLdsSmall) {
-          A.lds_bytes = kEvalLdsBig;
-          L.eval_direct.push_back(A);
-        } else {
-          L.eval_small.push_back(A);
-        }
-      }
+    if (s.ph == PH_EVAL2) {
+      push_eval(s, true, 0u, 0u, nullptr, true);
       export_small(s);
-      s.ph = second ? PH_EVAL2_WAIT : PH_EVAL_WAIT;
+      s.ph = PH_EVAL2_WAIT;
       return;
     }
     if (s.ph == PH_GROWTH) {                                // growth (adjacency_ransac.cpp:255-308)
@@ -2194,7 +2207,29 @@ struct Engine {
   void after_draw(Slot& s) {
     RoundState& r = s.r;
     r.it_drawn = r.it_begin + r.got;
-    if (r.got > 0) s.ph = PH_EVAL; else replay(s);
+    if (r.got > 0) eval_done(s, false); else replay(s);    // the iterations were evaluated in the ticks that drew them
+  }
+  // the first evaluation pass of a batch is complete (its status words are in the mailbox), or the second one
+  void eval_done(Slot& s, bool second) {
+    RoundState& r = s.r;
+    const uint32_t* m = mail(s);
+    if (!second) {
+      ctx->counters.last_gate_calls += m[13];
+      r.n_def = m[14];
+      TOD_DBG("  eval done: gate calls=%u deferred=%u", m[13], r.n_def);
+      if (r.n_def > 0) { s.ph = PH_EVAL2; return; }
+    }
+    ctx->counters.last_hypotheses += r.got;
+    replay(s);
+  }
+  bool eval_failed(Slot& s) {
+    const uint32_t* m = mail(s);
+    if (m[12] == 0) return false;
+    if (tod_debug())
+      fprintf(stderr, "[todhip] eval status %u: g=%u value=%u m=%u it=%u (n=%u W=%u)\n", m[12], m[16], m[17], m[18], m[19],
+              s.job.n, s.job.W);
+    fail(s, TODHIP_ESCRATCH);
+    return true;
   }
   // ---- ransac.h:95-135 over the iterations known so far
   void replay(Slot& s) {
@@ -2293,6 +2328,7 @@ struct Engine {
       return;
     }
     if (s.ph == PH_DRAW_WAIT) {
+      if (eval_failed(s)) return;                           // (the evaluation of this walk's iterations ran in the same tick)
       const ChainOut co = *reinterpret_cast<const ChainOut*>(m + 1);
       TOD_DBG("  draw window: S=%u len=%u -> done=%u pos_end=%u attempts=%u flag=%u", r.S, r.window_len, co.n_done, co.pos_end,
               co.attempts, co.flag);
@@ -2317,22 +2353,9 @@ struct Engine {
       if (r.got < r.want && !r.selection_empty) s.ph = PH_DRAW; else after_draw(s);
       return;
     }
-    if (s.ph == PH_EVAL_WAIT || s.ph == PH_EVAL2_WAIT) {
-      if (m[12] != 0) {
-        if (tod_debug())
-          fprintf(stderr, "[todhip] eval status %u: g=%u value=%u m=%u it=%u (n=%u W=%u)\n", m[12], m[16], m[17], m[18], m[19],
-                  s.job.n, s.job.W);
-        fail(s, TODHIP_ESCRATCH);
-        return;
-      }
-      if (s.ph == PH_EVAL_WAIT) {
-        ctx->counters.last_gate_calls += m[13];
-        r.n_def = m[14];
-        TOD_DBG("  eval done: gate calls=%u deferred=%u", m[13], r.n_def);
-        if (r.n_def > 0) { s.ph = PH_EVAL2; return; }
-      }
-      ctx->counters.last_hypotheses += r.got;
-      replay(s);
+    if (s.ph == PH_EVAL2_WAIT) {
+      if (eval_failed(s)) return;
+      eval_done(s, true);
       return;
     }
     if (s.ph == PH_GROWTH_WAIT) {
@@ -2480,7 +2503,7 @@ struct Engine {
   // ticking on the context's stream meanwhile. Nothing here changes what a slot computes or in which order it consumes it.
   static constexpr uint32_t kHeavyN = 96;                  // matches of an object from which its evaluation / growth is a flight
   struct Flight { hipStream_t st; hipEvent_t ev; std::vector<Slot*> slots; bool busy = false; std::atomic<bool>* taken = nullptr; };
-  static bool heavy(const Slot& s) { return (s.ph == PH_EVAL || s.ph == PH_EVAL2 || s.ph == PH_GROWTH) && s.job.n >= kHeavyN; }
+  static bool heavy(const Slot& s) { return (s.ph == PH_DRAW || s.ph == PH_EVAL2 || s.ph == PH_GROWTH) && s.job.n >= kHeavyN; }
   static uint32_t n_side_streams() {
     static const uint32_t n = [] {
       const char* e = getenv("TODHIP_VERIFY_FLIGHTS");
@@ -2919,7 +2942,7 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   A.counts = ws->counts.as<int32_t>(); A.gate_m = ws->gate_m.as<uint32_t>(); A.work = d_small + 8;
   A.status = d_small + 12; A.deferred = ws->deferred.as<uint32_t>(); A.stacks = ws->stacks.as<uint16_t>();
   A.stack_cap = kStackCap; A.lds_bytes = kEvalLdsSmall; A.from_deferred = 0; A.n_deferred = 0;
-  A.adjc_scratch = nullptr;
+  A.adjc_scratch = nullptr; A.n_items_dev = nullptr;
   A.dbg = dbg ? ws->table.as<uint32_t>() : nullptr; A.dbg_stride = dbg_stride; A.stop_level = stop_level;
   if (n_triples > kMaxEvalWaves) return TODHIP_EINVAL;
   if (W <= 8u) launch_list(st, eval_kernel<false>, std::vector<EvalArgs>{A}, 64, kEvalLdsSmall, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
