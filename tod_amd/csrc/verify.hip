@@ -40,12 +40,14 @@ namespace {
 // batch (each at its own point of its own RANSAC state machine) share launches, so a batch costs the launches and
 // host round trips of one frame.
 constexpr uint32_t kMaxSlots = 16;                         // 16 x 200 B of EvalArgs stays under the 4 KB kernarg limit
-constexpr uint32_t kManySlots = 40;                        // kernels with ~100 B of arguments per slot (4 KB of kernarg in all)
+constexpr uint32_t kManySlots = 36;                        // kernels with ~110 B of arguments per slot (4 KB of kernarg in all)
 template <class A, uint32_t N = kMaxSlots> struct Slots { A a[N]; };
 
 struct AdjArgs { ObjJob job; float span, err; };
 struct JobArgs { ObjJob job; };
-struct PrepArgs { ObjJob job; uint32_t* stats; };   // stats[0] = |valid|, [1] = sum of sample degrees inside valid, [2] = triangle found
+// gate (optional): the kernel does nothing unless *gate >= gate_min -- the next round's preparation rides in the tick of the growth
+// that decides whether there is a next round (GrowthOut::n_kp_inliers against min_inliers, GuessGenerator.cpp:205-206)
+struct PrepArgs { ObjJob job; uint32_t* stats; const uint32_t* gate; uint32_t gate_min; };   // stats[0] = |valid|, [1] = sum of sample degrees inside valid, [2] = triangle found
 struct DrawArgs { ObjJob job; const uint32_t* rnd; uint32_t window_len, S; DrawEntry* table; };
 struct ChainArgs {
   const DrawEntry* table; uint32_t S, n_req, attempts0, out_base;
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256) void round_prep_kernel(Slots<PrepArgs, kManySl
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.y].job;
   uint32_t* const stats = S.a[blockIdx.y].stats;
+  if (S.a[blockIdx.y].gate && *S.a[blockIdx.y].gate < S.a[blockIdx.y].gate_min) return;   // block-uniform
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   bool isv = false;
   uint32_t d = 0;
@@ -1580,13 +1583,14 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
 // ------------------------------------------------------------------------------------------------ K11
 // InvalidateQueryIndices (adjacency_ransac.cpp:93-123): drop every valid match whose keypoint is an inlier
 // keypoint, then InvalidateIndices (:63-89): repeatedly drop valid matches whose sample degree is < 3.
-struct InvArgs { ObjJob job; const u64* kp_bits; u64* scratch; };
+struct InvArgs { ObjJob job; const u64* kp_bits; u64* scratch; const uint32_t* gate; uint32_t gate_min; };   // gate: as PrepArgs
 // 256 threads (one wave per SIMD): a block this size still finds wave slots on a CU whose other slots are held by the
 // matcher's resident grid; a 1024-thread block had to wait for a whole matcher launch to end (1.4 ms on average)
 __global__ __launch_bounds__(256) void invalidate_kernel(Slots<InvArgs> SL) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = SL.a[blockIdx.x].job;
   const u64* const kp_bits = SL.a[blockIdx.x].kp_bits; u64* const scratch = SL.a[blockIdx.x].scratch;
+  if (SL.a[blockIdx.x].gate && *SL.a[blockIdx.x].gate < SL.a[blockIdx.x].gate_min) return;   // block-uniform
   __shared__ uint32_t sAny;
   const uint32_t tid = threadIdx.x, W = job.W, n = job.n;
   if (tid == 0) sAny = 0u;
@@ -1958,7 +1962,7 @@ struct Slot {
 struct Launches {
   std::vector<CopyArgs> copy_in, zero, copy_out;
   std::vector<LookupArgs> lookup; std::vector<ScanArgs> scan; std::vector<ScatterArgs> scatter; std::vector<GroupArgs> group;
-  std::vector<InvArgs> inval; std::vector<JobArgs> finite; std::vector<AdjArgs> adj; std::vector<PrepArgs> prep;
+  std::vector<InvArgs> inval, inval_after; std::vector<JobArgs> finite; std::vector<AdjArgs> adj; std::vector<PrepArgs> prep, prep_after;   // *_after: behind the growth kernels
   std::vector<DrawArgs> draw, draw_small; std::vector<ChainArgs> chain;
   // the rnd pointers of the draw lists are resolved at launch time: a later slot of the same tick may grow (move)
   // the shared stream buffer
@@ -2122,7 +2126,7 @@ struct Engine {
         const ObjJob job = make_job(s, s.objs[i]);
         L.finite.push_back({job});
         L.adj.push_back({job, spans[s.objs[i].obj], prm->sensor_error});
-        L.prep.push_back({job, ws->nvalid.as<uint32_t>() + 4 * i});
+        L.prep.push_back({job, ws->nvalid.as<uint32_t>() + 4 * i, nullptr, 0u});
       }
       L.copy_out.push_back({ws->nvalid.as<uint32_t>(), ws->m_nvalid.as<uint32_t>(), 4u * (uint32_t)std::max<size_t>(s.objs.size(), 1)});
       s.ph = PH_PREPALL_WAIT;
@@ -2142,11 +2146,11 @@ struct Engine {
     }
     if (s.ph == PH_ROUND) {                                 // one AdjacencyRansac::Ransac call (GuessGenerator.cpp:192-231)
       if (s.pending_invalidate) {
-        L.inval.push_back({s.job, ws->kp_bits.as<u64>(), obj_bits(s) + 6 * s.job.W});
+        L.inval.push_back({s.job, ws->kp_bits.as<u64>(), obj_bits(s) + 6 * s.job.W, nullptr, 0u});
         s.pending_invalidate = false;
       }
       L.zero.push_back({nullptr, d_small, 64u});
-      L.prep.push_back({s.job, d_small + 5});             // words 5..7: |valid|, degree sum, triangle (1..4 = ChainOut)
+      L.prep.push_back({s.job, d_small + 5, nullptr, 0u});   // words 5..7: |valid|, degree sum, triangle (1..4 = ChainOut)
       export_small(s);
       s.tr = todhip_round_trace();
       s.tr.object = s.objs[s.oi].obj; s.tr.draws_before = s.start_draws + s.abs_pos; s.tr.best_count = -INT_MAX;
@@ -2190,6 +2194,13 @@ struct Engine {
                        d_bits + 4 * W, d_bits + 5 * W, ws->m_kp.as<uint32_t>(), ws->kp_bits.as<u64>(), kp_words,
                        reinterpret_cast<GrowthOut*>(d_small + 32)};
       L.growth.push_back(ga);
+      // If the pose is accepted (enough inlier keypoints, GuessGenerator.cpp:205-206) the object gets another round, which starts
+      // with InvalidateQueryIndices and the validity / degree pass: both ride in this tick behind the growth, gated on the device
+      // by the count the growth kernel writes, so an accepted pose costs no tick of its own. (Not accepted: they do nothing.)
+      const uint32_t* gate = d_small + 32 + offsetof(GrowthOut, n_kp_inliers) / sizeof(uint32_t);
+      L.zero.push_back({nullptr, d_small, 32u});           // words 5..7 (the pass's counters) among them; GrowthOut starts at 32
+      L.inval_after.push_back({s.job, ws->kp_bits.as<u64>(), obj_bits(s) + 6 * s.job.W, gate, prm->min_inliers});
+      L.prep_after.push_back({s.job, d_small + 5, gate, prm->min_inliers});
       export_small(s);
       s.ph = PH_GROWTH_WAIT;
       return;
@@ -2287,8 +2298,12 @@ struct Engine {
     p.inlier_end = (uint32_t)s.inliers.size();
     s.poses.push_back(p);
     ctx->counters.last_poses += 1;
-    s.pending_invalidate = true;                            // InvalidateQueryIndices, then the next round (:207-230)
-    s.ph = PH_ROUND;
+    // InvalidateQueryIndices and the next round's validity pass (:207-230) ran behind the growth kernel in this tick
+    s.pending_invalidate = false;
+    s.tr = todhip_round_trace();
+    s.tr.object = s.objs[s.oi].obj; s.tr.draws_before = s.start_draws + s.abs_pos; s.tr.best_count = -INT_MAX;
+    const uint32_t* m = mail(s);
+    start_round(s, m[5], m[6], m[7]);
   }
 
   // ---- consume: the tick's results are in the mailbox
@@ -2466,6 +2481,8 @@ struct Engine {
       launch_list(st, eval_kernel<true>, wide, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
     }
     launch_list(st, growth_kernel, L.growth, 256, 0, 0, [](const GrowthArgs&) { return dim3(1); });
+    launch_list(st, invalidate_kernel, L.inval_after, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
+    launch_list<kManySlots>(st, round_prep_kernel, L.prep_after, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
     launch_list(st, copy_words_kernel, L.copy_out, 256, 0, 1, words);
     L = Launches();
   }
@@ -2935,7 +2952,7 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   launch_list<kManySlots>(st, finite_kernel, std::vector<JobArgs>{{job}}, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
   launch_list<kManySlots>(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
               [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
-  launch_list<kManySlots>(st, round_prep_kernel, std::vector<PrepArgs>{{job, d_small + 5}}, 256, 0, 1,
+  launch_list<kManySlots>(st, round_prep_kernel, std::vector<PrepArgs>{{job, d_small + 5, nullptr, 0u}}, 256, 0, 1,
               [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
   EvalArgs A;
   A.job = job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = 0; A.it_end = n_triples;
