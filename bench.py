@@ -11,7 +11,7 @@ The `chained` block (N=1) times the real dataflow: DB trained by todhip_model_* 
 consuming each other's device buffers (tod_amd/scenes.py).
 
 With N GPUs (tod_amd/sharded.py::ShardedMatcher) the descriptor rows are split into N object-aligned shards and a step
-processes 16 frames per rank: descriptors are all-gathered, every rank matches all N x 16 frames against its shard, the
+processes B frames per rank (--batch, 32): descriptors are all-gathered, every rank matches all N x B frames against its shard, the
 per-shard candidates are exchanged with one RCCL collective (all-to-all by default: a rank only needs the candidates of
 its own frames; --exchange all_gather for the literal all-gather), and every rank merges (order: distance asc, global
 row asc) and verifies its own frames. Per-GPU work is constant as N grows (weak scaling). Launch: the driver's
@@ -64,7 +64,7 @@ LANEOPS_DENSE = 16                                  # 8 v_xor_b32 + 8 accumulati
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="steps per timed region (200 x 16 frames at ~1.4 ms: 0.3 s per region)")
+    ap.add_argument("--steps", type=int, default=200, help="steps per timed region (200 x 32 frames at ~2.6 ms: 0.5 s per region)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--repeats", type=int, default=3, help="the timed region of --steps steps is run this many times; value = median")
     ap.add_argument("--objects", type=int, default=200, help="objects of 5000 descriptors (200 -> 1M rows)")
@@ -73,7 +73,10 @@ def parse():
     ap.add_argument("--radius", type=int, default=35)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
     ap.add_argument("--stages", default="orb,match,verify", help="comma list of: orb,match,verify")
-    ap.add_argument("--batch", type=int, default=16, help="frames per rank per step")
+    ap.add_argument("--batch", type=int, default=32,
+                    help="frames per rank per step of the headline pipeline (tools/batch_sweep.sh: 16 -> 11.8k frames/s, 24 -> 12.0k, 32 -> 12.4k, "
+                         "48 -> 11.9k: the per-launch costs of the DB pass are spread over more queries, and 250 query groups tile the "
+                         "matrix-core kernel better than 125 or 375); the other blocks keep their own batch sizes")
     ap.add_argument("--verify-workers", type=int, default=0,
                     help="verifier batches in flight in the chained and C5 pipelines (one context, stream and host thread each); 0 = 4: the "
                          "verifier mostly waits for single-wave kernels, so batches overlap almost freely -- until the process has more busy "
@@ -272,7 +275,7 @@ def run_chained(torch, capi, device, args):
     from tod_amd import scenes
     from tod_amd.pipeline import StagePipeline
     t_setup = time.perf_counter()
-    B, nq, k, radius = args.batch, args.nq, args.k, args.radius
+    B, nq, k, radius = 16, args.nq, args.k, args.radius                    # (its own batch size: the block was tuned at 16 frames per step)
     n_obj = args.objects
     textures = scenes.make_textures(n_obj)
     tctx = capi.Context(device)
@@ -670,10 +673,12 @@ def main():
     sp = SyntheticPipeline(torch, capi, local_rank, desc, pts, off, my_frames, nq, k, args.radius, B, stages, args.iterations,
                            args.min_inliers, engine=args.engine, shard=(rank, world) if sharded_db else None,
                            match_fn=match_sharded if sharded_db else None, main_stream=stream,
-                           # one verifier batch in flight when the step has collectives: the overlapped exchange brings a stream of its
-                           # own, and with five busy streams the matcher's short kernels between two DB passes run 5-10x slower
-                           # (tools/dist1_exp2.sh: RCCL on one rank, 9.8k frames/s with two workers, 10.9k with one; plain path 11.6k)
-                           verify_workers=int(os.environ.get("TOD_BENCH_HEADLINE_VW", "1" if sharded_db and not args.serial_exchange else "2")))
+                           # With collectives in the step the overlapped exchange brings a stream of its own, and with five busy streams
+                           # the matcher's short kernels between two DB passes run 5-10x slower (tools/dist1_exp2.sh: RCCL on one rank,
+                           # 16 frames per step: 9.8k frames/s with two verifier workers, 10.9k with one; plain path 11.6k). At 32 frames
+                           # per step that loss is spread over a step twice as long and one worker no longer keeps up
+                           # (tools/batch_sweep_dist.sh: 9.3k with one worker, 11.4k with two; plain path 12.4k)
+                           verify_workers=int(os.environ.get("TOD_BENCH_HEADLINE_VW", "1" if sharded_db and not args.serial_exchange and B < 24 else "2")))
     sp.pipe.next_orb = overlap
     info = sp.info
     check = None
