@@ -371,6 +371,9 @@ __device__ __forceinline__ void mfma_step(const Fp4Row& a, Fp4Row& a_next, const
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     if (t & 1) acc_odd = dot_block(a, qb[t]); else acc_even = dot_block(a, qb[t]);
+#if defined(TOD_K4X_ABLATE) && TOD_K4X_ABLATE == 3           // diagnostics build only: no fp4 expansion (the packed words are "used")
+    if (t == 0) { a_next = a; asm volatile("" :: "v"(p_next.x), "v"(p_next.y), "v"(p_next.z), "v"(p_next.w)); }
+#else
     if (QT >= 4) {
       if (t == 0) a_next.s[0] = expand_word(p_next.x, kc);
       if (t == 1) a_next.s[1] = expand_word(p_next.y, kc);
@@ -380,8 +383,13 @@ __device__ __forceinline__ void mfma_step(const Fp4Row& a, Fp4Row& a_next, const
       if (t == 0) { a_next.s[0] = expand_word(p_next.x, kc); a_next.s[1] = expand_word(p_next.y, kc); }
       if (t == 1) { a_next.s[2] = expand_word(p_next.z, kc); a_next.s[3] = expand_word(p_next.w, kc); }
     }
+#endif
+#if defined(TOD_K4X_ABLATE) && TOD_K4X_ABLATE == 2           // diagnostics build only: no block test (the MFMAs stay: their results are "used")
+    if (t == 0) asm volatile("" :: "v"(acc_odd)); else if (t & 1) asm volatile("" :: "v"(acc_even)); else asm volatile("" :: "v"(acc_odd));
+#else
     if (t == 0) mfma_block_test<K, MASK, IMAX>(acc_odd, thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]);   // previous step's last block
     else mfma_block_test<K, MASK, IMAX>((t & 1) ? acc_even : acc_odd, thr[t - 1], r_lane, n_lim, best[t - 1]);
+#endif
   }
 }
 
@@ -434,7 +442,11 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   // this lane's 16 bytes of DB row (row0 + 32 step + c), clamped into the DB (rows past the end are masked, not used)
   auto load_step = [&](uint32_t step) -> uint4 {
     const uint32_t r = min(row0 + 32u * min(step, n_steps - 1u) + c, last_row);
+#if defined(TOD_K4X_ABLATE) && TOD_K4X_ABLATE == 1           // diagnostics build only (tools/k4x_ablate.sh): no DB loads
+    return uint4{r * 2654435761u, r ^ step, r + h, r * 40503u};
+#else
     return *reinterpret_cast<const uint4*>(db + (size_t)r * kWords + 4u * h);
+#endif
   };
   Fp4Row a0, a1;
   {
