@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import numpy as np, torch
 from tod_amd import capi, synth
 desc, pts, off = synth.make_db(200)
-B, nq, k, radius = 16, 1000, 2, 35
+B, nq, k, radius = int(os.environ.get("B", "32")), 1000, 2, 35
 frames = [synth.make_frame(desc, pts, off, nq, frame=f % 8, visible_object=(17 * (f % 8) + 3) % 200)["q_desc"] for f in range(8)]
 for world in (1, 2, 4, 8):
     ctx = capi.Context(0)
