@@ -42,6 +42,8 @@ namespace {
 constexpr uint32_t kMaxSlots = 16;                         // 16 x 200 B of EvalArgs stays under the 4 KB kernarg limit
 constexpr uint32_t kManySlots = 36;                        // kernels with ~110 B of arguments per slot (4 KB of kernarg in all)
 template <class A, uint32_t N = kMaxSlots> struct Slots { A a[N]; };
+// the same argument sets in device memory (lists of thousands of objects: launch_many)
+template <class A> struct SlotsPtr { const A* a; };
 
 struct AdjArgs { ObjJob job; float span, err; };
 struct JobArgs { ObjJob job; };
@@ -70,7 +72,8 @@ inline double dbg_us() {
 #define TOD_DBG(...) do { if (tod_debug()) { fprintf(stderr, "[todhip %.0f] ", dbg_us()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 // ------------------------------------------------------------------------------------------------ K6
-__global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs, kManySlots> S) {
+template <class H>
+__global__ __launch_bounds__(256) void adjacency_kernel(H S) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.z].job;
   const float span = S.a[blockIdx.z].span, err = S.a[blockIdx.z].err;
@@ -106,7 +109,8 @@ __global__ __launch_bounds__(256) void adjacency_kernel(Slots<AdjArgs, kManySlot
   }
 }
 
-__global__ __launch_bounds__(256) void finite_kernel(Slots<JobArgs, kManySlots> S) {
+template <class H>
+__global__ __launch_bounds__(256) void finite_kernel(H S) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.y].job;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
@@ -132,7 +136,8 @@ __global__ __launch_bounds__(256) void finite_kernel(Slots<JobArgs, kManySlots> 
 // its own third level is empty, so it returns before drawing), i.e. every edge is paid for exactly once, at whichever
 // endpoint is picked first. A triangle-free object therefore advances the stream by exactly 1000 (|valid| + |E|) draws
 // (getSamples' 1000 attempts, :141-168) and yields nothing: the host skips its draw table and chain walk altogether.
-__global__ __launch_bounds__(256) void round_prep_kernel(Slots<PrepArgs, kManySlots> S) {
+template <class H>
+__global__ __launch_bounds__(256) void round_prep_kernel(H S) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = S.a[blockIdx.y].job;
   uint32_t* const stats = S.a[blockIdx.y].stats;
@@ -1769,6 +1774,7 @@ struct StreamCache;
 struct VerifyPool {
   std::vector<VerifyWs*> slots; std::vector<StreamCache*> streams;
   std::vector<hipEvent_t> side_ev;                          // one per flight of a batch (Engine::run_ticks), created on first use
+  HostBuf args_stage; DevBuf args_dev;                      // argument sets of a tick's long lists (launch_many)
 };
 // The flights' streams belong to the process, not to a context: a process has eight hardware queues for all of its streams
 // (DESIGN 7), the runtime deals streams onto them round robin, and every further stream -- busy or not -- makes it likelier that two
@@ -2433,6 +2439,40 @@ struct Engine {
     return std::min(kEvalLdsSmall, std::max(8192u, (want + 1023u) & ~1023u));
   }
 
+  // A list of thousands of argument sets (the all-objects preparation tick of a batch: ~190 objects per frame): the sets go to
+  // device memory in one copy, ordered by size class so that a launch's grid -- the extent of its largest member times the
+  // count -- stays tight, and each class is ONE launch (252 launches of <= 36 sets each became 3-4 per kernel). `used` = bytes
+  // of the staging area already taken in this tick.
+  template <class A, class KernP, class Extent>
+  bool launch_many(hipStream_t st, KernP kern, const std::vector<A>& v, int slot_dim, Extent extent, size_t& used) {
+    VerifyPool* pool = pool_of(ctx);
+    const size_t bytes = v.size() * sizeof(A);
+    used = (used + 255u) & ~(size_t)255u;
+    if (used + bytes > pool->args_stage.cap || used + bytes > pool->args_dev.cap) return false;
+    static const uint32_t kClass[] = {16u, 64u, 256u, 0xFFFFFFFFu};
+    A* host = reinterpret_cast<A*>(reinterpret_cast<unsigned char*>(pool->args_stage.p) + used);
+    const A* dev = reinterpret_cast<const A*>(reinterpret_cast<const unsigned char*>(pool->args_dev.p) + used);
+    size_t n_cls[4] = {0, 0, 0, 0}, at = 0;
+    auto cls_of = [&](const A& a) { uint32_t c = 0; while (a.job.n > kClass[c]) ++c; return c; };
+    for (const A& a : v) ++n_cls[cls_of(a)];
+    size_t start[4], fill[4];
+    for (int c = 0; c < 4; ++c) { start[c] = fill[c] = at; at += n_cls[c]; }
+    for (const A& a : v) host[fill[cls_of(a)]++] = a;
+    if (hipMemcpyAsync(const_cast<A*>(dev), host, bytes, hipMemcpyHostToDevice, st) != hipSuccess) return false;
+    used += bytes;
+    for (int c = 0; c < 4; ++c) {
+      for (size_t i0 = 0; i0 < n_cls[c]; i0 += 32768u) {    // (grid z / y limit)
+        const uint32_t n = (uint32_t)std::min<size_t>(32768u, n_cls[c] - i0);
+        uint32_t gx = 1, gy = 1;
+        for (uint32_t i = 0; i < n; ++i) { const dim3 e = extent(host[start[c] + i0 + i]); gx = std::max(gx, e.x); gy = std::max(gy, e.y); }
+        const dim3 grid = slot_dim == 1 ? dim3(gx, n) : dim3(gx, gy, n);
+        SlotsPtr<A> S = {dev + start[c] + i0};
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, S);
+      }
+    }
+    return true;
+  }
+
   void launch_all(hipStream_t st) {
     auto words = [](const CopyArgs& a) { return dim3(std::max(1u, std::min(64u, (a.n + 255u) / 256u))); };
     L.copy_in.insert(L.copy_in.end(), L.zero.begin(), L.zero.end());   // both precede every other kernel of the tick: one launch
@@ -2443,9 +2483,23 @@ struct Engine {
                 [](const ScatterArgs& a) { return dim3((uint32_t)(((size_t)a.nq * a.k + 255u) / 256u)); });
     launch_list(st, cluster_group_kernel, L.group, 256, 0, 1, [](const GroupArgs& a) { return dim3((a.n_all + 255u) / 256u); });
     launch_list(st, invalidate_kernel, L.inval, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
-    launch_list<kManySlots>(st, finite_kernel, L.finite, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
-    launch_list<kManySlots>(st, adjacency_kernel, L.adj, 256, 0, 2, [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
-    launch_list<kManySlots>(st, round_prep_kernel, L.prep, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+    {
+      auto ext_rows = [](const auto& a) { return dim3((a.job.n + 255u) / 256u); };
+      auto ext_adj = [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); };
+      bool many = L.adj.size() > 4u * kManySlots;
+      if (many) {
+        VerifyPool* pool = pool_of(ctx);
+        const size_t need = L.finite.size() * sizeof(JobArgs) + L.adj.size() * sizeof(AdjArgs) + L.prep.size() * sizeof(PrepArgs) + 1024u;
+        many = pool->args_stage.reserve(need) == hipSuccess && pool->args_dev.reserve(need) == hipSuccess;
+      }
+      size_t used = 0;
+      if (!many || !launch_many(st, finite_kernel<SlotsPtr<JobArgs>>, L.finite, 1, ext_rows, used))
+        launch_list<kManySlots>(st, finite_kernel<Slots<JobArgs, kManySlots>>, L.finite, 256, 0, 1, ext_rows);
+      if (!many || !launch_many(st, adjacency_kernel<SlotsPtr<AdjArgs>>, L.adj, 2, ext_adj, used))
+        launch_list<kManySlots>(st, adjacency_kernel<Slots<AdjArgs, kManySlots>>, L.adj, 256, 0, 2, ext_adj);
+      if (!many || !launch_many(st, round_prep_kernel<SlotsPtr<PrepArgs>>, L.prep, 1, ext_rows, used))
+        launch_list<kManySlots>(st, round_prep_kernel<Slots<PrepArgs, kManySlots>>, L.prep, 256, 0, 1, ext_rows);
+    }
     for (size_t i = 0; i < L.draw.size(); ++i) L.draw[i].rnd = L.draw_src[i].first->dev.as<uint32_t>() + L.draw_src[i].second;
     for (size_t i = 0; i < L.draw_small.size(); ++i)
       L.draw_small[i].rnd = L.draw_small_src[i].first->dev.as<uint32_t>() + L.draw_small_src[i].second;
@@ -2482,7 +2536,7 @@ struct Engine {
     }
     launch_list(st, growth_kernel, L.growth, 256, 0, 0, [](const GrowthArgs&) { return dim3(1); });
     launch_list(st, invalidate_kernel, L.inval_after, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
-    launch_list<kManySlots>(st, round_prep_kernel, L.prep_after, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+    launch_list<kManySlots>(st, round_prep_kernel<Slots<PrepArgs, kManySlots>>, L.prep_after, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
     launch_list(st, copy_words_kernel, L.copy_out, 256, 0, 1, words);
     L = Launches();
   }
@@ -2666,6 +2720,7 @@ void tod_verify_ws_free(todhip_ctx* ctx) {
   for (VerifyWs* ws : p->slots) { ws->release(); delete ws; }
   for (StreamCache* c : p->streams) { c->dev.release(); delete c; }
   for (hipEvent_t e : p->side_ev) (void)hipEventDestroy(e);
+  p->args_stage.release(); p->args_dev.release();
   delete p;
   ctx->verify_ws = nullptr;
 }
@@ -2902,7 +2957,7 @@ int todhip_test_adjacency(todhip_ctx* ctx, const float* train, const float* quer
   job.n = n; job.W = W;
   job.train = ws->train.as<float>(); job.query = ws->query.as<float>(); job.kpxy = ws->kpxy.as<float>();
   job.phys = ws->phys.as<u64>(); job.samp = ws->samp.as<u64>();
-  launch_list<kManySlots>(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
+  launch_list<kManySlots>(st, adjacency_kernel<Slots<AdjArgs, kManySlots>>, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
               [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
   TOD_HIP(hipGetLastError());
   TOD_HIP(hipMemcpyAsync(phys, ws->phys.p, (size_t)n * W * 8, hipMemcpyDeviceToHost, st));
@@ -2949,10 +3004,10 @@ int todhip_test_consensus(todhip_ctx* ctx, const float* train, const float* quer
   uint32_t* d_small = ws->small.as<uint32_t>();
   uint32_t* h_small = ws->h_small.as<uint32_t>();
   TOD_HIP(hipMemsetAsync(d_small, 0, 64 * sizeof(uint32_t), st));
-  launch_list<kManySlots>(st, finite_kernel, std::vector<JobArgs>{{job}}, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
-  launch_list<kManySlots>(st, adjacency_kernel, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
+  launch_list<kManySlots>(st, finite_kernel<Slots<JobArgs, kManySlots>>, std::vector<JobArgs>{{job}}, 256, 0, 1, [](const JobArgs& a) { return dim3((a.job.n + 255u) / 256u); });
+  launch_list<kManySlots>(st, adjacency_kernel<Slots<AdjArgs, kManySlots>>, std::vector<AdjArgs>{{job, span, err}}, 256, 0, 2,
               [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); });
-  launch_list<kManySlots>(st, round_prep_kernel, std::vector<PrepArgs>{{job, d_small + 5, nullptr, 0u}}, 256, 0, 1,
+  launch_list<kManySlots>(st, round_prep_kernel<Slots<PrepArgs, kManySlots>>, std::vector<PrepArgs>{{job, d_small + 5, nullptr, 0u}}, 256, 0, 1,
               [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
   EvalArgs A;
   A.job = job; A.iter_samples = ws->iter_samples.as<uint32_t>(); A.it_begin = 0; A.it_end = n_triples;
