@@ -59,7 +59,9 @@ struct CopyArgs { const uint32_t* src; uint32_t* dst; uint32_t n; };   // src ==
 
 // words from one address space to another (device <-> device-visible pinned host memory) or zero fill: the
 // host's mailbox traffic rides in kernels, so a tick of the batch engine is launches + ONE stream synchronize
-__global__ __launch_bounds__(256) void copy_words_kernel(Slots<CopyArgs> S) {
+constexpr uint32_t kWideSlots = 32;                        // argument sets of <= 124 B: a 32-frame batch's tick in one launch
+constexpr uint32_t kCopySlots = 160;                       // 24 B per copy: a tick's copies of 16 frames in one launch
+__global__ __launch_bounds__(256) void copy_words_kernel(Slots<CopyArgs, kCopySlots> S) {
   const CopyArgs& a = S.a[blockIdx.y];
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += gridDim.x * 256u) a.dst[i] = a.src ? a.src[i] : 0u;
 }
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void round_prep_kernel(H S) {
 }
 
 // ------------------------------------------------------------------------------------------------ K7a
-__global__ __launch_bounds__(256) void draw_table_kernel(Slots<DrawArgs> SL) {
+__global__ __launch_bounds__(256) void draw_table_kernel(Slots<DrawArgs, kWideSlots> SL) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = SL.a[blockIdx.y].job;
   const uint32_t* __restrict__ rnd = SL.a[blockIdx.y].rnd;
@@ -244,7 +246,7 @@ __device__ __forceinline__ uint32_t nth_set_bit128(u64 w0, u64 w1, uint32_t n) {
   }
   return base + pos;
 }
-__global__ __launch_bounds__(256) void draw_table_small_kernel(Slots<DrawArgs> SL) {
+__global__ __launch_bounds__(256) void draw_table_small_kernel(Slots<DrawArgs, kWideSlots> SL) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = SL.a[blockIdx.y].job;
   const uint32_t* __restrict__ rnd = SL.a[blockIdx.y].rnd;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void draw_table_small_kernel(Slots<DrawArgs> S
 // started, and all threads then fetch those attempts' triples.
 constexpr uint32_t kChainLdsEntries = 36u * 1024u;       // 144 KB of packed (consumed << 2 | status) words
 constexpr uint32_t kChainMaxReq = 4096u;                  // == kMaxEvalWaves
-__global__ __launch_bounds__(256) void chain_kernel(Slots<ChainArgs> SL) {
+__global__ __launch_bounds__(256) void chain_kernel(Slots<ChainArgs, kWideSlots> SL) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   extern __shared__ __align__(16) unsigned char lds_raw[];
   uint32_t* s_hop = reinterpret_cast<uint32_t*>(lds_raw);                       // min(S, kChainLdsEntries)
@@ -1591,7 +1593,7 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
 struct InvArgs { ObjJob job; const u64* kp_bits; u64* scratch; const uint32_t* gate; uint32_t gate_min; };   // gate: as PrepArgs
 // 256 threads (one wave per SIMD): a block this size still finds wave slots on a CU whose other slots are held by the
 // matcher's resident grid; a 1024-thread block had to wait for a whole matcher launch to end (1.4 ms on average)
-__global__ __launch_bounds__(256) void invalidate_kernel(Slots<InvArgs> SL) {
+__global__ __launch_bounds__(256) void invalidate_kernel(Slots<InvArgs, kWideSlots> SL) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const ObjJob& job = SL.a[blockIdx.x].job;
   const u64* const kp_bits = SL.a[blockIdx.x].kp_bits; u64* const scratch = SL.a[blockIdx.x].scratch;
@@ -2476,13 +2478,13 @@ struct Engine {
   void launch_all(hipStream_t st) {
     auto words = [](const CopyArgs& a) { return dim3(std::max(1u, std::min(64u, (a.n + 255u) / 256u))); };
     L.copy_in.insert(L.copy_in.end(), L.zero.begin(), L.zero.end());   // both precede every other kernel of the tick: one launch
-    launch_list(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
+    launch_list<kCopySlots>(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
     launch_list(st, cluster_lookup_kernel, L.lookup, 256, 0, 1, [](const LookupArgs& a) { return dim3((a.nq + 255u) / 256u); });
     launch_list(st, cluster_scan_kernel, L.scan, 256, 0, 0, [](const ScanArgs&) { return dim3(1); });
     launch_list(st, cluster_scatter_kernel, L.scatter, 256, 0, 1,
                 [](const ScatterArgs& a) { return dim3((uint32_t)(((size_t)a.nq * a.k + 255u) / 256u)); });
     launch_list(st, cluster_group_kernel, L.group, 256, 0, 1, [](const GroupArgs& a) { return dim3((a.n_all + 255u) / 256u); });
-    launch_list(st, invalidate_kernel, L.inval, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
+    launch_list<kWideSlots>(st, invalidate_kernel, L.inval, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
     {
       auto ext_rows = [](const auto& a) { return dim3((a.job.n + 255u) / 256u); };
       auto ext_adj = [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); };
@@ -2503,13 +2505,13 @@ struct Engine {
     for (size_t i = 0; i < L.draw.size(); ++i) L.draw[i].rnd = L.draw_src[i].first->dev.as<uint32_t>() + L.draw_src[i].second;
     for (size_t i = 0; i < L.draw_small.size(); ++i)
       L.draw_small[i].rnd = L.draw_small_src[i].first->dev.as<uint32_t>() + L.draw_small_src[i].second;
-    launch_list(st, draw_table_kernel, L.draw, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 3u) / 4u); });
-    launch_list(st, draw_table_small_kernel, L.draw_small, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 255u) / 256u); });
+    launch_list<kWideSlots>(st, draw_table_kernel, L.draw, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 3u) / 4u); });
+    launch_list<kWideSlots>(st, draw_table_small_kernel, L.draw_small, 256, 0, 1, [](const DrawArgs& a) { return dim3((a.S + 255u) / 256u); });
     {
       // dynamic LDS: the packed hop words of the largest window of the launch + the per-iteration start positions
       uint32_t lds = 0;
       for (const ChainArgs& c : L.chain) lds = std::max(lds, (std::min(c.S, kChainLdsEntries) + std::min(c.n_req, kChainMaxReq)) * 4u);
-      launch_list(st, chain_kernel, L.chain, 256, lds, 0, [](const ChainArgs&) { return dim3(1); });
+      launch_list<kWideSlots>(st, chain_kernel, L.chain, 256, lds, 0, [](const ChainArgs&) { return dim3(1); });
     }
     {
       // one dynamic LDS size per launch: the largest any slot of the launch wants; every slot carves that much
@@ -2535,9 +2537,9 @@ struct Engine {
       launch_list(st, eval_kernel<true>, wide, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
     }
     launch_list(st, growth_kernel, L.growth, 256, 0, 0, [](const GrowthArgs&) { return dim3(1); });
-    launch_list(st, invalidate_kernel, L.inval_after, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
+    launch_list<kWideSlots>(st, invalidate_kernel, L.inval_after, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
     launch_list<kManySlots>(st, round_prep_kernel<Slots<PrepArgs, kManySlots>>, L.prep_after, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
-    launch_list(st, copy_words_kernel, L.copy_out, 256, 0, 1, words);
+    launch_list<kCopySlots>(st, copy_words_kernel, L.copy_out, 256, 0, 1, words);
     L = Launches();
   }
 
