@@ -311,20 +311,28 @@ __global__ __launch_bounds__(256) void chain_kernel(Slots<ChainArgs, kWideSlots>
   __shared__ uint32_t s_done;
   for (uint32_t i = threadIdx.x; i < n_lds; i += 256u) s_hop[i] = (table[i].consumed << 2) | table[i].status;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t p = 0, done = 0, attempts = attempts0, flag = 0;
+  if (threadIdx.x < 64u) {
+    // Wave 0 walks, with wave-uniform control flow: the hop words of 64 consecutive positions sit in one register (lane i = position
+    // base + i) and a hop inside the window is a v_readlane -- an attempt consumes a handful of draws, so a window serves ~10 hops
+    // and the dependent LDS round trip (~100 cycles, what a hop cost before) is paid once per window.
+    const uint32_t lane = threadIdx.x;
+    uint32_t p = 0, done = 0, attempts = attempts0, flag = 0, base = 0xFFFFFF00u, win = 0;
     while (done < n_req) {
       bool got = false;
       while (true) {
         if (p >= S) { flag = 1; break; }
-        const uint32_t hop = p < n_lds ? s_hop[p] : ((table[p].consumed << 2) | table[p].status);
+        if (p - base >= 64u) {                              // wave-uniform (also true on the first pass: base is far above)
+          base = p;
+          const uint32_t idx = base + lane;
+          win = idx < n_lds ? s_hop[idx] : (idx < S ? ((table[idx].consumed << 2) | table[idx].status) : 0u);
+        }
+        const uint32_t hop = (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(p - base));
         const uint32_t status = hop & 3u;
         if (status == DRAW_OVERFLOW) { flag = 1; break; }
         const uint32_t at = p;
-        p += hop >> 2;
+        p = uni(p + (hop >> 2));
         if (status == DRAW_OK) {
-          s_start[done] = at;
-          iter_pos_after[out_base + done] = p;
+          if (lane == 0) { s_start[done] = at; iter_pos_after[out_base + done] = p; }
           got = true;
           break;
         }
@@ -334,8 +342,10 @@ __global__ __launch_bounds__(256) void chain_kernel(Slots<ChainArgs, kWideSlots>
       attempts = 0;
       ++done;
     }
-    out->n_done = done; out->pos_end = p; out->attempts = attempts; out->flag = flag;
-    s_done = done;
+    if (lane == 0) {
+      out->n_done = done; out->pos_end = p; out->attempts = attempts; out->flag = flag;
+      s_done = done;
+    }
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < s_done; i += 256u) {
