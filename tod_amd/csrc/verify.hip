@@ -1197,8 +1197,8 @@ __device__ __forceinline__ int32_t gate_eval(const EvalArgs& A, const WaveBits& 
 // launched with 64 threads; the bound is deliberately larger so that hipcc keeps __syncthreads() as a real,
 // convergent s_barrier (with a 64-thread bound it drops the barrier and may split the lanes of the wave)
 // kWide = false: objects of up to 512 matches (job.W <= 8), the launch's every slot; true: any size
-template <bool kWide>
-__global__ __launch_bounds__(128) void eval_kernel(Slots<EvalArgs> SL) {
+template <bool kWide, class H = Slots<EvalArgs>>
+__global__ __launch_bounds__(128) void eval_kernel(H SL) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const EvalArgs& A = SL.a[blockIdx.y];
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1904,6 +1904,10 @@ int set_big_lds_once(todhip_ctx* ctx) {
                                 (int)kEvalLdsBig));
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kEvalLdsBig));
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_kernel<false, SlotsPtr<EvalArgs>>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eval_kernel<true, SlotsPtr<EvalArgs>>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clique_test_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(clique_test_kernel<true>),
@@ -2456,12 +2460,14 @@ struct Engine {
   // count -- stays tight, and each class is ONE launch (252 launches of <= 36 sets each became 3-4 per kernel). `used` = bytes
   // of the staging area already taken in this tick.
   template <class A, class KernP, class Extent>
-  bool launch_many(hipStream_t st, KernP kern, const std::vector<A>& v, int slot_dim, Extent extent, size_t& used) {
+  bool launch_many(hipStream_t st, KernP kern, const std::vector<A>& v, int slot_dim, Extent extent, size_t& used, uint32_t block = 256u,
+                   uint32_t lds = 0u, bool by_class = true) {
     VerifyPool* pool = pool_of(ctx);
     const size_t bytes = v.size() * sizeof(A);
     used = (used + 255u) & ~(size_t)255u;
     if (used + bytes > pool->args_stage.cap || used + bytes > pool->args_dev.cap) return false;
-    static const uint32_t kClass[] = {16u, 64u, 256u, 0xFFFFFFFFu};
+    static const uint32_t kClassBy[] = {16u, 64u, 256u, 0xFFFFFFFFu}, kClassOne[] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const uint32_t* kClass = by_class ? kClassBy : kClassOne;
     A* host = reinterpret_cast<A*>(reinterpret_cast<unsigned char*>(pool->args_stage.p) + used);
     const A* dev = reinterpret_cast<const A*>(reinterpret_cast<const unsigned char*>(pool->args_dev.p) + used);
     size_t n_cls[4] = {0, 0, 0, 0}, at = 0;
@@ -2479,13 +2485,39 @@ struct Engine {
         for (uint32_t i = 0; i < n; ++i) { const dim3 e = extent(host[start[c] + i0 + i]); gx = std::max(gx, e.x); gy = std::max(gy, e.y); }
         const dim3 grid = slot_dim == 1 ? dim3(gx, n) : dim3(gx, gy, n);
         SlotsPtr<A> S = {dev + start[c] + i0};
-        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, S);
+        hipLaunchKernelGGL(kern, grid, dim3(block), lds, st, S);
       }
     }
     return true;
   }
 
   void launch_all(hipStream_t st) {
+    // the staging area for argument sets in device memory (launch_many) is sized once per tick, before anything reads it
+    size_t used = 0;
+    bool stage_ok = false;
+    {
+      const size_t n_eval = L.eval_small.size() + L.eval_direct.size() + L.eval_big.size();
+      if (L.adj.size() > 4u * kManySlots || n_eval > kMaxSlots) {
+        VerifyPool* pool = pool_of(ctx);
+        const size_t need = L.finite.size() * sizeof(JobArgs) + L.adj.size() * sizeof(AdjArgs) + L.prep.size() * sizeof(PrepArgs) +
+                            n_eval * sizeof(EvalArgs) + 4096u;
+        stage_ok = pool->args_stage.reserve(need) == hipSuccess && pool->args_dev.reserve(need) == hipSuccess;
+      }
+    }
+    // more hypothesis evaluations than fit one launch's arguments (a batch of more than 16 frames): one launch all the same
+    auto launch_evals = [&](const std::vector<EvalArgs>& v, bool wide, uint32_t lds, bool deferred) {
+      auto ext_it = [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); };
+      auto ext_def = [](const EvalArgs& a) { return dim3(a.n_deferred); };
+      if (v.size() > kMaxSlots && stage_ok) {
+        const bool ok = wide ? (deferred ? launch_many(st, eval_kernel<true, SlotsPtr<EvalArgs>>, v, 1, ext_def, used, 64u, lds, false)
+                                         : launch_many(st, eval_kernel<true, SlotsPtr<EvalArgs>>, v, 1, ext_it, used, 64u, lds, false))
+                             : (deferred ? launch_many(st, eval_kernel<false, SlotsPtr<EvalArgs>>, v, 1, ext_def, used, 64u, lds, false)
+                                         : launch_many(st, eval_kernel<false, SlotsPtr<EvalArgs>>, v, 1, ext_it, used, 64u, lds, false));
+        if (ok) return;
+      }
+      if (wide) { if (deferred) launch_list(st, eval_kernel<true>, v, 64, lds, 1, ext_def); else launch_list(st, eval_kernel<true>, v, 64, lds, 1, ext_it); }
+      else { if (deferred) launch_list(st, eval_kernel<false>, v, 64, lds, 1, ext_def); else launch_list(st, eval_kernel<false>, v, 64, lds, 1, ext_it); }
+    };
     auto words = [](const CopyArgs& a) { return dim3(std::max(1u, std::min(64u, (a.n + 255u) / 256u))); };
     L.copy_in.insert(L.copy_in.end(), L.zero.begin(), L.zero.end());   // both precede every other kernel of the tick: one launch
     launch_list<kCopySlots>(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
@@ -2499,12 +2531,7 @@ struct Engine {
       auto ext_rows = [](const auto& a) { return dim3((a.job.n + 255u) / 256u); };
       auto ext_adj = [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); };
       bool many = L.adj.size() > 4u * kManySlots;
-      if (many) {
-        VerifyPool* pool = pool_of(ctx);
-        const size_t need = L.finite.size() * sizeof(JobArgs) + L.adj.size() * sizeof(AdjArgs) + L.prep.size() * sizeof(PrepArgs) + 1024u;
-        many = pool->args_stage.reserve(need) == hipSuccess && pool->args_dev.reserve(need) == hipSuccess;
-      }
-      size_t used = 0;
+      if (many) many = stage_ok;
       if (!many || !launch_many(st, finite_kernel<SlotsPtr<JobArgs>>, L.finite, 1, ext_rows, used))
         launch_list<kManySlots>(st, finite_kernel<Slots<JobArgs, kManySlots>>, L.finite, 256, 0, 1, ext_rows);
       if (!many || !launch_many(st, adjacency_kernel<SlotsPtr<AdjArgs>>, L.adj, 2, ext_adj, used))
@@ -2531,20 +2558,20 @@ struct Engine {
       // objects of more than 512 matches go to the kernel's wide instantiation (their own launch)
       std::vector<EvalArgs> narrow, wide;
       for (const EvalArgs& a : L.eval_small) (a.job.W <= 8u ? narrow : wide).push_back(a);
-      launch_list(st, eval_kernel<false>, narrow, 64, lds, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
-      launch_list(st, eval_kernel<true>, wide, 64, lds, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+      launch_evals(narrow, false, lds, false);
+      launch_evals(wide, true, lds, false);
     }
     {
       std::vector<EvalArgs> narrow, wide;
       for (const EvalArgs& a : L.eval_direct) (a.job.W <= 8u ? narrow : wide).push_back(a);
-      launch_list(st, eval_kernel<false>, narrow, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
-      launch_list(st, eval_kernel<true>, wide, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.it_end - a.it_begin); });
+      launch_evals(narrow, false, kEvalLdsBig, false);
+      launch_evals(wide, true, kEvalLdsBig, false);
     }
     {
       std::vector<EvalArgs> narrow, wide;
       for (const EvalArgs& a : L.eval_big) (a.job.W <= 8u ? narrow : wide).push_back(a);
-      launch_list(st, eval_kernel<false>, narrow, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
-      launch_list(st, eval_kernel<true>, wide, 64, kEvalLdsBig, 1, [](const EvalArgs& a) { return dim3(a.n_deferred); });
+      launch_evals(narrow, false, kEvalLdsBig, true);
+      launch_evals(wide, true, kEvalLdsBig, true);
     }
     launch_list(st, growth_kernel, L.growth, 256, 0, 0, [](const GrowthArgs&) { return dim3(1); });
     launch_list<kWideSlots>(st, invalidate_kernel, L.inval_after, 256, 0, 0, [](const InvArgs&) { return dim3(1); });

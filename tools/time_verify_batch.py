@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import numpy as np, torch
 from tod_amd import capi, synth
 desc, pts, off = synth.make_db(200)
-B, nq, k = 16, 1000, 2
+B, nq, k = int(os.environ.get("B", "16")), 1000, 2
 frames = [synth.make_frame(desc, pts, off, nq, frame=f % 8, visible_object=(17 * (f % 8) + 3) % 200) for f in range(B)]
 main = capi.Context(0)
 spans = main.db_load(desc, pts, off)
@@ -34,4 +34,4 @@ for with_matcher in (False, True):
     dt = (time.perf_counter() - t0) / n
     stop[0] = True
     if with_matcher: t.join()
-    print("verify_batch_device, 16 frames, matcher running=%s: %.3f ms per batch (%d poses)" % (with_matcher, dt * 1e3, sum(len(x) for x in p)), flush=True)
+    print("verify_batch_device, %d frames, matcher running=%s: %.3f ms per batch (%d poses)" % (B, with_matcher, dt * 1e3, sum(len(x) for x in p)), flush=True)
