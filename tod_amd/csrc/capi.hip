@@ -259,14 +259,13 @@ int todhip_match(todhip_ctx* ctx, const uint8_t* q_desc, uint32_t nq, uint32_t k
   const size_t stage_bytes = (size_t)nq * sizeof(uint32_t) + nm * sizeof(todhip_dmatch) + nm * 3 * sizeof(float);
   TOD_HIP(ctx->h_stage.reserve(stage_bytes));
   TOD_HIP(hipMemcpyAsync(ctx->m_q.p, q_desc, (size_t)nq * ctx->desc_bytes, hipMemcpyHostToDevice, ctx->stream));
-  int rc = todhip_match_device(ctx, ctx->m_q.p, nq, k, radius, ctx->m_counts.p, ctx->m_matches.p, ctx->m_xyz.p);
-  if (rc != TODHIP_OK) return rc;
+  // the finalize kernel writes its three outputs straight into pinned host memory (a few tens of KB over PCIe): no device-to-host
+  // copies behind it, one synchronization
   uint32_t* h_counts = ctx->h_stage.as<uint32_t>();
   todhip_dmatch* h_m = reinterpret_cast<todhip_dmatch*>(h_counts + nq);
   float* h_xyz = reinterpret_cast<float*>(h_m + nm);
-  TOD_HIP(hipMemcpyAsync(h_counts, ctx->m_counts.p, (size_t)nq * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  TOD_HIP(hipMemcpyAsync(h_m, ctx->m_matches.p, nm * sizeof(todhip_dmatch), hipMemcpyDeviceToHost, ctx->stream));
-  TOD_HIP(hipMemcpyAsync(h_xyz, ctx->m_xyz.p, nm * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  int rc = todhip_match_device(ctx, ctx->m_q.p, nq, k, radius, h_counts, h_m, h_xyz);
+  if (rc != TODHIP_OK) return rc;
   TOD_HIP(hipStreamSynchronize(ctx->stream));
   // fixed stride k -> CSR (the cell's vector<vector<DMatch>> / vector<Mat> shapes)
   uint32_t out = 0;

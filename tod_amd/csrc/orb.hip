@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void copy_out_kernel(const uint32_t* __restric
 
 struct OrbWs {
   DevBuf pyr, blur, tmp, score, cand, eq, sel1, sel2, small, pattern, in_img, kp_xy, kp_aux, desc, o_xy, o_aux, o_desc, maskbuf;
-  HostBuf h_out;
+  HostBuf h_out, h_kp;                                     // h_kp: the host form's keypoints, written by copy_out_kernel itself
   bool pattern_is_default = false;
   // the per-frame launch sequence is static for a given geometry: captured once per context, replayed. It reads
   // and writes workspace buffers only (image and mask are copied in, keypoints copied out), so the caller's
@@ -624,7 +624,7 @@ void tod_orb_ws_free(todhip_ctx* ctx) {
   for (DevBuf* b : bufs) b->release();
   if (ws->graph_exec) (void)hipGraphExecDestroy(ws->graph_exec);
   if (ws->graph) (void)hipGraphDestroy(ws->graph);
-  ws->h_out.release();
+  ws->h_out.release(); ws->h_kp.release();
   delete ws;
   ctx->orb_ws = nullptr;
 }
@@ -666,7 +666,11 @@ int todhip_orb_masked(todhip_ctx* ctx, const uint8_t* gray, const uint8_t* mask,
   if (cap == 0) return TODHIP_ECAPACITY;
   const size_t img_bytes = (size_t)H * stride;
   TOD_HIP(ws->in_img.reserve(mask ? 2 * img_bytes : img_bytes));       // the mask rides behind the image
-  TOD_HIP(ws->kp_xy.reserve((size_t)cap * 8)); TOD_HIP(ws->kp_aux.reserve((size_t)cap * 16)); TOD_HIP(ws->desc.reserve((size_t)cap * 32));
+  // the outputs land in pinned host memory, written by the last kernel itself (56 B per keypoint over PCIe): no device-to-host
+  // copies and no second synchronization behind orb_device's own
+  TOD_HIP(ws->h_kp.reserve((size_t)cap * 56 + 64));
+  float* const p_xy = ws->h_kp.as<float>(); float* const p_aux = p_xy + (size_t)cap * 2;
+  uint8_t* const p_desc = reinterpret_cast<uint8_t*>(p_aux + (size_t)cap * 4);
   TOD_HIP(hipMemcpyAsync(ws->in_img.p, gray, img_bytes, hipMemcpyHostToDevice, ctx->stream));
   const uint8_t* d_mask = nullptr;
   if (mask) {
@@ -677,13 +681,10 @@ int todhip_orb_masked(todhip_ctx* ctx, const uint8_t* gray, const uint8_t* mask,
   }
   uint32_t n = 0;
   const int rc = orb_device(ctx, ws->in_img.as<uint8_t>(), 0, d_mask, 1, H, W, stride, n_features, n_levels, scale_factor, pattern,
-                            ws->kp_xy.as<float>(), ws->kp_aux.as<float>(), ws->desc.as<uint8_t>(), cap, &n);
+                            p_xy, p_aux, p_desc, cap, &n);           // (synchronizes the stream before it returns)
   if (rc != TODHIP_OK) return rc;
   if (n) {
-    TOD_HIP(hipMemcpyAsync(kp_xy, ws->kp_xy.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    TOD_HIP(hipMemcpyAsync(kp_aux, ws->kp_aux.p, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
-    TOD_HIP(hipMemcpyAsync(desc, ws->desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    TOD_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(kp_xy, p_xy, (size_t)n * 8); std::memcpy(kp_aux, p_aux, (size_t)n * 16); std::memcpy(desc, p_desc, (size_t)n * 32);
   }
   *n_out = n;
   return TODHIP_OK;
