@@ -2858,16 +2858,24 @@ int todhip_verify(todhip_ctx* ctx, const float* kp_xy, uint32_t nq, const float*
   if (total == 0) return TODHIP_OK;
   TOD_HIP(ws->train.reserve((size_t)total * 12)); TOD_HIP(ws->query.reserve((size_t)total * 12));
   TOD_HIP(ws->qidx.reserve((size_t)total * 4)); TOD_HIP(ws->kpxy.reserve((size_t)total * 8));
+  // the objects' slices are contiguous on the device (object order): four uploads for the frame, not four per object (a frame of
+  // self-similar texture spreads its matches over a couple of hundred objects)
+  std::vector<float> h_train((size_t)total * 3), h_query((size_t)total * 3), h_kpxy((size_t)total * 2);
+  std::vector<uint32_t> h_qidx(total);
   size_t i = 0;
   for (auto& kv : objects) {
     HostCluster& c = kv.second;
     const ObjSpan& o = s.objs[i++];
     if (o.n == 0) continue;
-    TOD_HIP(hipMemcpyAsync(ws->train.as<float>() + 3 * (size_t)o.offset, c.train.data(), (size_t)o.n * 12, hipMemcpyHostToDevice, st));
-    TOD_HIP(hipMemcpyAsync(ws->query.as<float>() + 3 * (size_t)o.offset, c.query.data(), (size_t)o.n * 12, hipMemcpyHostToDevice, st));
-    TOD_HIP(hipMemcpyAsync(ws->qidx.as<uint32_t>() + o.offset, c.qidx.data(), (size_t)o.n * 4, hipMemcpyHostToDevice, st));
-    TOD_HIP(hipMemcpyAsync(ws->kpxy.as<float>() + 2 * (size_t)o.offset, c.kpxy.data(), (size_t)o.n * 8, hipMemcpyHostToDevice, st));
+    std::memcpy(h_train.data() + 3 * (size_t)o.offset, c.train.data(), (size_t)o.n * 12);
+    std::memcpy(h_query.data() + 3 * (size_t)o.offset, c.query.data(), (size_t)o.n * 12);
+    std::memcpy(h_qidx.data() + o.offset, c.qidx.data(), (size_t)o.n * 4);
+    std::memcpy(h_kpxy.data() + 2 * (size_t)o.offset, c.kpxy.data(), (size_t)o.n * 8);
   }
+  TOD_HIP(hipMemcpyAsync(ws->train.p, h_train.data(), (size_t)total * 12, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->query.p, h_query.data(), (size_t)total * 12, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->qidx.p, h_qidx.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->kpxy.p, h_kpxy.data(), (size_t)total * 8, hipMemcpyHostToDevice, st));
   TOD_HIP(hipStreamSynchronize(st));   // the host vectors die with this scope
   Engine E = {ctx, st, nq, H, Wimg, 0u, n_objs, spans, prm, {}};
   rc = E.reserve_common(s);
