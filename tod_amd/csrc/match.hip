@@ -774,6 +774,13 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
   const int env_wpc = getenv("TODHIP_K4X_WAVES_PER_CU") ? atoi(getenv("TODHIP_K4X_WAVES_PER_CU")) : 0;   // tuning knobs, read per launch
   uint32_t wpc = 32;
   if ((uint64_t)n_rows * n_qw < (uint64_t)ctx->n_cu * wpc * 1536u) wpc = 16;
+  // A tile starts with empty lists and the radius as its threshold, and every row inside the threshold costs a walk of its block
+  // until the list's k-th entry tightens it. On independent bits almost no row is; on self-similar texture (rendered views of
+  // rectangle patterns: a median of 1300 rows of 1M within 35 bits of a query, tools/count_close_rows.py) tiles of a few hundred
+  // rows spend their life in that walk. One frame's launch therefore gets at most 8 waves per CU (tiles of >= ~4000 rows)
+  // and 4 query blocks per wave (launch_topk_mfma): 0.32 -> 0.19 ms on such a frame, 0.096 -> 0.095 ms on independent bits
+  // (tools/k4x_chained_frame.sh, tools/k4x_synth_frame.sh).
+  if ((uint64_t)n_rows * n_qw < (uint64_t)ctx->n_cu * 16u * 4096u) wpc = 8;
   if (env_wpc > 0) wpc = (uint32_t)env_wpc;
   uint32_t n_tiles = std::max(1u, (uint32_t)ctx->n_cu * wpc / n_qw);
   n_tiles = std::min(n_tiles, std::max(1u, n_rows / 256u));
@@ -863,6 +870,7 @@ int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t
   if (kMaxQT >= 8 && padded(6) < padded((uint32_t)qt)) qt = 6;
   if (kMaxQT >= 6 && padded(4) < padded((uint32_t)qt)) qt = 4;
   if (padded(2) < padded((uint32_t)qt)) qt = 2;
+  if (nq <= 2048u && qt > 4) qt = 4;                                  // a frame or two: longer tiles, see launch_topk_mfma_qt
   if ((env_qt == 2 || env_qt == 4 || env_qt == 6 || env_qt == 8) && env_qt <= kMaxQT) qt = env_qt;
   if (qt == 8) return launch_topk_mfma_qt<K, (kMaxQT >= 8 ? 8 : 4)>(ctx, d_q, nq, radius, d_lists, n_lists);
   if (qt == 6) return launch_topk_mfma_qt<K, (kMaxQT >= 6 ? 6 : 4)>(ctx, d_q, nq, radius, d_lists, n_lists);

@@ -38,3 +38,16 @@ tot = [a + b + c for a, b, c in zip(t_orb, t_match, t_verify)]
 print("data-chained frames through host buffers: orb %.3f ms, match %.3f ms, verify %.3f ms (median; verify %.2f .. %.2f), %.0f frames/s; "
       "%.2f poses per frame, %d objects with matches per frame" % (med(t_orb), med(t_match), med(t_verify), 1e3 * min(t_verify), 1e3 * max(t_verify),
                                                                  len(tot) / sum(tot), n_pose / len(tot), statistics.median(n_objs)))
+# the matcher alone on one of these frames, host and device form
+kp, aux, de = ctx.orb(imgs[0], nq, 3, 1.2)
+d_q = torch.from_numpy(de).cuda(); n = len(de)
+d_c = torch.zeros(n, dtype=torch.int32, device='cuda'); d_m = torch.zeros((n * k, 4), dtype=torch.int32, device='cuda'); d_x = torch.zeros((n * k, 3), device='cuda')
+for name, call in (("host form", lambda: ctx.match(de, k, radius)), ("device form", lambda: (ctx.match_device(d_q.data_ptr(), n, k, radius, d_c.data_ptr(), d_m.data_ptr(), d_x.data_ptr()), ctx.synchronize()))):
+    for _ in range(3): call()
+    t0 = time.perf_counter()
+    for _ in range(50): call()
+    print("match %s on a chained frame (%d queries): %.3f ms" % (name, n, (time.perf_counter() - t0) / 50 * 1e3))
+ctx.set_kernel_timing(True); c0 = ctx.counters()
+for _ in range(20): ctx.match_device(d_q.data_ptr(), n, k, radius, d_c.data_ptr(), d_m.data_ptr(), d_x.data_ptr())
+ctx.synchronize(); c1 = ctx.counters()
+print("DB pass kernel alone: %.3f ms" % ((c1.sum_match_kernel_ms - c0.sum_match_kernel_ms) / 20))
