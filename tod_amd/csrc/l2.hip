@@ -278,16 +278,24 @@ __global__ __launch_bounds__(256, 2) void l2_gemm_kernel(const uint16_t* __restr
   read_norms(0u);
   uint32_t cur = 0;
   for (uint32_t tile = t_begin; tile < t_end; ++tile, cur ^= 1u) {
+#if !defined(TOD_L2_ABLATE) || (TOD_L2_ABLATE != 1 && TOD_L2_ABLATE != 3)   // diagnostics builds (tools/l2_ablate.sh): 1 no DMA, 2 no LDS reads, 3 neither
     issue(tile + 2u, cur);                                  // in flight now: tile + 1 (the other slot) and tile + 2
+#endif
     f32x16 acc[2];
     auto mfma_tile = [&](uint32_t t) {
+#if !defined(TOD_L2_ABLATE) || (TOD_L2_ABLATE != 1 && TOD_L2_ABLATE != 3)
       if (t + 1 == kQTilesPerWave) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // tile + 1 has landed
+#endif
       f32x16 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[t][0], nrm, 0, 0, 0);
+#if !defined(TOD_L2_ABLATE) || TOD_L2_ABLATE < 2
       if (t + 1 == kQTilesPerWave) { a[0] = read_frag(cur ^ 1u, 0u); read_norms(cur ^ 1u); }
+#endif
 #pragma unroll
       for (uint32_t s = 1; s < 8; ++s) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[t][s], c, 0, 0, 0);
+#if !defined(TOD_L2_ABLATE) || TOD_L2_ABLATE < 2
         if (t + 1 == kQTilesPerWave) a[s] = read_frag(cur ^ 1u, s);
+#endif
       }
       return c;
     };
