@@ -61,6 +61,10 @@ typedef struct {
   double   last_match_kernel_ms;      /* HIP-event time of the dominant matcher kernel (if timing enabled) */
   double   sum_match_kernel_ms;
   uint64_t n_match_kernel_launches;
+  uint32_t last_sprint_launches;      /* verifier: launches of the single-wave small-object kernel in the last call ... */
+  uint32_t last_sprint_rounds;        /* ... and the Ransac rounds (adjacency_ransac.cpp:234-309) it ran without the host */
+  uint32_t last_verify_ticks;         /* host round trips (launch + synchronize) of the last verify call */
+  uint32_t reserved0;
 } todhip_counters;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

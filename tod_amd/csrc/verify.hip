@@ -1343,6 +1343,51 @@ __device__ inline float det3f(const float m[3][3]) {
          m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
 }
 
+// The serial tail of estimateRigidTransformationSVD (sac_model_registration_graph.h:330-346): H (double sums, rounded to float), SVD,
+// reflection fix, R = U Vt (double accumulation), T = c_train - R c_query. C = {c_train, c_query}. One lane's work; shared by the
+// block form (growth_kernel) and the single-wave form (sprint_kernel) so that both execute the same arithmetic.
+__device__ inline void kabsch_solve(const double Hd[9], const float C[6], float R[9], float T[3]) {
+  float H[3][3], U[3][3], wv[3], Vt[3][3], Rm[3][3];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] = (float)Hd[3 * r + c];
+  svd3(H, U, wv, Vt);
+  if (det3f(U) * det3f(Vt) < 0)
+    for (int x = 0; x < 3; ++x) Vt[2][x] *= -1;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += (double)U[r][k] * (double)Vt[k][c];
+      Rm[r][c] = (float)s;
+    }
+  for (int r = 0; r < 3; ++r) {
+    float s = 0;
+    for (int k = 0; k < 3; ++k) s += Rm[r][k] * C[3 + k];
+    T[r] = C[r] - s;
+    for (int c = 0; c < 3; ++c) R[3 * r + c] = Rm[r][c];
+  }
+}
+// adjacency_ransac.cpp:275-283: norm(R q + T - t)^2 < thresh, the norm in double
+__device__ __forceinline__ bool growth_admits(const float R[9], const float T[3], const float* q, const float* t, double thresh) {
+  float p[3];
+  for (int r = 0; r < 3; ++r) {
+    float s = 0;
+    for (int k = 0; k < 3; ++k) s += R[3 * r + k] * q[k];
+    p[r] = s + T[r];
+  }
+  const double nn = norm3d(p[0] - t[0], p[1] - t[1], p[2] - t[2]);
+  return nn * nn < thresh;
+}
+// adjacency_ransac.cpp:304-305: R = R^T, T = -R T
+__device__ inline void pose_invert(const float R[9], const float T[3], float Rout[9], float Tout[3]) {
+  float Rt[3][3];
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rt[r][c] = R[3 * c + r];
+  for (int r = 0; r < 3; ++r) {
+    float s = 0;
+    for (int k = 0; k < 3; ++k) s += (-Rt[r][k]) * T[k];
+    Tout[r] = s;
+    for (int c = 0; c < 3; ++c) Rout[3 * r + c] = Rt[r][c];
+  }
+}
+
 constexpr uint32_t kGrowthLdsPoints = 2048;   // inlier points staged in LDS per Kabsch pass (48 KB)
 
 struct GrowthOut {
@@ -1480,23 +1525,7 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
     }
     __syncthreads();
     if (tid == 0) {
-      float H[3][3], U[3][3], wv[3], Vt[3][3], Rm[3][3];
-      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) H[r][c] = (float)sAcc[3 * r + c];
-      svd3(H, U, wv, Vt);
-      if (det3f(U) * det3f(Vt) < 0)
-        for (int x = 0; x < 3; ++x) Vt[2][x] *= -1;
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-          double s = 0;
-          for (int k = 0; k < 3; ++k) s += (double)U[r][k] * (double)Vt[k][c];
-          Rm[r][c] = (float)s;
-        }
-      for (int r = 0; r < 3; ++r) {
-        float s = 0;
-        for (int k = 0; k < 3; ++k) s += Rm[r][k] * sC[3 + k];
-        sT[r] = sC[r] - s;
-        for (int c = 0; c < 3; ++c) sR[3 * r + c] = Rm[r][c];
-      }
+      kabsch_solve(sAcc, sC, sR, sT);
       sFlag = 0u;
     }
     __syncthreads();
@@ -1508,16 +1537,7 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
       if (w < W) {
         const uint32_t v = w * 64u + (tid & 63u);
         if (v < n && ((rest[w] >> (v & 63u)) & 1ull)) {
-          const float* q = job.query + 3 * v;
-          const float* t = job.train + 3 * v;
-          float p[3];
-          for (int r = 0; r < 3; ++r) {
-            float s = 0;
-            for (int k = 0; k < 3; ++k) s += sR[3 * r + k] * q[k];
-            p[r] = s + sT[r];
-          }
-          const double nn = norm3d(p[0] - t[0], p[1] - t[1], p[2] - t[2]);
-          pass = nn * nn < thresh;
+          pass = growth_admits(sR, sT, job.query + 3 * v, job.train + 3 * v, thresh);
         }
       }
       const u64 bal = __ballot(pass);
@@ -1534,16 +1554,7 @@ __global__ __launch_bounds__(256) void growth_kernel(Slots<GrowthArgs> SL) {
     if (!any_extra) { do_final = true; thresh *= 4; }      // :295-301
   }
   // ---- pose inversion (:304-305) and unique keypoint indices (:306-308)
-  if (tid == 0) {
-    float Rt[3][3];
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Rt[r][c] = sR[3 * c + r];
-    for (int r = 0; r < 3; ++r) {
-      float s = 0;
-      for (int k = 0; k < 3; ++k) s += (-Rt[r][k]) * sT[k];
-      out->T[r] = s;
-      for (int c = 0; c < 3; ++c) out->R[3 * r + c] = Rt[r][c];
-    }
-  }
+  if (tid == 0) pose_invert(sR, sT, out->R, out->T);
   // unique keypoint indices in ascending match order (:306-308). qidx is non-decreasing in the match index (App. A Q4),
   // so an inlier starts a new keypoint iff the inlier before it has another qidx: one wave per 64-match word, the word
   // boundaries are stitched by one lane.
@@ -1763,20 +1774,23 @@ __global__ __launch_bounds__(256) void cluster_group_kernel(Slots<GroupArgs> SL)
   kpxy[2 * d] = fkp[2 * f]; kpxy[2 * d + 1] = fkp[2 * f + 1];
 }
 
+#include "verify_sprint.h"
+
 // ------------------------------------------------------------------------------------------------ host side
 struct VerifyWs {
   DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, nvalid, rnd, table, iter_samples, counts, gate_m,
       small, deferred, stacks, kp_bits, clique_adj, adjc_scratch, c_kept, c_offs, c_qpt, c_obj, c_hist, c_goff, f_train,
-      f_query, f_qidx, f_kp;
+      f_query, f_qidx, f_kp, sprint_status, sprint_stack;
   // the slot's mailbox: pinned host memory that kernels read and write directly (see copy_words_kernel)
   HostBuf m_small, m_hist, m_goff, m_rnd, m_pos, m_counts, m_kp, m_nvalid;
+  HostBuf m_sprint, m_sprint_out, m_sprint_kp;              // sprint_kernel: the object list in, records and keypoint lists out
   HostBuf h_small;                                          // staging of the test hooks
   void release() {
     DevBuf* bufs[] = {&train, &query, &qidx, &kpxy, &phys, &samp, &bits, &sampdeg, &nvalid, &rnd, &table, &iter_samples, &counts, &gate_m,
                       &small, &deferred, &stacks, &kp_bits, &clique_adj, &adjc_scratch, &c_kept, &c_offs, &c_qpt, &c_obj, &c_hist,
-                      &c_goff, &f_train, &f_query, &f_qidx, &f_kp};
+                      &c_goff, &f_train, &f_query, &f_qidx, &f_kp, &sprint_status, &sprint_stack};
     for (DevBuf* b : bufs) b->release();
-    HostBuf* hb[] = {&m_small, &m_hist, &m_goff, &m_rnd, &m_pos, &m_counts, &m_kp, &m_nvalid, &h_small};
+    HostBuf* hb[] = {&m_small, &m_hist, &m_goff, &m_rnd, &m_pos, &m_counts, &m_kp, &m_nvalid, &h_small, &m_sprint, &m_sprint_out, &m_sprint_kp};
     for (HostBuf* b : hb) b->release();
   }
 };
@@ -1787,6 +1801,7 @@ struct VerifyPool {
   std::vector<VerifyWs*> slots; std::vector<StreamCache*> streams;
   std::vector<hipEvent_t> side_ev;                          // one per flight of a batch (Engine::run_ticks), created on first use
   HostBuf args_stage; DevBuf args_dev;                      // argument sets of a tick's long lists (launch_many)
+  DevBuf kceil; bool kceil_ready = false;                   // sprint_kernel: ceil(k) of ransac.h:130 per (|valid|, n_best), 65 x 65
 };
 // The flights' streams belong to the process, not to a context: a process has eight hardware queues for all of its streams
 // (DESIGN 7), the runtime deals streams onto them round robin, and every further stream -- busy or not -- makes it likelier that two
@@ -1924,6 +1939,7 @@ struct ObjSpan {
   // this object's slices of the slot's adjacency / bitset / degree buffers (all objects of a frame are prepared in
   // one tick, so each needs its own), and its first round's |valid|
   uint64_t adj_off = 0; uint32_t bits_off = 0, deg_off = 0, nvalid = 0, degsum = 0, triangle = 1;
+  bool resume = false, counted = false;                    // sprint_kernel left it unfinished (its first-round statistics are stale) / in the counters
 };
 struct DepthInput { const void* d_depth; int is_u16; float fx, fy, cx, cy; };
 
@@ -1935,7 +1951,7 @@ struct DepthInput { const void* d_depth; int is_u16; float fx, fy, cx, cy; };
 // each non-empty list once (all slots in one grid), synchronizes once, and lets every slot consume its results
 // (the ransac.h:95-135 bookkeeping is replayed on the host so that pow/log are libm's).
 enum Phase { PH_CLUSTER, PH_CLUSTER_WAIT, PH_GROUP, PH_PREPALL, PH_PREPALL_WAIT, PH_OBJECT, PH_ROUND, PH_PREP_WAIT, PH_DRAW,
-             PH_DRAW_WAIT, PH_EVAL2, PH_EVAL2_WAIT, PH_GROWTH, PH_GROWTH_WAIT, PH_DONE };
+             PH_DRAW_WAIT, PH_EVAL2, PH_EVAL2_WAIT, PH_GROWTH, PH_GROWTH_WAIT, PH_SPRINT_WAIT, PH_DONE };
 
 struct RoundState {                                       // computeModel (ransac.h:80-143) in flight
   uint64_t consumed = 0;                                  // draws used by completed getSamples calls of this round
@@ -1977,6 +1993,8 @@ struct Slot {
   // getSamples gave up (1000 failing attempts, ~4-9k draws). Frames with many stray matches hold runs of such objects; a
   // first window sized for a healthy object (576) made each of them crawl through three windows = three ticks
   uint32_t s_hint = 0;
+  std::vector<size_t> sprint_members;                      // indices into objs of the sprint in flight (sprint_kernel)
+  uint64_t sprint_margin = 1u << 17;                       // rand() words the device copy of the stream reaches beyond the sprint's start
   todhip_round_trace tr = {};
   RoundState r;
 };
@@ -1990,6 +2008,7 @@ struct Launches {
   // the shared stream buffer
   std::vector<std::pair<StreamCache*, uint64_t>> draw_src, draw_small_src; std::vector<EvalArgs> eval_small, eval_big, eval_direct;
   std::vector<GrowthArgs> growth;
+  std::vector<SprintArgs> sprint; std::vector<StreamCache*> sprint_src;
 };
 
 // launch `kern` over the argument sets of v, kMaxSlots at a time; extent(a) = blocks one set needs in x (and y)
@@ -2158,6 +2177,7 @@ struct Engine {
       // Ransac returns no inliers for < 3 valid matches and draws nothing (:238-241)
       while (s.oi < s.objs.size() && s.objs[s.oi].n < 3) ++s.oi;
       if (s.oi >= s.objs.size()) { s.ph = PH_DONE; return; }
+      if (sprint_on() && sprint_live(s.objs[s.oi])) { issue_sprint(s); return; }
       const ObjSpan& o = s.objs[s.oi];
       s.job = make_job(s, o);
       ctx->counters.last_objects_verified += 1;
@@ -2227,6 +2247,129 @@ struct Engine {
       s.ph = PH_GROWTH_WAIT;
       return;
     }
+  }
+
+  // ---- sprint_kernel: the live objects of at most kSprintN matches from s.oi up to the next live big object, in one launch
+  static bool sprint_on() {
+    static const bool on = [] { const char* e = getenv("TODHIP_VERIFY_SPRINT"); return !(e && e[0] == '0'); }();   // read once
+    return on;
+  }
+  static bool sprint_live(const ObjSpan& o) {
+    return o.n >= 3u && o.n <= kSprintN && (o.resume || (o.nvalid >= 3u && o.triangle != 0u));
+  }
+  void issue_sprint(Slot& s) {
+    VerifyWs* ws = s.ws;
+    SLOT_HIP(ws->m_sprint.reserve(kSprintMaxObjs * sizeof(SprintObj)));
+    SLOT_HIP(ws->m_sprint_out.reserve((kSprintHdrWords + (size_t)kSprintMaxRecs * kSprintRecWords) * sizeof(uint32_t)));
+    SLOT_HIP(ws->m_sprint_kp.reserve((size_t)kSprintMaxRecs * kSprintN * sizeof(uint32_t)));
+    SLOT_HIP(ws->sprint_status.reserve(16 * sizeof(uint32_t)));
+    SLOT_HIP(ws->sprint_stack.reserve((size_t)kSprintStackCap * sizeof(uint16_t)));
+    SprintObj* list = ws->m_sprint.as<SprintObj>();
+    s.sprint_members.clear();
+    uint64_t skip = 0, total_skip = 0;
+    for (size_t i = s.oi; i < s.objs.size() && s.sprint_members.size() < kSprintMaxObjs; ++i) {
+      const ObjSpan& o = s.objs[i];
+      if (o.n < 3u) continue;
+      if (sprint_live(o)) {
+        SprintObj so;
+        so.job = make_job(s, o); so.skip = skip; so.index = (uint32_t)i; so.pad = 0;
+        list[s.sprint_members.size()] = so;
+        s.sprint_members.push_back(i);
+        total_skip += skip; skip = 0;
+        continue;
+      }
+      if (o.nvalid < 3u) continue;                           // no round, no draw (:238-241)
+      if (o.triangle) break;                                 // a live big object: the sprint ends before it
+      skip += (uint64_t)kMaxSampleChecks * ((uint64_t)o.nvalid + o.degsum / 2u);   // triangle-free: start_round
+    }
+    SLOT_HIP(s.stream->ensure_device(s.abs_pos + total_skip + s.sprint_margin, st));
+    SprintArgs a;
+    a.objs = list; a.rnd = nullptr; a.rnd_len = 0; a.pos0 = s.abs_pos; a.kceil = pool_of(ctx)->kceil.as<uint32_t>();
+    a.out = ws->m_sprint_out.as<uint32_t>(); a.kp_out = ws->m_sprint_kp.as<uint32_t>();
+    a.status = ws->sprint_status.as<uint32_t>(); a.stack = ws->sprint_stack.as<uint16_t>();
+    a.n_objs = (uint32_t)s.sprint_members.size(); a.max_iterations = prm->n_ransac_iterations; a.min_inliers = prm->min_inliers;
+    a.err = prm->sensor_error; a.rec_cap = kSprintMaxRecs; a.kp_cap = kSprintMaxRecs * kSprintN;
+    a.out[0] = 0u; a.out[1] = SPRINT_ERROR; a.out[2] = 0u;   // (overwritten by the kernel)
+    L.zero.push_back({nullptr, a.status, 8u});
+    L.sprint.push_back(a);
+    L.sprint_src.push_back(s.stream);                        // rnd / rnd_len are resolved at launch time (the shared stream may move)
+    s.ph = PH_SPRINT_WAIT;
+  }
+  void consume_sprint(Slot& s) {
+    VerifyWs* ws = s.ws;
+    const uint32_t* out = ws->m_sprint_out.as<uint32_t>();
+    const uint32_t* kp_out = ws->m_sprint_kp.as<uint32_t>();
+    const uint32_t n_rec = out[0], reason = out[1], n_done = out[2];
+    TOD_DBG("sprint: %zu objects, %u done, %u records, reason %u, gate calls %u, hypotheses %u", s.sprint_members.size(), n_done, n_rec,
+            reason, out[5], out[6]);
+    if (reason == SPRINT_ERROR || n_rec > kSprintMaxRecs || n_done > s.sprint_members.size()) {
+      if (tod_debug()) fprintf(stderr, "[todhip] sprint error: detail %u status %u\n", out[7], out[1]);
+      fail(s, TODHIP_ESCRATCH);
+      return;
+    }
+    ctx->counters.last_gate_calls += out[5];
+    ctx->counters.last_hypotheses += out[6];
+    ctx->counters.last_sprint_launches += 1;
+    ctx->counters.last_sprint_rounds += n_rec;
+    uint32_t ri = 0;
+    for (uint32_t m = 0; m < s.sprint_members.size(); ++m) {
+      const size_t idx = s.sprint_members[m];
+      const bool complete = m < n_done;
+      const bool touched = complete || (ri < n_rec && out[kSprintHdrWords + (size_t)ri * kSprintRecWords] == m);
+      if (!touched) break;                                   // the wave stopped before this object: PH_OBJECT takes it from here
+      // the objects the host decides without a kernel on the way (first round: fewer than 3 valid matches, or triangle-free)
+      while (s.oi < idx) {
+        const ObjSpan& t = s.objs[s.oi];
+        if (t.n < 3u) { ++s.oi; continue; }
+        s.job = make_job(s, t);
+        ctx->counters.last_objects_verified += 1;
+        s.pending_invalidate = false;
+        s.tr = todhip_round_trace();
+        s.tr.object = t.obj; s.tr.draws_before = s.start_draws + s.abs_pos; s.tr.best_count = -INT_MAX;
+        start_round(s, t.nvalid, t.degsum, t.triangle);      // -> round_done: ++s.oi
+        if (s.ph == PH_DONE) return;                         // (a failure)
+      }
+      ObjSpan& o = s.objs[idx];
+      if (!o.counted) { ctx->counters.last_objects_verified += 1; o.counted = true; }
+      for (; ri < n_rec; ++ri) {
+        const uint32_t* rec = out + kSprintHdrWords + (size_t)ri * kSprintRecWords;
+        if (rec[0] != m) break;
+        const uint64_t consumed = ((uint64_t)rec[5] << 32) | rec[4];
+        todhip_round_trace tr = todhip_round_trace();
+        tr.object = o.obj; tr.draws_before = s.start_draws + s.abs_pos;
+        tr.iterations = rec[1]; tr.best_iteration = rec[2]; tr.best_count = (int32_t)rec[3];
+        s.abs_pos += consumed;
+        const uint32_t n_kp = rec[7] ? rec[6] : 0u;
+        ctx->counters.last_rounds += 1;
+        tr.draws_after = s.start_draws + s.abs_pos; tr.n_inlier_kp = n_kp; tr.accepted = n_kp >= prm->min_inliers;
+        s.traces.push_back(tr);
+        if (n_kp >= prm->min_inliers) {                      // GuessGenerator.cpp:205-230
+          if (rec[20] + n_kp > kSprintMaxRecs * kSprintN) { fail(s, TODHIP_ESCRATCH); return; }
+          todhip_pose p;
+          std::memset(&p, 0, sizeof(p));
+          p.object = o.obj;
+          std::memcpy(p.R, rec + 8, sizeof(p.R));
+          std::memcpy(p.t, rec + 17, sizeof(p.t));
+          p.inlier_begin = (uint32_t)s.inliers.size();
+          s.inliers.insert(s.inliers.end(), kp_out + rec[20], kp_out + rec[20] + n_kp);
+          p.inlier_end = (uint32_t)s.inliers.size();
+          s.poses.push_back(p);
+          ctx->counters.last_poses += 1;
+        }
+      }
+      if (!complete) {                                       // relaunch from this object; the kernel recomputes its statistics
+        o.resume = true;
+        s.oi = idx;
+        break;
+      }
+      s.oi = idx + 1;
+    }
+    if (reason == SPRINT_NEED_STREAM) {
+      if (s.sprint_margin >= (1ull << 28)) { fail(s, TODHIP_ESCRATCH); return; }
+      s.sprint_margin *= 4u;
+    }
+    s.sprint_members.clear();
+    s.ph = PH_OBJECT;
   }
 
   // ---- one evaluation batch of computeModel starts: draw `want` iterations (as many windows as it takes)
@@ -2395,6 +2538,7 @@ struct Engine {
       eval_done(s, true);
       return;
     }
+    if (s.ph == PH_SPRINT_WAIT) { consume_sprint(s); return; }
     if (s.ph == PH_GROWTH_WAIT) {
       const GrowthOut* go = reinterpret_cast<const GrowthOut*>(m + 32);
       TOD_DBG("  growth: model=%u matches=%u kps=%u passes=%u", go->n_model_inliers, go->n_match_inliers, go->n_kp_inliers,
@@ -2431,6 +2575,25 @@ struct Engine {
     TOD_HIP(ws->m_small.reserve(kMailSmallWords * sizeof(uint32_t)));
     TOD_HIP(ws->kp_bits.reserve((size_t)(kp_words + 1) * sizeof(u64)));
     TOD_HIP(ws->m_kp.reserve((size_t)std::max(nq, 1u) * sizeof(uint32_t)));
+    VerifyPool* pool = pool_of(ctx);
+    if (!pool->kceil_ready) {
+      // ransac.h:121-130 with libm, once: k = log(1 - 0.99) / log(1 - w^3), w = n_best / |valid|; `iterations_ < k` (:95) is
+      // `iterations_ < ceil(k)` for an integer iterations_, so the device replays the loop test exactly from this table
+      std::vector<uint32_t> tab(65u * 65u, 1u);
+      for (uint32_t nv = 1; nv <= 64u; ++nv)
+        for (uint32_t nb = 0; nb <= 64u; ++nb) {
+          const double w = (double)(int)nb / (double)nv;
+          double p_no_outliers = 1.0 - std::pow(w, 3.0);
+          p_no_outliers = std::max(std::numeric_limits<double>::epsilon(), p_no_outliers);
+          p_no_outliers = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no_outliers);
+          const double k = std::log(1.0 - 0.99) / std::log(p_no_outliers);
+          const double c = std::ceil(k);
+          tab[nv * 65u + nb] = c >= 2147483647.0 ? 0x7FFFFFFFu : (uint32_t)c;
+        }
+      TOD_HIP(pool->kceil.reserve(tab.size() * sizeof(uint32_t)));
+      TOD_HIP(hipMemcpy(pool->kceil.p, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+      pool->kceil_ready = true;
+    }
     return TODHIP_OK;
   }
   int reserve_cluster(Slot& s) {
@@ -2521,6 +2684,8 @@ struct Engine {
     auto words = [](const CopyArgs& a) { return dim3(std::max(1u, std::min(64u, (a.n + 255u) / 256u))); };
     L.copy_in.insert(L.copy_in.end(), L.zero.begin(), L.zero.end());   // both precede every other kernel of the tick: one launch
     launch_list<kCopySlots>(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
+    for (size_t i = 0; i < L.sprint.size(); ++i) { L.sprint[i].rnd = L.sprint_src[i]->dev.as<uint32_t>(); L.sprint[i].rnd_len = L.sprint_src[i]->dev_valid; }
+    launch_list<kWideSlots>(st, sprint_kernel, L.sprint, 64, kSprintLds, 0, [](const SprintArgs&) { return dim3(1); });
     launch_list(st, cluster_lookup_kernel, L.lookup, 256, 0, 1, [](const LookupArgs& a) { return dim3((a.nq + 255u) / 256u); });
     launch_list(st, cluster_scan_kernel, L.scan, 256, 0, 0, [](const ScanArgs&) { return dim3(1); });
     launch_list(st, cluster_scatter_kernel, L.scatter, 256, 0, 1,
@@ -2623,9 +2788,9 @@ struct Engine {
     return n;
   }
   void describe(char* what, size_t cap) const {
-    snprintf(what, cap, "lookup %zu adj %zu prep %zu draw %zu+%zu chain %zu eval %zu+%zu growth %zu inval %zu", L.lookup.size(),
+    snprintf(what, cap, "lookup %zu adj %zu prep %zu draw %zu+%zu chain %zu eval %zu+%zu growth %zu inval %zu sprint %zu", L.lookup.size(),
              L.adj.size(), L.prep.size(), L.draw.size(), L.draw_small.size(), L.chain.size(), L.eval_small.size() + L.eval_direct.size(),
-             L.eval_big.size(), L.growth.size(), L.inval.size());
+             L.eval_big.size(), L.growth.size(), L.inval.size(), L.sprint.size());
   }
   int run_ticks(std::vector<Slot*>& slots) {
     std::vector<Flight> flights;
@@ -2701,7 +2866,7 @@ struct Engine {
       char what[128] = "";
       std::chrono::steady_clock::time_point t0;
       if (tod_debug()) { describe(what, sizeof(what)); t0 = std::chrono::steady_clock::now(); }
-      if (!main_slots.empty()) { launch_all(st); LOOP_HIP(hipGetLastError()); }
+      if (!main_slots.empty()) { launch_all(st); LOOP_HIP(hipGetLastError()); ctx->counters.last_verify_ticks += 1; }
       else L = Launches();
       if (!heavy_now.empty()) {
         const size_t per = (heavy_now.size() + n_free - 1) / n_free;
@@ -2759,7 +2924,7 @@ void tod_verify_ws_free(todhip_ctx* ctx) {
   for (VerifyWs* ws : p->slots) { ws->release(); delete ws; }
   for (StreamCache* c : p->streams) { c->dev.release(); delete c; }
   for (hipEvent_t e : p->side_ev) (void)hipEventDestroy(e);
-  p->args_stage.release(); p->args_dev.release();
+  p->args_stage.release(); p->args_dev.release(); p->kceil.release();
   delete p;
   ctx->verify_ws = nullptr;
 }
@@ -2789,6 +2954,7 @@ static int verify_prologue(todhip_ctx* ctx, const todhip_verify_params* prm) {
   if (!ctx || !prm) return TODHIP_EINVAL;
   ctx->counters.last_objects_verified = ctx->counters.last_rounds = ctx->counters.last_hypotheses = 0;
   ctx->counters.last_gate_calls = ctx->counters.last_poses = 0;
+  ctx->counters.last_sprint_launches = ctx->counters.last_sprint_rounds = ctx->counters.last_verify_ticks = 0;
   ctx->traces.clear();
   TOD_HIP(hipSetDevice(ctx->device));
   return set_big_lds_once(ctx);

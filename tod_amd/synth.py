@@ -92,7 +92,7 @@ def random_graph_edges(n, p, seed):
 
 
 def make_verify_scene(n_kp, n_objects=6, per_object=400, visible=((1, 0.30),), matches_per_kp=5, seed=0, H=480, W=640,
-                      f=525.0, noise=0.002, nan_frac=0.10, true_match_rank=0):
+                      f=525.0, noise=0.002, nan_frac=0.10, true_match_rank=0, placements=None):
     """A hard scene for stage C, with the matches given directly (SURVEY probe P4 style): every keypoint carries
     `matches_per_kp` matches; a keypoint on a visible object has its true match plus random distractors, a clutter
     keypoint has only distractors. `visible` = ((object, fraction of keypoints), ...), each object at its own pose.
@@ -110,9 +110,11 @@ def make_verify_scene(n_kp, n_objects=6, per_object=400, visible=((1, 0.30),), m
     for vi, (obj, frac) in enumerate(visible):
         cnt = int(round(n_kp * frac))
         ang = 0.7 + 0.9 * vi
+        t = np.array([0.05 - 0.35 * vi, -0.02 + 0.2 * vi, 0.8 + 0.15 * vi], np.float32)
+        if placements is not None:                             # (angle, (tx, ty, tz)) per visible object, in the camera's view
+            ang, t = placements[vi][0], np.asarray(placements[vi][1], np.float32)
         c, s_ = np.cos(ang), np.sin(ang)
         R = np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]], np.float32)
-        t = np.array([0.05 - 0.35 * vi, -0.02 + 0.2 * vi, 0.8 + 0.15 * vi], np.float32)
         rows = rng.choice(per_object, size=min(cnt, per_object), replace=False)
         cnt = len(rows)
         xyz[start:start + cnt] = (model[obj][rows] @ R.T + t + rng.normal(0, noise, (cnt, 3))).astype(np.float32)
