@@ -1929,6 +1929,8 @@ int set_big_lds_once(todhip_ctx* ctx) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kEvalLdsBig));
     TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kEvalLdsBig));
+    TOD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sprint_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kSprintLds));
     done.store(true, std::memory_order_release);
   }
   return TODHIP_OK;
@@ -2263,7 +2265,7 @@ struct Engine {
     SLOT_HIP(ws->m_sprint_out.reserve((kSprintHdrWords + (size_t)kSprintMaxRecs * kSprintRecWords) * sizeof(uint32_t)));
     SLOT_HIP(ws->m_sprint_kp.reserve((size_t)kSprintMaxRecs * kSprintN * sizeof(uint32_t)));
     SLOT_HIP(ws->sprint_status.reserve(16 * sizeof(uint32_t)));
-    SLOT_HIP(ws->sprint_stack.reserve((size_t)kSprintStackCap * sizeof(uint16_t)));
+    SLOT_HIP(ws->sprint_stack.reserve((size_t)kSprintWaves * kSprintStackCap * sizeof(uint16_t)));
     SprintObj* list = ws->m_sprint.as<SprintObj>();
     s.sprint_members.clear();
     uint64_t skip = 0, total_skip = 0;
@@ -2300,8 +2302,9 @@ struct Engine {
     const uint32_t* out = ws->m_sprint_out.as<uint32_t>();
     const uint32_t* kp_out = ws->m_sprint_kp.as<uint32_t>();
     const uint32_t n_rec = out[0], reason = out[1], n_done = out[2];
-    TOD_DBG("sprint: %zu objects, %u done, %u records, reason %u, gate calls %u, hypotheses %u", s.sprint_members.size(), n_done, n_rec,
-            reason, out[5], out[6]);
+    TOD_DBG("sprint: %zu objects, %u done, %u records, reason %u, gate calls %u, hypotheses %u, windows %u; ticks: ring %u attempt %u walk %u eval %u "
+            "book %u growth %u all %u", s.sprint_members.size(), n_done, n_rec, reason, out[5], out[6], out[8], out[9], out[10], out[11], out[12],
+            out[13], out[14], out[15]);
     if (reason == SPRINT_ERROR || n_rec > kSprintMaxRecs || n_done > s.sprint_members.size()) {
       if (tod_debug()) fprintf(stderr, "[todhip] sprint error: detail %u status %u\n", out[7], out[1]);
       fail(s, TODHIP_ESCRATCH);
@@ -2685,7 +2688,7 @@ struct Engine {
     L.copy_in.insert(L.copy_in.end(), L.zero.begin(), L.zero.end());   // both precede every other kernel of the tick: one launch
     launch_list<kCopySlots>(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
     for (size_t i = 0; i < L.sprint.size(); ++i) { L.sprint[i].rnd = L.sprint_src[i]->dev.as<uint32_t>(); L.sprint[i].rnd_len = L.sprint_src[i]->dev_valid; }
-    launch_list<kWideSlots>(st, sprint_kernel, L.sprint, 64, kSprintLds, 0, [](const SprintArgs&) { return dim3(1); });
+    launch_list<kWideSlots>(st, sprint_kernel, L.sprint, kSprintThreads, kSprintLds, 0, [](const SprintArgs&) { return dim3(1); });
     launch_list(st, cluster_lookup_kernel, L.lookup, 256, 0, 1, [](const LookupArgs& a) { return dim3((a.nq + 255u) / 256u); });
     launch_list(st, cluster_scan_kernel, L.scan, 256, 0, 0, [](const ScanArgs&) { return dim3(1); });
     launch_list(st, cluster_scatter_kernel, L.scatter, 256, 0, 1,
