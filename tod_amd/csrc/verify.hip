@@ -66,11 +66,14 @@ __global__ __launch_bounds__(256) void copy_words_kernel(Slots<CopyArgs, kCopySl
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < a.n; i += gridDim.x * 256u) a.dst[i] = a.src ? a.src[i] : 0u;
 }
 
-inline bool tod_debug() { static const bool on = getenv("TODHIP_DEBUG") != nullptr; return on; }   // read once
+// TODHIP_DEBUG=1: ticks, flights and sprints (a timeline that costs a few lines per tick); 2: also every round, draw window, evaluation
+inline int tod_debug_level() { static const int lv = [] { const char* e = getenv("TODHIP_DEBUG"); return e ? std::max(1, atoi(e)) : 0; }(); return lv; }   // read once
+inline bool tod_debug() { return tod_debug_level() > 0; }
 inline double dbg_us() {
   static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 }
+#define TOD_DBG2(...) do { if (tod_debug_level() > 1) { fprintf(stderr, "[todhip %.0f] ", dbg_us()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 #define TOD_DBG(...) do { if (tod_debug()) { fprintf(stderr, "[todhip %.0f] ", dbg_us()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 
 // ------------------------------------------------------------------------------------------------ K6
@@ -1799,8 +1802,11 @@ struct VerifyWs {
 struct StreamCache;
 struct VerifyPool {
   std::vector<VerifyWs*> slots; std::vector<StreamCache*> streams;
-  std::vector<hipEvent_t> side_ev;                          // one per flight of a batch (Engine::run_ticks), created on first use
-  HostBuf args_stage; DevBuf args_dev;                      // argument sets of a tick's long lists (launch_many)
+  std::vector<hipEvent_t> side_ev;                          // one per lane of a batch (Engine::run_ticks), created on first use
+  // argument sets of a launch group's long lists (launch_many): one pair per lane, so that groups in flight on different streams
+  // never share staging memory, and a pair only grows while its lane is idle
+  static constexpr size_t kMaxLanes = 17;
+  HostBuf args_stage[kMaxLanes]; DevBuf args_dev[kMaxLanes];
   DevBuf kceil; bool kceil_ready = false;                   // sprint_kernel: ceil(k) of ransac.h:130 per (|valid|, n_best), 65 x 65
 };
 // The flights' streams belong to the process, not to a context: a process has eight hardware queues for all of its streams
@@ -2042,6 +2048,7 @@ struct Engine {
   const float* spans;
   const todhip_verify_params* prm;
   Launches L;
+  size_t lane_now = 0;                                      // the lane launch_all is filling (its staging pair)
 
   static uint32_t* mail(const Slot& s) { return s.ws->m_small.as<uint32_t>(); }
   void export_small(Slot& s) { L.copy_out.push_back({s.ws->small.as<uint32_t>(), mail(s), 64u}); }
@@ -2067,7 +2074,7 @@ struct Engine {
   void start_round(Slot& s, uint32_t nvalid, uint32_t degsum, uint32_t triangle) {
     VerifyWs* ws = s.ws;
     RoundState& r = s.r;
-    TOD_DBG("round: n=%u W=%u nvalid=%u edges=%u triangle=%u", s.job.n, s.job.W, nvalid, degsum / 2u, triangle);
+    TOD_DBG2("round: n=%u W=%u nvalid=%u edges=%u triangle=%u", s.job.n, s.job.W, nvalid, degsum / 2u, triangle);
     if (nvalid < 3) { round_done(s, false); return; }      // :238-241
     if (!triangle) {
       // no three mutually sample-adjacent valid matches: getSamples fails 1000 times, each attempt consuming exactly
@@ -2395,7 +2402,7 @@ struct Engine {
     if (!second) {
       ctx->counters.last_gate_calls += m[13];
       r.n_def = m[14];
-      TOD_DBG("  eval done: gate calls=%u deferred=%u", m[13], r.n_def);
+      TOD_DBG2("  eval done: gate calls=%u deferred=%u", m[13], r.n_def);
       if (r.n_def > 0) { s.ph = PH_EVAL2; return; }
     }
     ctx->counters.last_hypotheses += r.got;
@@ -2513,7 +2520,7 @@ struct Engine {
     if (s.ph == PH_DRAW_WAIT) {
       if (eval_failed(s)) return;                           // (the evaluation of this walk's iterations ran in the same tick)
       const ChainOut co = *reinterpret_cast<const ChainOut*>(m + 1);
-      TOD_DBG("  draw window: S=%u len=%u -> done=%u pos_end=%u attempts=%u flag=%u", r.S, r.window_len, co.n_done, co.pos_end,
+      TOD_DBG2("  draw window: S=%u len=%u -> done=%u pos_end=%u attempts=%u flag=%u", r.S, r.window_len, co.n_done, co.pos_end,
               co.attempts, co.flag);
       uint32_t* hp = ws->m_pos.as<uint32_t>();             // positions of this walk are relative to the window start
       for (uint32_t i = 0; i < co.n_done; ++i) hp[r.it_begin + r.got + i] += (uint32_t)r.consumed;
@@ -2544,7 +2551,7 @@ struct Engine {
     if (s.ph == PH_SPRINT_WAIT) { consume_sprint(s); return; }
     if (s.ph == PH_GROWTH_WAIT) {
       const GrowthOut* go = reinterpret_cast<const GrowthOut*>(m + 32);
-      TOD_DBG("  growth: model=%u matches=%u kps=%u passes=%u", go->n_model_inliers, go->n_match_inliers, go->n_kp_inliers,
+      TOD_DBG2("  growth: model=%u matches=%u kps=%u passes=%u", go->n_model_inliers, go->n_match_inliers, go->n_kp_inliers,
               go->passes);
       round_done(s, true);
       return;
@@ -2629,13 +2636,15 @@ struct Engine {
   bool launch_many(hipStream_t st, KernP kern, const std::vector<A>& v, int slot_dim, Extent extent, size_t& used, uint32_t block = 256u,
                    uint32_t lds = 0u, bool by_class = true) {
     VerifyPool* pool = pool_of(ctx);
+    HostBuf& args_stage = pool->args_stage[lane_now];
+    DevBuf& args_dev = pool->args_dev[lane_now];
     const size_t bytes = v.size() * sizeof(A);
     used = (used + 255u) & ~(size_t)255u;
-    if (used + bytes > pool->args_stage.cap || used + bytes > pool->args_dev.cap) return false;
+    if (used + bytes > args_stage.cap || used + bytes > args_dev.cap) return false;
     static const uint32_t kClassBy[] = {16u, 64u, 256u, 0xFFFFFFFFu}, kClassOne[] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     const uint32_t* kClass = by_class ? kClassBy : kClassOne;
-    A* host = reinterpret_cast<A*>(reinterpret_cast<unsigned char*>(pool->args_stage.p) + used);
-    const A* dev = reinterpret_cast<const A*>(reinterpret_cast<const unsigned char*>(pool->args_dev.p) + used);
+    A* host = reinterpret_cast<A*>(reinterpret_cast<unsigned char*>(args_stage.p) + used);
+    const A* dev = reinterpret_cast<const A*>(reinterpret_cast<const unsigned char*>(args_dev.p) + used);
     size_t n_cls[4] = {0, 0, 0, 0}, at = 0;
     auto cls_of = [&](const A& a) { uint32_t c = 0; while (a.job.n > kClass[c]) ++c; return c; };
     for (const A& a : v) ++n_cls[cls_of(a)];
@@ -2657,6 +2666,13 @@ struct Engine {
     return true;
   }
 
+  template <class F>
+  static void split_evals(const std::vector<EvalArgs>& v, uint32_t lds, bool deferred, F& launch_evals) {
+    bool any_wide = false, any_narrow = false;
+    for (const EvalArgs& a : v) (a.job.W <= 8u ? any_narrow : any_wide) = true;
+    if (any_wide && any_narrow) { launch_evals(v, true, lds, deferred); return; }
+    launch_evals(v, any_wide, lds, deferred);
+  }
   void launch_all(hipStream_t st) {
     // the staging area for argument sets in device memory (launch_many) is sized once per tick, before anything reads it
     size_t used = 0;
@@ -2667,7 +2683,7 @@ struct Engine {
         VerifyPool* pool = pool_of(ctx);
         const size_t need = L.finite.size() * sizeof(JobArgs) + L.adj.size() * sizeof(AdjArgs) + L.prep.size() * sizeof(PrepArgs) +
                             n_eval * sizeof(EvalArgs) + 4096u;
-        stage_ok = pool->args_stage.reserve(need) == hipSuccess && pool->args_dev.reserve(need) == hipSuccess;
+        stage_ok = pool->args_stage[lane_now].reserve(need) == hipSuccess && pool->args_dev[lane_now].reserve(need) == hipSuccess;   // (the lane is idle)
       }
     }
     // more hypothesis evaluations than fit one launch's arguments (a batch of more than 16 frames): one launch all the same
@@ -2723,24 +2739,13 @@ struct Engine {
       uint32_t lds = 8192u;
       for (const EvalArgs& a : L.eval_small) lds = std::max(lds, a.lds_bytes);
       for (EvalArgs& a : L.eval_small) a.lds_bytes = lds;
-      // objects of more than 512 matches go to the kernel's wide instantiation (their own launch)
-      std::vector<EvalArgs> narrow, wide;
-      for (const EvalArgs& a : L.eval_small) (a.job.W <= 8u ? narrow : wide).push_back(a);
-      launch_evals(narrow, false, lds, false);
-      launch_evals(wide, true, lds, false);
+      // objects of more than 512 matches need the kernel's wide instantiation. It serves the smaller ones as well (6 % slower than
+      // their own instantiation): when a tick holds both kinds -- the frames of a batch reach objects of 340 and of 590 matches
+      // together -- one launch for all of them instead of two in a row, each as long as its slowest clique search
+      split_evals(L.eval_small, lds, false, launch_evals);
     }
-    {
-      std::vector<EvalArgs> narrow, wide;
-      for (const EvalArgs& a : L.eval_direct) (a.job.W <= 8u ? narrow : wide).push_back(a);
-      launch_evals(narrow, false, kEvalLdsBig, false);
-      launch_evals(wide, true, kEvalLdsBig, false);
-    }
-    {
-      std::vector<EvalArgs> narrow, wide;
-      for (const EvalArgs& a : L.eval_big) (a.job.W <= 8u ? narrow : wide).push_back(a);
-      launch_evals(narrow, false, kEvalLdsBig, true);
-      launch_evals(wide, true, kEvalLdsBig, true);
-    }
+    split_evals(L.eval_direct, kEvalLdsBig, false, launch_evals);
+    split_evals(L.eval_big, kEvalLdsBig, true, launch_evals);
     launch_list(st, growth_kernel, L.growth, 256, 0, 0, [](const GrowthArgs&) { return dim3(1); });
     launch_list<kWideSlots>(st, invalidate_kernel, L.inval_after, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
     launch_list<kManySlots>(st, round_prep_kernel<Slots<PrepArgs, kManySlots>>, L.prep_after, 256, 0, 1, [](const PrepArgs& a) { return dim3((a.job.n + 255u) / 256u); });
@@ -2773,15 +2778,28 @@ struct Engine {
     }
     return rc_run;
   }
-  // A tick = every ready slot issues the kernels of its next phase; the lists are launched once for all of them, the host
-  // waits and every slot consumes its results. Lock-step is cheap while the phases are short, but one slot's clique gate
-  // over a few hundred vertices (a single wave for ~1 ms) would hold up the 15 others whose next step takes 30 us, and the
-  // frames of a batch reach their big object at different ticks. Heavy phases therefore leave the lock-step: they are launched
-  // on one of a few side streams ("flights") and their slots rejoin when the flight's event has fired; the other slots keep
-  // ticking on the context's stream meanwhile. Nothing here changes what a slot computes or in which order it consumes it.
-  static constexpr uint32_t kHeavyN = 96;                  // matches of an object from which its evaluation / growth is a flight
-  struct Flight { hipStream_t st; hipEvent_t ev; std::vector<Slot*> slots; bool busy = false; std::atomic<bool>* taken = nullptr; };
-  static bool heavy(const Slot& s) { return (s.ph == PH_DRAW || s.ph == PH_EVAL2 || s.ph == PH_GROWTH) && s.job.n >= kHeavyN; }
+  // A launch group = the slots that are ready at one moment and in the same kind of phase: each issues the kernels of its next
+  // phase, the lists are launched once for all of them on an idle LANE (the context's stream, or one of the process's few side
+  // streams), an event is recorded, and when it has fired every slot of the group consumes its results. The host never blocks on one
+  // group while another could be consumed or launched: the frames of a batch reach their sprints, their big object's clique gates
+  // (a single wave for most of a millisecond) and its growth at different moments, and a kernel of one kind queued behind a long one
+  // of another kind on the same stream would wait for it. With one lane (a lone frame, or more than two batches in the air in this
+  // process: their contexts' streams already overlap each other) this is the plain lock-step tick: everything ready in one launch,
+  // one wait. Nothing here changes what a slot computes or in which order it consumes it.
+  static constexpr uint32_t kHeavyN = 96;                  // matches of an object from which its evaluation / growth is a kind of its own
+  enum Kind { K_LIGHT = 0, K_GROWTH = 1, K_SPRINT = 2, K_EVAL = 3, K_COUNT = 4 };
+  static Kind kind_of(const Slot& s) {
+    if (s.ph == PH_OBJECT) {                                // its next launch: a sprint, or the first evaluation of a big object
+      size_t i = s.oi;                                      // (the objects PH_OBJECT decides without a kernel are skipped)
+      while (i < s.objs.size() && !s.objs[i].resume && (s.objs[i].n < 3u || s.objs[i].nvalid < 3u || !s.objs[i].triangle)) ++i;
+      if (i >= s.objs.size()) return K_LIGHT;
+      if (sprint_on() && sprint_live(s.objs[i])) return K_SPRINT;
+      return s.objs[i].n >= kHeavyN ? K_EVAL : K_LIGHT;
+    }
+    if ((s.ph == PH_DRAW || s.ph == PH_EVAL2) && s.job.n >= kHeavyN) return K_EVAL;
+    if (s.ph == PH_GROWTH && s.job.n >= kHeavyN) return K_GROWTH;
+    return K_LIGHT;
+  }
   static uint32_t n_side_streams() {
     static const uint32_t n = [] {
       const char* e = getenv("TODHIP_VERIFY_FLIGHTS");
@@ -2795,120 +2813,95 @@ struct Engine {
              L.adj.size(), L.prep.size(), L.draw.size(), L.draw_small.size(), L.chain.size(), L.eval_small.size() + L.eval_direct.size(),
              L.eval_big.size(), L.growth.size(), L.inval.size(), L.sprint.size());
   }
+  struct Lane {
+    hipStream_t st; hipEvent_t ev; std::atomic<bool>* taken;   // taken: a side stream of the process, claimed while a group is on it
+    std::vector<Slot*> slots; bool busy = false; std::chrono::steady_clock::time_point t0; char what[128];
+  };
   int run_ticks(std::vector<Slot*>& slots) {
-    std::vector<Flight> flights;
     struct InAir { InAir() { n = g_batches_in_air.fetch_add(1) + 1; } ~InAir() { g_batches_in_air.fetch_sub(1); } int n; } in_air;
-    if (slots.size() > 1 && in_air.n <= 2) {
-      VerifyPool* pool = pool_of(ctx);
-      std::vector<hipStream_t> side;
-      SideStreams::PerDevice* pd = nullptr;
-      TOD_HIP(g_side_streams.get(ctx->device, n_side_streams(), side, &pd));
-      while (pool->side_ev.size() < side.size()) {
-        hipEvent_t e2;
-        TOD_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-        pool->side_ev.push_back(e2);
-      }
-      for (size_t i = 0; i < side.size(); ++i) flights.push_back({side[i], pool->side_ev[i], {}, false, &pd->taken[i]});
+    VerifyPool* pool = pool_of(ctx);
+    std::vector<hipStream_t> side;
+    SideStreams::PerDevice* pd = nullptr;
+    if (slots.size() > 1 && in_air.n <= 2 && n_side_streams() > 0) TOD_HIP(g_side_streams.get(ctx->device, n_side_streams(), side, &pd));
+    while (pool->side_ev.size() < side.size() + 1) {
+      hipEvent_t e2;
+      TOD_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+      pool->side_ev.push_back(e2);
     }
-    std::vector<Flight*> free_now;                          // streams taken for this iteration's heavy slots
+    std::vector<Lane> lanes(1 + side.size());
+    lanes[0].st = st; lanes[0].ev = pool->side_ev[0]; lanes[0].taken = nullptr;
+    for (size_t i = 0; i < side.size(); ++i) { lanes[1 + i].st = side[i]; lanes[1 + i].ev = pool->side_ev[1 + i]; lanes[1 + i].taken = &pd->taken[i]; }
     auto drain = [&]() {
-      for (Flight* fp : free_now) if (!fp->busy) fp->taken->store(false);
-      free_now.clear();
-      for (Flight& f : flights) if (f.busy) { (void)hipEventSynchronize(f.ev); f.busy = false; f.taken->store(false); }
+      for (Lane& ln : lanes) if (ln.busy) { (void)hipEventSynchronize(ln.ev); ln.busy = false; if (ln.taken) ln.taken->store(false); }
     };
 #define LOOP_HIP(expr) do { if ((expr) != hipSuccess) { drain(); return TODHIP_EHIP; } } while (0)
-    std::vector<Slot*> main_slots, heavy_now;
+    std::vector<Slot*> ready[K_COUNT];
     while (true) {
-      // flights that have landed: their slots consume and are ready again
-      for (Flight& f : flights) {
-        if (!f.busy) continue;
-        const hipError_t q = hipEventQuery(f.ev);
-        if (q == hipErrorNotReady) continue;
-        LOOP_HIP(q);
-        f.busy = false;
-        f.taken->store(false);
-        TOD_DBG("flight of %zu slot(s) landed", f.slots.size());
-        for (Slot* s : f.slots) { s->in_flight = false; if (s->ph != PH_DONE) consume(*s); }
-        f.slots.clear();
-      }
+      // groups that have landed: their slots consume and are ready again
       bool any_busy = false;
-      for (const Flight& f : flights) any_busy = any_busy || f.busy;
-      main_slots.clear(); heavy_now.clear();
-      bool any_live = false;
-      // Heavy phases fly only when that lets something else go on meanwhile: other slots with light phases to tick through, or
-      // flights already in the air. When all the ready slots arrive at a heavy phase together (frames with one object each, all of
-      // a size), one launch for all of them on the context's stream is the cheapest form there is.
-      bool mixed = any_busy;
-      if (!flights.empty() && !mixed) {
-        bool some_heavy = false, some_light = false;
-        for (Slot* s : slots) {
-          if (s->ph == PH_DONE || s->in_flight) continue;
-          if (heavy(*s)) some_heavy = true; else some_light = true;
-        }
-        mixed = some_heavy && some_light;
+      for (Lane& ln : lanes) {
+        if (!ln.busy) continue;
+        const hipError_t q = hipEventQuery(ln.ev);
+        if (q == hipErrorNotReady) { any_busy = true; continue; }
+        LOOP_HIP(q);
+        ln.busy = false;
+        if (ln.taken) ln.taken->store(false);
+        if (tod_debug())
+          TOD_DBG("tick %.1f us: %s (lane %zu, %zu slots)", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ln.t0).count(),
+                  ln.what, (size_t)(&ln - lanes.data()), ln.slots.size());
+        for (Slot* s : ln.slots) { s->in_flight = false; if (s->ph != PH_DONE) consume(*s); }
+        ln.slots.clear();
+        TOD_DBG("consumed");
       }
-      // streams this context can have right now (another context may hold them): taken here, given back when unused or landed
-      free_now.clear();
-      if (mixed)
-        for (Flight& f : flights) {
-          bool expected = false;
-          if (!f.busy && f.taken->compare_exchange_strong(expected, true)) free_now.push_back(&f);
-        }
-      const size_t n_free = free_now.size();
+      for (auto& r : ready) r.clear();
+      size_t n_ready = 0;
       for (Slot* s : slots) {
         if (s->ph == PH_DONE || s->in_flight) continue;
-        any_live = true;
-        if (mixed && heavy(*s) && (n_free || any_busy)) {   // no stream to be had, but one of ours is in the air: it waits for that
-          if (n_free) heavy_now.push_back(s);
-          continue;
-        }
-        issue(*s);
-        if (s->ph != PH_DONE) main_slots.push_back(s);
+        ready[lanes.size() > 1 ? kind_of(*s) : K_LIGHT].push_back(s);
+        ++n_ready;
       }
-      if (!any_live && !any_busy) break;
-      char what[128] = "";
-      std::chrono::steady_clock::time_point t0;
-      if (tod_debug()) { describe(what, sizeof(what)); t0 = std::chrono::steady_clock::now(); }
-      if (!main_slots.empty()) { launch_all(st); LOOP_HIP(hipGetLastError()); ctx->counters.last_verify_ticks += 1; }
-      else L = Launches();
-      if (!heavy_now.empty()) {
-        const size_t per = (heavy_now.size() + n_free - 1) / n_free;
-        size_t next = 0;
-        for (Flight* fp : free_now) {
-          Flight& f = *fp;
-          if (next >= heavy_now.size()) continue;
-          for (size_t i = 0; i < per && next < heavy_now.size(); ++i, ++next) {
-            Slot* s = heavy_now[next];
-            issue(*s);
-            if (s->ph != PH_DONE) { s->in_flight = true; f.slots.push_back(s); }
-          }
-          if (f.slots.empty()) { L = Launches(); continue; }
-          if (tod_debug()) { char w2[128]; describe(w2, sizeof(w2)); TOD_DBG("flight of %zu slot(s): %s", f.slots.size(), w2); }
-          launch_all(f.st);
-          LOOP_HIP(hipGetLastError());
-          LOOP_HIP(hipEventRecord(f.ev, f.st));
-          f.busy = true; any_busy = true;
+      if (n_ready == 0 && !any_busy) break;
+      // every kind of ready slots takes an idle lane of its own; a kind that finds none waits for the next landing
+      bool launched = false;
+      for (int k = 0; k < K_COUNT && n_ready; ++k) {
+        if (ready[k].empty()) continue;
+        Lane* ln = nullptr;
+        for (Lane& c : lanes) {
+          if (c.busy) continue;
+          if (c.taken) { bool expected = false; if (!c.taken->compare_exchange_strong(expected, true)) continue; }   // another context has it
+          ln = &c;
+          break;
         }
+        if (!ln) break;
+        lane_now = (size_t)(ln - lanes.data());
+        for (Slot* s : ready[k]) {
+          issue(*s);
+          if (s->ph != PH_DONE) { s->in_flight = true; ln->slots.push_back(s); }
+        }
+        if (ln->slots.empty()) { L = Launches(); if (ln->taken) ln->taken->store(false); launched = true; continue; }   // (they finished without a kernel)
+        if (tod_debug()) { describe(ln->what, sizeof(ln->what)); ln->t0 = std::chrono::steady_clock::now(); }
+        launch_all(ln->st);
+        const hipError_t e1 = hipGetLastError();
+        const hipError_t e2 = e1 == hipSuccess ? hipEventRecord(ln->ev, ln->st) : e1;
+        if (e2 != hipSuccess) { if (ln->taken) ln->taken->store(false); for (Slot* s : ln->slots) s->in_flight = false; ln->slots.clear(); drain(); return TODHIP_EHIP; }
+        ln->busy = true;
+        launched = true;
+        ctx->counters.last_verify_ticks += 1;
       }
-      for (Flight* fp : free_now) if (!fp->busy) fp->taken->store(false);   // taken but not needed
-      free_now.clear();
-      if (!main_slots.empty()) {
-        LOOP_HIP(hipStreamSynchronize(st));
-        if (tod_debug())
-          TOD_DBG("tick %.1f us: %s", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
-        for (Slot* s : main_slots)
-          if (s->ph != PH_DONE) consume(*s);
-      } else if (any_busy) {                                 // nothing but flights: wait for the first one to land
-        bool landed = false;
-        while (!landed) {
-          for (Flight& f : flights) {
-            if (!f.busy) continue;
-            const hipError_t q = hipEventQuery(f.ev);
-            if (q == hipSuccess) { landed = true; break; }
-            if (q != hipErrorNotReady) LOOP_HIP(q);
-          }
-          if (!landed) std::this_thread::yield();
+      if (launched) continue;                                // (slots that finished without a kernel may be ready for more)
+      // nothing could be launched: wait for the first group to land
+      bool landed = false;
+      while (!landed) {
+        bool busy_now = false;
+        for (Lane& ln : lanes) {
+          if (!ln.busy) continue;
+          busy_now = true;
+          const hipError_t q = hipEventQuery(ln.ev);
+          if (q == hipSuccess) { landed = true; break; }
+          if (q != hipErrorNotReady) LOOP_HIP(q);
         }
+        if (!busy_now) break;                                // every lane is idle (another context holds the side streams): try again
+        if (!landed) std::this_thread::yield();
       }
     }
 #undef LOOP_HIP
@@ -2927,7 +2920,8 @@ void tod_verify_ws_free(todhip_ctx* ctx) {
   for (VerifyWs* ws : p->slots) { ws->release(); delete ws; }
   for (StreamCache* c : p->streams) { c->dev.release(); delete c; }
   for (hipEvent_t e : p->side_ev) (void)hipEventDestroy(e);
-  p->args_stage.release(); p->args_dev.release(); p->kceil.release();
+  for (size_t i = 0; i < VerifyPool::kMaxLanes; ++i) { p->args_stage[i].release(); p->args_dev[i].release(); }
+  p->kceil.release();
   delete p;
   ctx->verify_ws = nullptr;
 }

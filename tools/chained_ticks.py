@@ -22,12 +22,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         sys.stderr.write("=== TOTAL %.1f ms\n" % ((time.perf_counter() - t) * 1e3))
     sys.exit(0)
 for B in (1, 16):
-    env = dict(os.environ, TODHIP_DEBUG="1")
+    env = dict(os.environ, TODHIP_DEBUG=os.environ.get("CHAINED_TICKS_LEVEL", "1"))   # 2: also rounds and draw windows (slows the host down)
     p = subprocess.run([sys.executable, __file__, "child", str(B)], env=env, capture_output=True, text=True)
     log = p.stderr.split("=== REP 1")[-1]
     if os.environ.get("CHAINED_TICKS_RAW"):
         open(os.environ["CHAINED_TICKS_RAW"] + ".B%d" % B, "w").write(log)
-    ticks = re.findall(r"tick ([0-9.]+) us: (.*)", log)
+    ticks = [(us, re.sub(r" \(lane.*", "", what)) for us, what in re.findall(r"tick ([0-9.]+) us: (.*)", log)]
     total = re.findall(r"=== TOTAL ([0-9.]+) ms", log)
     by = collections.defaultdict(lambda: [0, 0.0])
     for us, what in ticks:
