@@ -92,6 +92,8 @@ def parse():
     ap.add_argument("--serial-exchange", action="store_true",
                     help="several ranks: issue the collectives on the matcher's stream, in program order (gather -> match -> "
                          "exchange -> merge), instead of on their own stream where they overlap the neighbouring DB passes")
+    ap.add_argument("--latency-cus", type=int, default=0, help="reserve this many compute units for the latency-bound stages' streams "
+                    "(todhip_set_cu_partition): ORB and verifier kernels then never share a SIMD with the matcher's DB pass")
     ap.add_argument("--iterations", type=int, default=2500, help="n_ransac_iterations (conf/detection.ork:38)")
     ap.add_argument("--min-inliers", type=int, default=8, help="min_inliers (conf/detection.ork:39)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
@@ -260,10 +262,17 @@ def launch_ms(c0, c1):
 _STREAMS = {}
 
 
+_LATENCY_CUS = 0                                                          # --latency-cus: the CU partition (todhip_set_cu_partition)
+
+
 def pooled_stream(torch, role, index=0, priority=0):
     key = (role, index)
     if key not in _STREAMS:
-        _STREAMS[key] = torch.cuda.Stream(priority=priority)
+        if _LATENCY_CUS > 0:                                                  # the matcher on most of the chip, ORB and the verifier on the rest
+            from tod_amd import capi
+            _STREAMS[key] = torch.cuda.ExternalStream(capi.stream_create(torch.cuda.current_device(), latency=(role != "match")))
+        else:
+            _STREAMS[key] = torch.cuda.Stream(priority=priority)
     return _STREAMS[key]
 
 
@@ -634,6 +643,10 @@ def main():
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    if args.latency_cus > 0:
+        global _LATENCY_CUS
+        _LATENCY_CUS = args.latency_cus
+        capi.set_cu_partition(args.latency_cus)
     # TOD_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, collectives, shard + merge) with one rank --
     # the only way to exercise the RCCL calls on a 1-GPU box
     use_dist = world > 1 or os.environ.get("TOD_BENCH_FORCE_DIST") == "1"

@@ -76,6 +76,17 @@ void* todhip_stream(todhip_ctx*);
 int  todhip_last_hip_error(const todhip_ctx*);
 int  todhip_synchronize(todhip_ctx*);
 int  todhip_get_counters(todhip_ctx*, todhip_counters* out);
+/* Streams for contexts that run side by side (a pipeline: ORB, matcher and verifier contexts, each on a stream of its own, as
+ * bench.py and tod_amd/pipeline.py drive them). todhip_set_cu_partition(n) reserves the device's last n compute units for
+ * TODHIP_STREAM_LATENCY streams (the short, latency-bound kernels of ORB and of the verifier -- a single wave for hundreds of
+ * microseconds -- which otherwise share every SIMD with the matcher's chip-filling DB pass); TODHIP_STREAM_THROUGHPUT streams get
+ * the other compute units. n = 0 (the default, or the environment's TODHIP_LATENCY_CUS): no partition, latency streams are plain
+ * high-priority streams. Process-wide; set it before the first stream is created (the verifier's own side streams are latency
+ * streams, created on first use). A multiple of 8 takes the same share of every XCD. */
+enum { TODHIP_STREAM_THROUGHPUT = 0, TODHIP_STREAM_LATENCY = 1 };
+int  todhip_set_cu_partition(uint32_t latency_cus);
+int  todhip_stream_create(int device, int kind, void** stream_out);
+int  todhip_stream_destroy(void* stream);
 int  todhip_set_kernel_timing(todhip_ctx*, int enable);   /* bracket the matcher kernel with HIP events */
 /* The exact Hamming search of todhip_match* exists twice, with identical results: on the vector ALU (xor + popcount,
  * partial-distance elimination: data dependent) and on the matrix cores (bits as +-1 MX-fp4 values, dot = 256 - 2 d:

@@ -53,7 +53,7 @@ class Counters(C.Structure):
 # every symbol include/todhip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "todhip_version", "todhip_create", "todhip_destroy", "todhip_stream", "todhip_last_hip_error",
-    "todhip_synchronize", "todhip_get_counters", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_set_ratio_test", "todhip_db_load", "todhip_db_info",
+    "todhip_synchronize", "todhip_get_counters", "todhip_set_cu_partition", "todhip_stream_create", "todhip_stream_destroy", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_set_ratio_test", "todhip_db_load", "todhip_db_info",
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device", "todhip_merge_shards_device_on",
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_orb_masked", "todhip_test_clique", "todhip_test_clique_gate",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
@@ -385,7 +385,10 @@ class Context:
         n_poses = C.c_uint32(cap_p)
         pose_ptr = (C.c_uint32 * (n_frames + 1))()
         cap = max(nq, 1) * cap_p
-        inl = np.zeros(cap, np.uint32)
+        if getattr(self, "_inl_cap", 0) < cap:                # (a megabyte per call otherwise: kept per context, results are copied out)
+            self._inl = np.zeros(cap, np.uint32)
+            self._inl_cap = cap
+        inl = self._inl
         n_inl = C.c_uint32(cap)
         if depth is None:
             rc = lib().todhip_verify_batch_device(self._h, C.c_uint32(n_frames), C.c_void_p(d_kp_xy), C.c_uint32(nq),
@@ -557,6 +560,18 @@ class Model:
         if self._h:
             lib().todhip_model_free(self._ctx._h, self._h)
             self._h = C.c_void_p()
+
+
+def set_cu_partition(latency_cus):
+    """Reserve the device's last `latency_cus` compute units for latency streams (todhip_set_cu_partition); 0 = none."""
+    _check(lib().todhip_set_cu_partition(C.c_uint32(latency_cus)), "todhip_set_cu_partition")
+
+
+def stream_create(device=0, latency=False):
+    """A HIP stream handle (int) of the given kind, honouring the CU partition (todhip_stream_create)."""
+    out = C.c_void_p()
+    _check(lib().todhip_stream_create(C.c_int(device), C.c_int(1 if latency else 0), C.byref(out)), "todhip_stream_create")
+    return out.value
 
 
 def rng_new(seed=1):

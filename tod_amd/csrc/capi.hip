@@ -2,10 +2,13 @@
 // and the host-buffer / device-buffer forms of the matcher. The verifier and ORB entry points live
 // in verify.hip and orb.hip.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <new>
+#include <vector>
 
 #include "ctx.h"
 
@@ -60,6 +63,55 @@ void todhip_destroy(todhip_ctx* ctx) {
     if (ctx->evp[i]) (void)hipEventDestroy(ctx->evp[i]);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+// ---- CU partition: the short, latency-bound kernels (ORB, verifier, merges) beside the matcher's chip-filling DB pass.
+// A wave of theirs shares its SIMD with resident matcher waves and its kernels run several times stretched; with a partition the
+// last `latency_cus` compute units take no matcher waves at all (hipExtStreamCreateWithCUMask: a queue's waves only go to the CUs
+// of its mask; the runtime deals the mask's bits round robin over the XCDs, so a multiple of 8 takes the same share of each).
+static std::atomic<uint32_t> g_latency_cus{0xFFFFFFFFu};     // 0xFFFFFFFF: not set yet (environment TODHIP_LATENCY_CUS, else 0)
+static uint32_t latency_cus_now() {
+  uint32_t v = g_latency_cus.load();
+  if (v == 0xFFFFFFFFu) {
+    const char* e = getenv("TODHIP_LATENCY_CUS");
+    v = e ? (uint32_t)strtoul(e, nullptr, 10) : 0u;
+    g_latency_cus.store(v);
+  }
+  return v;
+}
+int todhip_set_cu_partition(uint32_t latency_cus) { g_latency_cus.store(latency_cus); return TODHIP_OK; }
+
+hipError_t tod_stream_create(hipStream_t* out, int device, int kind) {
+  const uint32_t lat = latency_cus_now();
+  int n_cu = 0;
+  hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
+  if (e != hipSuccess) return e;
+  if (lat == 0u || lat >= (uint32_t)n_cu) {
+    if (kind == TODHIP_STREAM_LATENCY) {
+      int least = 0, greatest = 0;                          // latency-bound work: the highest priority there is
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+      return hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest);
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  }
+  const uint32_t words = ((uint32_t)n_cu + 31u) / 32u;
+  std::vector<uint32_t> mask(words, 0u);
+  const uint32_t lo = kind == TODHIP_STREAM_LATENCY ? (uint32_t)n_cu - lat : 0u, hi = kind == TODHIP_STREAM_LATENCY ? (uint32_t)n_cu : (uint32_t)n_cu - lat;
+  for (uint32_t b = lo; b < hi; ++b) mask[b >> 5] |= 1u << (b & 31u);
+  return hipExtStreamCreateWithCUMask(out, words, mask.data());
+}
+
+int todhip_stream_create(int device, int kind, void** stream_out) {
+  if (!stream_out || (kind != TODHIP_STREAM_THROUGHPUT && kind != TODHIP_STREAM_LATENCY)) return TODHIP_EINVAL;
+  if (hipSetDevice(device) != hipSuccess) return TODHIP_EHIP;
+  hipStream_t st = nullptr;
+  if (tod_stream_create(&st, device, kind) != hipSuccess) return TODHIP_EHIP;
+  *stream_out = (void*)st;
+  return TODHIP_OK;
+}
+int todhip_stream_destroy(void* stream) {
+  if (!stream) return TODHIP_EINVAL;
+  return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? TODHIP_OK : TODHIP_EHIP;
 }
 
 void* todhip_stream(todhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

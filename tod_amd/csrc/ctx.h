@@ -109,6 +109,8 @@ struct todhip_ctx {
   void* lsh_ws = nullptr;
 };
 
+// capi.hip: a stream of the given kind (todhip_stream_create), honouring the process's CU partition
+extern "C" hipError_t tod_stream_create(hipStream_t* out, int device, int kind);
 // match.hip
 int tod_timing_begin(todhip_ctx* ctx, int* slot);
 int tod_timing_end(todhip_ctx* ctx, int slot);

@@ -1826,10 +1826,8 @@ struct SideStreams {
     std::lock_guard<std::mutex> g(mu);
     PerDevice& d = by_device[device];
     while (d.st.size() < n) {
-      int least = 0, greatest = 0;                          // latency-bound work: the highest priority there is
-      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
-      hipStream_t s2;
-      const hipError_t e = hipStreamCreateWithPriority(&s2, hipStreamNonBlocking, greatest);
+      hipStream_t s2;                                       // latency-bound work: the highest priority there is, or the CU partition's
+      const hipError_t e = tod_stream_create(&s2, device, TODHIP_STREAM_LATENCY);
       if (e != hipSuccess) return e;
       d.st.push_back(s2);
     }
