@@ -73,10 +73,30 @@ inline double dbg_us() {
   static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 }
+inline int dbg_thread() { static std::atomic<int> next{0}; thread_local int id = next.fetch_add(1); return id; }   // which host thread (= which context's batch)
 #define TOD_DBG2(...) do { if (tod_debug_level() > 1) { fprintf(stderr, "[todhip %.0f] ", dbg_us()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
-#define TOD_DBG(...) do { if (tod_debug()) { fprintf(stderr, "[todhip %.0f] ", dbg_us()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+#define TOD_DBG(...) do { if (tod_debug()) { char b_[512]; int n_ = snprintf(b_, sizeof(b_), "[todhip %.0f] ", dbg_us()); n_ += snprintf(b_ + n_, sizeof(b_) - n_, __VA_ARGS__); \
+    snprintf(b_ + std::min<int>(n_, (int)sizeof(b_) - 16), 16, " {t%d}\n", dbg_thread()); fputs(b_, stderr); } } while (0)   /* one write per line: threads do not interleave */
 
 // ------------------------------------------------------------------------------------------------ K6
+// one pair of FillAdjacency (adjacency_ransac.cpp:136-166): q / t = query / training point, k = keypoint pixel of the two matches
+__device__ __forceinline__ void pair_test(const float* q1, const float* q2, const float* t1, const float* t2, const float* k1, const float* k2,
+                                          float span, float err, bool& phys, bool& samp) {
+  phys = false; samp = false;
+  float dq = dist_sq3(q1, q2);
+  const float lim = (span + 2 * err) * (span + 2 * err);
+  if (!(dq > lim)) {                                      // adjacency_ransac.cpp:144
+    dq = sqrtf(dq);
+    const float dt = (float)norm3d(t1[0] - t2[0], t1[1] - t2[1], t1[2] - t2[2]);
+    const float a = fabsf(dt - dq);
+    if (!(a > 4 * err)) {                                 // :151
+      phys = true;
+      const float px = (k1[0] - k2[0]) * (k1[0] - k2[0]) + (k1[1] - k2[1]) * (k1[1] - k2[1]);
+      samp = (px > 20 * 20) && (a < 2 * err);             // :158-161
+    }
+  }
+}
+
 template <class H>
 __global__ __launch_bounds__(256) void adjacency_kernel(H S) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
@@ -90,22 +110,8 @@ __global__ __launch_bounds__(256) void adjacency_kernel(H S) {
   bool phys = false, samp = false;
   if (j < job.n && j != i) {
     const uint32_t lo = min(i, j), hi = max(i, j);       // the reference visits each pair once with i < j
-    float dq = dist_sq3(job.query + 3 * lo, job.query + 3 * hi);
-    const float lim = (span + 2 * err) * (span + 2 * err);
-    if (!(dq > lim)) {                                    // adjacency_ransac.cpp:144
-      dq = sqrtf(dq);
-      const float* t1 = job.train + 3 * lo;
-      const float* t2 = job.train + 3 * hi;
-      const float dt = (float)norm3d(t1[0] - t2[0], t1[1] - t2[1], t1[2] - t2[2]);
-      const float a = fabsf(dt - dq);
-      if (!(a > 4 * err)) {                               // :151
-        phys = true;
-        const float* k1 = job.kpxy + 2 * lo;
-        const float* k2 = job.kpxy + 2 * hi;
-        const float px = (k1[0] - k2[0]) * (k1[0] - k2[0]) + (k1[1] - k2[1]) * (k1[1] - k2[1]);
-        samp = (px > 20 * 20) && (a < 2 * err);           // :158-161
-      }
-    }
+    pair_test(job.query + 3 * lo, job.query + 3 * hi, job.train + 3 * lo, job.train + 3 * hi, job.kpxy + 2 * lo, job.kpxy + 2 * hi, span, err,
+              phys, samp);
   }
   const u64 pb = __ballot(phys), sb = __ballot(samp);
   if (lane_id() == 0) {
@@ -1658,6 +1664,58 @@ __global__ __launch_bounds__(256) void invalidate_kernel(Slots<InvArgs, kWideSlo
   }
 }
 
+// finite_kernel + adjacency_kernel + round_prep_kernel for an object of at most 64 matches, by ONE wave: lane j = match j, row i of
+// both bit matrices is one ballot, and the first round's statistics come from the rows in registers. A frame of self-similar texture
+// has ~190 such objects and one big one: three dependent launches of ~2000 mostly empty blocks per frame become one launch of one
+// wave per object (inside the pipeline, beside the matcher's resident grid, every dependent launch and every block costs a multiple
+// of what it costs alone).
+struct PrepSmallArgs { ObjJob job; uint32_t* stats; float span, err; };
+template <class H>
+__global__ __launch_bounds__(64) void small_prep_kernel(H S) {
+  TOD_LATENCY_PRIO();
+  const PrepSmallArgs& A = S.a[blockIdx.y];
+  const ObjJob& job = A.job;
+  const uint32_t n = job.n, l = lane_id();
+  const float span = A.span, err = A.err;
+  float q[3] = {0.f, 0.f, 0.f}, t[3] = {0.f, 0.f, 0.f}, kp[2] = {0.f, 0.f};
+  if (l < n) {
+    for (int c = 0; c < 3; ++c) { q[c] = job.query[3 * l + c]; t[c] = job.train[3 * l + c]; }
+    kp[0] = job.kpxy[2 * l]; kp[1] = job.kpxy[2 * l + 1];
+  }
+  bool fin = l < n;
+  for (int c = 0; c < 3; ++c) fin = fin && isfinite(t[c]) && isfinite(q[c]);
+  const u64 finite = __ballot(fin);
+  const u64 valid = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+  u64 my_phys = 0ull, my_samp = 0ull;
+  for (uint32_t i = 0; i < n; ++i) {                       // row i: the pair (i, lane)
+    float qi[3], ti[3], ki[2];
+    for (int c = 0; c < 3; ++c) { qi[c] = __shfl(q[c], (int)i); ti[c] = __shfl(t[c], (int)i); }
+    ki[0] = __shfl(kp[0], (int)i); ki[1] = __shfl(kp[1], (int)i);
+    bool ph = false, sa = false;
+    if (l < n && l != i) {
+      if (i < l) pair_test(qi, q, ti, t, ki, kp, span, err, ph, sa);   // the reference visits each pair once with i < j
+      else pair_test(q, qi, t, ti, kp, ki, span, err, ph, sa);
+    }
+    const u64 pb = __ballot(ph), sb = __ballot(sa);
+    if (l == i) { my_phys = pb; my_samp = sb; }
+  }
+  const bool isv = l < n;
+  const uint32_t d = isv ? (uint32_t)__popcll(my_samp & valid) : 0u;
+  const u64 deg7 = __ballot(isv && d >= kGateMinimal);
+  const uint32_t degsum = wave_sum(d);
+  bool on_tri = false;                                     // (wave-uniform loop: cross-lane reads need every lane active)
+  for (uint32_t o = 0; o < n; ++o) {
+    const u64 ro = rdlane64(my_samp, o);
+    on_tri = on_tri || (((my_samp >> o) & 1ull) && (my_samp & ro & valid) != 0ull);
+  }
+  const bool triangle = __ballot(on_tri) != 0ull;
+  if (l < n) { job.phys[l] = my_phys; job.samp[l] = my_samp; job.sampdeg[l] = d; }
+  if (l == 0u) {
+    job.finite[0] = finite; job.valid[0] = valid; job.deg7[0] = deg7;
+    A.stats[0] = n; A.stats[1] = degsum; A.stats[2] = triangle ? 1u : 0u;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ K_c
 // ClusterPerObject (adjacency_ransac.cpp:176-205) for device-resident inputs. Matches arrive in the matcher's
 // fixed-stride layout (k slots per query, counts[q] used); the flat order (query asc, rank asc) is what the
@@ -1777,13 +1835,132 @@ __global__ __launch_bounds__(256) void cluster_group_kernel(Slots<GroupArgs> SL)
   kpxy[2 * d] = fkp[2 * f]; kpxy[2 * d + 1] = fkp[2 * f + 1];
 }
 
+// ClusterPerObject of one frame in ONE launch of one block (the four kernels above are its parts, kept for the launch-group of a
+// frame whose match list does not fit one block's patience: none today): lookup -> scan -> scatter + histogram -> object offsets
+// -> stable grouping, with the histogram and the frame's totals written straight into the slot's mailbox. Inside the pipeline
+// every dependent launch waits for wave slots beside the matcher's resident grid: five dependent launches and a host round trip
+// between the scatter and the grouping were 0.4-0.5 ms per batch there (45 us alone).
+struct ClusterArgs {
+  const float* kp_xy; const float* cloud; const void* depth; const uint32_t* counts; const todhip_dmatch* matches; const float* mxyz;
+  uint32_t nq, k, H, Wimg, n_objs; int depth_is_u16; float fx, fy, cx, cy;
+  uint32_t *kept, *offs, *obj_of, *src, *hist, *goff, *cnt; float* qpt;          // device scratch
+  float *train, *query, *kpxy; uint32_t* qidx;                                    // grouped outputs
+  uint32_t *m_hist, *m_ctl;                                                       // mailbox (pinned): histogram; [0] error, [4] n_all
+};
+__global__ __launch_bounds__(256) void cluster_frame_kernel(Slots<ClusterArgs> SL) {
+  TOD_LATENCY_PRIO();
+  const ClusterArgs& a = SL.a[blockIdx.x];
+  __shared__ uint32_t part[256], s_o[256], s_err, s_total;
+  const uint32_t tid = threadIdx.x, nq = a.nq, k = a.k, n_objs = a.n_objs;
+  if (tid == 0) s_err = 0u;
+  for (uint32_t o = tid; o < n_objs; o += 256u) { a.hist[o] = 0u; a.cnt[o] = 0u; }
+  __syncthreads();
+  // ---- the keypoint's 3D point (adjacency_ransac.cpp:184-189), see cluster_lookup_kernel
+  for (uint32_t q = tid; q < nq; q += 256u) {
+    const int row = (int)a.kp_xy[2 * q + 1], col = (int)a.kp_xy[2 * q];    // float -> int truncation (:185)
+    if (row < 0 || col < 0 || (uint32_t)row >= a.H || (uint32_t)col >= a.Wimg) { atomicExch(&s_err, 1u); a.kept[q] = 0; continue; }
+    float x, y, z;
+    if (a.cloud) {
+      const float* p = a.cloud + 3 * ((size_t)row * a.Wimg + col);
+      x = p[0]; y = p[1]; z = p[2];
+    } else {
+      if (a.depth_is_u16) {
+        const uint16_t d = reinterpret_cast<const uint16_t*>(a.depth)[(size_t)row * a.Wimg + col];
+        z = d == 0 ? __builtin_nanf("") : (float)d * 0.001f;
+      } else {
+        z = reinterpret_cast<const float*>(a.depth)[(size_t)row * a.Wimg + col];
+      }
+      x = ((float)col - a.cx) * z / a.fx; y = ((float)row - a.cy) * z / a.fy;
+    }
+    a.qpt[3 * q] = x; a.qpt[3 * q + 1] = y; a.qpt[3 * q + 2] = z;
+    a.kept[q] = isnan(x) ? 0u : a.counts[q];                               // only .x is tested (:189)
+  }
+  __syncthreads();
+  // ---- exclusive scan of kept -> offs: the flat order (query asc, rank asc) of the reference's push_back
+  {
+    const uint32_t chunk = (nq + 255u) / 256u;
+    const uint32_t lo = min(nq, tid * chunk), hi = min(nq, lo + chunk);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += a.kept[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (uint32_t i = 0; i < 256u; ++i) { const uint32_t c = part[i]; part[i] = acc; acc += c; }
+      s_total = acc;
+    }
+    __syncthreads();
+    uint32_t acc = part[tid];
+    for (uint32_t i = lo; i < hi; ++i) { a.offs[i] = acc; acc += a.kept[i]; }
+  }
+  const uint32_t n_all = s_total;
+  __syncthreads();
+  // ---- every match's flat slot, object and source; histogram per object
+  for (uint32_t t = tid; t < nq * k; t += 256u) {
+    const uint32_t q = t / k, j = t % k;
+    if (j >= a.kept[q]) continue;
+    const uint32_t f = a.offs[q] + j;
+    const todhip_dmatch m = a.matches[t];
+    uint32_t o = (uint32_t)m.imgIdx;
+    if (m.imgIdx < 0 || o >= n_objs) { atomicExch(&s_err, 2u); o = 0; }
+    a.obj_of[f] = o; a.src[f] = t;
+    atomicAdd(&a.hist[o], 1u);
+  }
+  __threadfence();
+  __syncthreads();
+  // ---- object offsets = exclusive scan of the histogram; the histogram goes to the host
+  {
+    const uint32_t chunk = (n_objs + 255u) / 256u;
+    const uint32_t lo = min(n_objs, tid * chunk), hi = min(n_objs, lo + chunk);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += __hip_atomic_load(a.hist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (uint32_t i = 0; i < 256u; ++i) { const uint32_t c = part[i]; part[i] = acc; acc += c; }
+    }
+    __syncthreads();
+    uint32_t acc = part[tid];
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint32_t h = __hip_atomic_load(a.hist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a.goff[i] = acc; a.m_hist[i] = h;
+      acc += h;
+    }
+  }
+  __syncthreads();
+  // ---- stable grouping by object, 256 flat slots at a time: destination = object offset + matches of the object in earlier
+  // chunks (cnt) + earlier matches of the object in this chunk
+  for (uint32_t base = 0; base < n_all; base += 256u) {
+    const uint32_t f = base + tid;
+    const bool have = f < n_all;
+    const uint32_t o = have ? a.obj_of[f] : 0xFFFFFFFFu;
+    s_o[tid] = o;
+    __syncthreads();
+    if (have) {
+      uint32_t before = 0, after = 0;
+      for (uint32_t u = 0; u < tid; ++u) before += s_o[u] == o;
+      for (uint32_t u = tid + 1u; u < 256u; ++u) after += s_o[u] == o;
+      const uint32_t seen = a.cnt[o];                       // (written by the chunk before, behind a barrier)
+      const uint32_t d = a.goff[o] + seen + before;
+      const uint32_t t = a.src[f], q = t / k;
+      for (int c = 0; c < 3; ++c) { a.train[3 * d + c] = a.mxyz[(size_t)t * 3 + c]; a.query[3 * d + c] = a.qpt[3 * q + c]; }
+      a.qidx[d] = q;
+      a.kpxy[2 * d] = a.kp_xy[2 * q]; a.kpxy[2 * d + 1] = a.kp_xy[2 * q + 1];
+      if (after == 0u) a.cnt[o] = seen + before + 1u;       // the object's last match of the chunk
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { a.m_ctl[0] = s_err; a.m_ctl[4] = n_all; }
+}
+
 #include "verify_sprint.h"
 
 // ------------------------------------------------------------------------------------------------ host side
 struct VerifyWs {
   DevBuf train, query, qidx, kpxy, phys, samp, bits, sampdeg, nvalid, rnd, table, iter_samples, counts, gate_m,
       small, deferred, stacks, kp_bits, clique_adj, adjc_scratch, c_kept, c_offs, c_qpt, c_obj, c_hist, c_goff, f_train,
-      f_query, f_qidx, f_kp, sprint_status, sprint_stack;
+      f_query, f_qidx, f_kp, sprint_status, sprint_stack, c_src, c_cnt;
   // the slot's mailbox: pinned host memory that kernels read and write directly (see copy_words_kernel)
   HostBuf m_small, m_hist, m_goff, m_rnd, m_pos, m_counts, m_kp, m_nvalid;
   HostBuf m_sprint, m_sprint_out, m_sprint_kp;              // sprint_kernel: the object list in, records and keypoint lists out
@@ -1791,7 +1968,7 @@ struct VerifyWs {
   void release() {
     DevBuf* bufs[] = {&train, &query, &qidx, &kpxy, &phys, &samp, &bits, &sampdeg, &nvalid, &rnd, &table, &iter_samples, &counts, &gate_m,
                       &small, &deferred, &stacks, &kp_bits, &clique_adj, &adjc_scratch, &c_kept, &c_offs, &c_qpt, &c_obj, &c_hist,
-                      &c_goff, &f_train, &f_query, &f_qidx, &f_kp, &sprint_status, &sprint_stack};
+                      &c_goff, &f_train, &f_query, &f_qidx, &f_kp, &sprint_status, &sprint_stack, &c_src, &c_cnt};
     for (DevBuf* b : bufs) b->release();
     HostBuf* hb[] = {&m_small, &m_hist, &m_goff, &m_rnd, &m_pos, &m_counts, &m_kp, &m_nvalid, &h_small, &m_sprint, &m_sprint_out, &m_sprint_kp};
     for (HostBuf* b : hb) b->release();
@@ -2015,6 +2192,7 @@ struct Launches {
   std::vector<std::pair<StreamCache*, uint64_t>> draw_src, draw_small_src; std::vector<EvalArgs> eval_small, eval_big, eval_direct;
   std::vector<GrowthArgs> growth;
   std::vector<SprintArgs> sprint; std::vector<StreamCache*> sprint_src;
+  std::vector<ClusterArgs> cluster; std::vector<PrepSmallArgs> prep_small;
 };
 
 // launch `kern` over the argument sets of v, kMaxSlots at a time; extent(a) = blocks one set needs in x (and y)
@@ -2140,20 +2318,17 @@ struct Engine {
   void issue(Slot& s) {
     VerifyWs* ws = s.ws;
     uint32_t* d_small = ws->small.as<uint32_t>();
-    if (s.ph == PH_CLUSTER) {
-      L.zero.push_back({nullptr, d_small + 60, 1u});
-      L.zero.push_back({nullptr, ws->c_hist.as<uint32_t>(), n_objs});
-      LookupArgs la = {s.d_kp_xy, nq, s.use_depth ? nullptr : s.d_cloud, s.dep.d_depth, s.dep.is_u16, H, Wimg, s.dep.fx, s.dep.fy,
-                       s.dep.cx, s.dep.cy, s.d_counts, ws->c_kept.as<uint32_t>(), ws->c_qpt.as<float>(), d_small + 60};
-      L.lookup.push_back(la);
-      L.scan.push_back({ws->c_kept.as<uint32_t>(), nq, ws->c_offs.as<uint32_t>()});
-      ScatterArgs sa = {s.d_kp_xy, nq, k, s.d_matches, s.d_mxyz, ws->c_kept.as<uint32_t>(), ws->c_offs.as<uint32_t>(),
-                        ws->c_qpt.as<float>(), n_objs, ws->c_obj.as<uint32_t>(), ws->c_hist.as<uint32_t>(), ws->f_train.as<float>(),
-                        ws->f_query.as<float>(), ws->f_qidx.as<uint32_t>(), ws->f_kp.as<float>(), d_small + 60};
-      L.scatter.push_back(sa);
-      export_small(s);
-      L.copy_out.push_back({ws->c_offs.as<uint32_t>() + nq, mail(s) + 64, 1u});
-      L.copy_out.push_back({ws->c_hist.as<uint32_t>(), ws->m_hist.as<uint32_t>(), n_objs});
+    if (s.ph == PH_CLUSTER) {                               // ClusterPerObject, one launch (cluster_frame_kernel)
+      ClusterArgs ca;
+      ca.kp_xy = s.d_kp_xy; ca.cloud = s.use_depth ? nullptr : s.d_cloud; ca.depth = s.dep.d_depth; ca.counts = s.d_counts;
+      ca.matches = s.d_matches; ca.mxyz = s.d_mxyz; ca.nq = nq; ca.k = k; ca.H = H; ca.Wimg = Wimg; ca.n_objs = n_objs;
+      ca.depth_is_u16 = s.dep.is_u16; ca.fx = s.dep.fx; ca.fy = s.dep.fy; ca.cx = s.dep.cx; ca.cy = s.dep.cy;
+      ca.kept = ws->c_kept.as<uint32_t>(); ca.offs = ws->c_offs.as<uint32_t>(); ca.obj_of = ws->c_obj.as<uint32_t>();
+      ca.src = ws->c_src.as<uint32_t>(); ca.hist = ws->c_hist.as<uint32_t>(); ca.goff = ws->c_goff.as<uint32_t>();
+      ca.cnt = ws->c_cnt.as<uint32_t>(); ca.qpt = ws->c_qpt.as<float>();
+      ca.train = ws->train.as<float>(); ca.query = ws->query.as<float>(); ca.kpxy = ws->kpxy.as<float>(); ca.qidx = ws->qidx.as<uint32_t>();
+      ca.m_hist = ws->m_hist.as<uint32_t>(); ca.m_ctl = mail(s) + 60;
+      L.cluster.push_back(ca);
       s.ph = PH_CLUSTER_WAIT;
       return;
     }
@@ -2172,6 +2347,12 @@ struct Engine {
       for (size_t i = 0; i < s.objs.size(); ++i) {
         if (s.objs[i].n < 3) continue;
         const ObjJob job = make_job(s, s.objs[i]);
+        if (job.n <= 64u) {                                  // finite + adjacency + statistics by one wave
+          PrepSmallArgs pa;
+          pa.job = job; pa.stats = ws->nvalid.as<uint32_t>() + 4 * i; pa.span = spans[s.objs[i].obj]; pa.err = prm->sensor_error;
+          L.prep_small.push_back(pa);
+          continue;
+        }
         L.finite.push_back({job});
         L.adj.push_back({job, spans[s.objs[i].obj], prm->sensor_error});
         L.prep.push_back({job, ws->nvalid.as<uint32_t>() + 4 * i, nullptr, 0u});
@@ -2500,7 +2681,7 @@ struct Engine {
       }
       s.oi = 0;
       if (!reserve_objects(s, max_n)) return;
-      s.ph = PH_GROUP;
+      s.ph = PH_PREPALL;                                     // (the grouping by object rode in the cluster launch)
       return;
     }
     if (s.ph == PH_PREPALL_WAIT) {
@@ -2610,6 +2791,7 @@ struct Engine {
     TOD_HIP(ws->c_kept.reserve((size_t)nq * 4)); TOD_HIP(ws->c_offs.reserve(((size_t)nq + 1) * 4));
     TOD_HIP(ws->c_qpt.reserve((size_t)nq * 12)); TOD_HIP(ws->c_obj.reserve(cap * 4));
     TOD_HIP(ws->c_hist.reserve((size_t)n_objs * 4)); TOD_HIP(ws->c_goff.reserve((size_t)n_objs * 4));
+    TOD_HIP(ws->c_src.reserve(cap * 4)); TOD_HIP(ws->c_cnt.reserve((size_t)n_objs * 4));
     TOD_HIP(ws->m_hist.reserve((size_t)n_objs * 4)); TOD_HIP(ws->m_goff.reserve((size_t)n_objs * 4));
     TOD_HIP(ws->f_train.reserve(cap * 12)); TOD_HIP(ws->f_query.reserve(cap * 12));
     TOD_HIP(ws->f_qidx.reserve(cap * 4)); TOD_HIP(ws->f_kp.reserve(cap * 8));
@@ -2677,10 +2859,10 @@ struct Engine {
     bool stage_ok = false;
     {
       const size_t n_eval = L.eval_small.size() + L.eval_direct.size() + L.eval_big.size();
-      if (L.adj.size() > 4u * kManySlots || n_eval > kMaxSlots) {
+      if (L.adj.size() > 4u * kManySlots || n_eval > kMaxSlots || L.prep_small.size() > kManySlots) {
         VerifyPool* pool = pool_of(ctx);
         const size_t need = L.finite.size() * sizeof(JobArgs) + L.adj.size() * sizeof(AdjArgs) + L.prep.size() * sizeof(PrepArgs) +
-                            n_eval * sizeof(EvalArgs) + 4096u;
+                            L.prep_small.size() * sizeof(PrepSmallArgs) + n_eval * sizeof(EvalArgs) + 4096u;
         stage_ok = pool->args_stage[lane_now].reserve(need) == hipSuccess && pool->args_dev[lane_now].reserve(need) == hipSuccess;   // (the lane is idle)
       }
     }
@@ -2703,12 +2885,19 @@ struct Engine {
     launch_list<kCopySlots>(st, copy_words_kernel, L.copy_in, 256, 0, 1, words);
     for (size_t i = 0; i < L.sprint.size(); ++i) { L.sprint[i].rnd = L.sprint_src[i]->dev.as<uint32_t>(); L.sprint[i].rnd_len = L.sprint_src[i]->dev_valid; }
     launch_list<kWideSlots>(st, sprint_kernel, L.sprint, kSprintThreads, kSprintLds, 0, [](const SprintArgs&) { return dim3(1); });
+    launch_list(st, cluster_frame_kernel, L.cluster, 256, 0, 0, [](const ClusterArgs&) { return dim3(1); });
     launch_list(st, cluster_lookup_kernel, L.lookup, 256, 0, 1, [](const LookupArgs& a) { return dim3((a.nq + 255u) / 256u); });
     launch_list(st, cluster_scan_kernel, L.scan, 256, 0, 0, [](const ScanArgs&) { return dim3(1); });
     launch_list(st, cluster_scatter_kernel, L.scatter, 256, 0, 1,
                 [](const ScatterArgs& a) { return dim3((uint32_t)(((size_t)a.nq * a.k + 255u) / 256u)); });
     launch_list(st, cluster_group_kernel, L.group, 256, 0, 1, [](const GroupArgs& a) { return dim3((a.n_all + 255u) / 256u); });
     launch_list<kWideSlots>(st, invalidate_kernel, L.inval, 256, 0, 0, [](const InvArgs&) { return dim3(1); });
+    {
+      auto one = [](const PrepSmallArgs&) { return dim3(1); };
+      if (!(L.prep_small.size() > kManySlots && stage_ok &&
+            launch_many(st, small_prep_kernel<SlotsPtr<PrepSmallArgs>>, L.prep_small, 1, one, used, 64u, 0u, false)))
+        launch_list<kManySlots>(st, small_prep_kernel<Slots<PrepSmallArgs, kManySlots>>, L.prep_small, 64, 0, 1, one);
+    }
     {
       auto ext_rows = [](const auto& a) { return dim3((a.job.n + 255u) / 256u); };
       auto ext_adj = [](const AdjArgs& a) { return dim3(a.job.n, (a.job.W + 3u) / 4u); };
@@ -2807,8 +2996,8 @@ struct Engine {
     return n;
   }
   void describe(char* what, size_t cap) const {
-    snprintf(what, cap, "lookup %zu adj %zu prep %zu draw %zu+%zu chain %zu eval %zu+%zu growth %zu inval %zu sprint %zu", L.lookup.size(),
-             L.adj.size(), L.prep.size(), L.draw.size(), L.draw_small.size(), L.chain.size(), L.eval_small.size() + L.eval_direct.size(),
+    snprintf(what, cap, "lookup %zu adj %zu prep %zu draw %zu+%zu chain %zu eval %zu+%zu growth %zu inval %zu sprint %zu", L.lookup.size() + L.cluster.size(),
+             L.adj.size() + L.prep_small.size(), L.prep.size() + L.prep_small.size(), L.draw.size(), L.draw_small.size(), L.chain.size(), L.eval_small.size() + L.eval_direct.size(),
              L.eval_big.size(), L.growth.size(), L.inval.size(), L.sprint.size());
   }
   struct Lane {
