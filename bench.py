@@ -92,6 +92,12 @@ def parse():
     ap.add_argument("--serial-exchange", action="store_true",
                     help="several ranks: issue the collectives on the matcher's stream, in program order (gather -> match -> "
                          "exchange -> merge), instead of on their own stream where they overlap the neighbouring DB passes")
+    ap.add_argument("--chained-workers", type=int, default=2, help="verifier batches in flight in the chained block (0: --verify-workers)")
+    ap.add_argument("--chained-latency-cus", type=int, default=96,
+                    help="chained block: the matcher's stream keeps off this many compute units (todhip_set_cu_partition), on which the "
+                         "verifier's single-wave launch groups (sprints, clique gates, growth: its side streams) then run alone; ORB's and "
+                         "the verifier's wide kernels keep the whole chip. The block is verifier-bound: 2 batches in flight 6.4k frames/s "
+                         "without, 7.0k with 64, 7.4k with 96, 6.4k with 128 (the matcher becomes the bound); 0 = no partition")
     ap.add_argument("--latency-cus", type=int, default=0, help="reserve this many compute units for the latency-bound stages' streams "
                     "(todhip_set_cu_partition): ORB and verifier kernels then never share a SIMD with the matcher's DB pass")
     ap.add_argument("--iterations", type=int, default=2500, help="n_ransac_iterations (conf/detection.ork:38)")
@@ -268,8 +274,9 @@ _LATENCY_CUS = 0                                                          # --la
 def pooled_stream(torch, role, index=0, priority=0):
     key = (role, index)
     if key not in _STREAMS:
-        if _LATENCY_CUS > 0:                                                  # the matcher on most of the chip, ORB and the verifier on the rest
-            from tod_amd import capi
+        solo = os.environ.get("TOD_BENCH_PARTITION_SOLO") == "1"              # experiment: only the matcher leaves the reserved CUs; ORB and the
+        if _LATENCY_CUS > 0 and (role == "match" or not solo):                 # verifier's wide kernels keep the whole chip, the verifier's
+            from tod_amd import capi                                          # single-wave groups (its side streams) get the reserved CUs
             _STREAMS[key] = torch.cuda.ExternalStream(capi.stream_create(torch.cuda.current_device(), latency=(role != "match")))
         else:
             _STREAMS[key] = torch.cuda.Stream(priority=priority)
@@ -292,8 +299,17 @@ def run_chained(torch, capi, device, args):
     tctx.close()
     batches = scenes.make_detection_batches(textures, 4, B)
     H, W = scenes.H, scenes.W
-    mstream, ostream = pooled_stream(torch, "match"), pooled_stream(torch, "orb", 0, -1)
-    NV = args.verify_workers if args.verify_workers > 0 else 4
+    lat_cus = 0 if _LATENCY_CUS > 0 else args.chained_latency_cus         # (--latency-cus partitions every stream of the process already)
+    if lat_cus > 0:
+        capi.set_cu_partition(lat_cus)
+        key = ("match-partitioned", lat_cus)
+        if key not in _STREAMS:
+            _STREAMS[key] = torch.cuda.ExternalStream(capi.stream_create(device, latency=False))
+        mstream = _STREAMS[key]
+    else:
+        mstream = pooled_stream(torch, "match")
+    ostream = pooled_stream(torch, "orb", 0, -1)
+    NV = args.chained_workers if args.chained_workers > 0 else (args.verify_workers if args.verify_workers > 0 else 4)
     vstreams = [pooled_stream(torch, "verify", j, -1) for j in range(NV)]
     mctx, octx = capi.Context(device, mstream.cuda_stream), capi.Context(device, ostream.cuda_stream)
     vctxs = [capi.Context(device, s.cuda_stream) for s in vstreams]
@@ -363,7 +379,7 @@ def run_chained(torch, capi, device, args):
                    "library), per step todhip_orb_batch_device -> todhip_match_device -> todhip_verify_batch_device_depth on %d rendered "
                    "detection views, every stage reading the previous stage's device buffers" % (len(scenes.TRAIN_VIEWS), B),
            "db_rows": int(off[-1]), "db_objects": n_obj, "k": k, "radius": radius, "frames_per_step": B, "steps": steps,
-           "verifier_batches_in_flight": NV,
+           "verifier_batches_in_flight": NV, "latency_cus": lat_cus,
            "frames_per_s": spread(fps), "ms_per_step": statistics.median(secs) / steps * 1e3,
            "matcher_launch_ms": k_ms, "matcher_launches": n_l,
            "stage_ms_per_step": {key: 1e3 * v / (steps * args.repeats) for key, v in pipe.stage_s.items()},
@@ -375,6 +391,8 @@ def run_chained(torch, capi, device, args):
     pipe.close()
     for c in [mctx, octx] + vctxs:
         c.close()
+    if lat_cus > 0:
+        capi.set_cu_partition(_LATENCY_CUS)
     return out
 
 

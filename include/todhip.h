@@ -81,8 +81,10 @@ int  todhip_get_counters(todhip_ctx*, todhip_counters* out);
  * TODHIP_STREAM_LATENCY streams (the short, latency-bound kernels of ORB and of the verifier -- a single wave for hundreds of
  * microseconds -- which otherwise share every SIMD with the matcher's chip-filling DB pass); TODHIP_STREAM_THROUGHPUT streams get
  * the other compute units. n = 0 (the default, or the environment's TODHIP_LATENCY_CUS): no partition, latency streams are plain
- * high-priority streams. Process-wide; set it before the first stream is created (the verifier's own side streams are latency
- * streams, created on first use). A multiple of 8 takes the same share of every XCD. */
+ * high-priority streams. Process-wide; applies to streams created afterwards (the verifier's own side streams -- the lanes its
+ * single-wave launch groups run on: sprints, clique gates, growth -- are latency streams and are re-created on their next use).
+ * A multiple of 8 takes the same share of every XCD. Measured: a pipeline whose matcher is the bound loses with any
+ * partition; a verifier-bound one (frames of ~190 objects) gains 15 % with the matcher alone confined to 160 of 256 CUs. */
 enum { TODHIP_STREAM_THROUGHPUT = 0, TODHIP_STREAM_LATENCY = 1 };
 int  todhip_set_cu_partition(uint32_t latency_cus);
 int  todhip_stream_create(int device, int kind, void** stream_out);

@@ -80,6 +80,7 @@ static uint32_t latency_cus_now() {
   return v;
 }
 int todhip_set_cu_partition(uint32_t latency_cus) { g_latency_cus.store(latency_cus); return TODHIP_OK; }
+uint32_t tod_cu_partition() { return latency_cus_now(); }
 
 hipError_t tod_stream_create(hipStream_t* out, int device, int kind) {
   const uint32_t lat = latency_cus_now();

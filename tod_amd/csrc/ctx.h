@@ -111,6 +111,7 @@ struct todhip_ctx {
 
 // capi.hip: a stream of the given kind (todhip_stream_create), honouring the process's CU partition
 extern "C" hipError_t tod_stream_create(hipStream_t* out, int device, int kind);
+extern "C" uint32_t tod_cu_partition();                     // todhip_set_cu_partition's current value
 // match.hip
 int tod_timing_begin(todhip_ctx* ctx, int* slot);
 int tod_timing_end(todhip_ctx* ctx, int slot);

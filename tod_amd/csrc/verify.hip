@@ -1995,6 +1995,7 @@ struct SideStreams {
   struct PerDevice {
     std::vector<hipStream_t> st;
     std::atomic<bool> taken[16];
+    uint32_t partition = 0;                                 // todhip_set_cu_partition's value the streams were created under
     PerDevice() { for (auto& t : taken) t.store(false); }
   };
   std::mutex mu;
@@ -2002,6 +2003,16 @@ struct SideStreams {
   hipError_t get(int device, uint32_t n, std::vector<hipStream_t>& out, PerDevice** pd) {
     std::lock_guard<std::mutex> g(mu);
     PerDevice& d = by_device[device];
+    const uint32_t part = tod_cu_partition();
+    if (d.partition != part) {                              // the CU partition changed: new streams, once nobody is on the old ones
+      bool in_use = false;
+      for (size_t i = 0; i < d.st.size(); ++i) in_use = in_use || d.taken[i].load();
+      if (!in_use) {
+        for (hipStream_t s0 : d.st) { (void)hipStreamSynchronize(s0); (void)hipStreamDestroy(s0); }
+        d.st.clear();
+        d.partition = part;
+      }
+    }
     while (d.st.size() < n) {
       hipStream_t s2;                                       // latency-bound work: the highest priority there is, or the CU partition's
       const hipError_t e = tod_stream_create(&s2, device, TODHIP_STREAM_LATENCY);

@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT"
 for w in ${1:-3 6}; do
   for f in ${2:-0 3 8}; do
-    TODHIP_VERIFY_FLIGHTS=$f timeout -k 10 300 python bench.py --extras chained --stages match --no-cpu-baseline --verify-workers $w --steps ${3:-60} --repeats 3 > gpurun_out/vw${w}_f$f.json 2> gpurun_out/vw${w}_f$f.err || { tail -5 gpurun_out/vw${w}_f$f.err; exit 1; }
+    TODHIP_VERIFY_FLIGHTS=$f timeout -k 10 300 python bench.py --extras chained --stages match --no-cpu-baseline --verify-workers $w --chained-workers $w --steps ${3:-60} --repeats 3 > gpurun_out/vw${w}_f$f.json 2> gpurun_out/vw${w}_f$f.err || { tail -5 gpurun_out/vw${w}_f$f.err; exit 1; }
     python3 -c "
 import json
 d=json.load(open('gpurun_out/vw${w}_f$f.json'))

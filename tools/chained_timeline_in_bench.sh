@@ -1,6 +1,6 @@
 # one verifier batch's timeline inside the running chained pipeline (TODHIP_DEBUG=1): usage chained_timeline_in_bench.sh [workers]
 cd "$GRAFT_REPO_ROOT"
-TODHIP_DEBUG=1 timeout -k 10 300 python bench.py --extras chained --stages match --no-cpu-baseline --verify-workers ${1:-2} --steps 30 --repeats 1 > gpurun_out/tl.json 2> gpurun_out/tl.err
+TODHIP_DEBUG=1 timeout -k 10 300 python bench.py --extras chained --stages match --no-cpu-baseline --verify-workers ${1:-2} --chained-workers ${1:-2} --steps 30 --repeats 1 > gpurun_out/tl.json 2> gpurun_out/tl.err
 python3 - <<'PY'
 import re, collections
 lines = open("gpurun_out/tl.err").read().splitlines()

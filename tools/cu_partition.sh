@@ -2,7 +2,7 @@
 cd "$GRAFT_REPO_ROOT"
 for cus in ${1:-0 8 16 32}; do
   for w in ${2:-2 4}; do
-    timeout -k 10 300 python bench.py --extras chained --stages match --no-cpu-baseline --verify-workers $w --latency-cus $cus --steps ${3:-60} --repeats 3 > gpurun_out/cu${cus}_w$w.json 2> gpurun_out/cu${cus}_w$w.err || { tail -5 gpurun_out/cu${cus}_w$w.err; exit 1; }
+    timeout -k 10 300 python bench.py --extras chained --stages match --no-cpu-baseline --verify-workers $w --chained-workers $w --latency-cus 0 --chained-latency-cus $cus --steps ${3:-60} --repeats 3 > gpurun_out/cu${cus}_w$w.json 2> gpurun_out/cu${cus}_w$w.err || { tail -5 gpurun_out/cu${cus}_w$w.err; exit 1; }
     python3 -c "
 import json
 d=json.load(open('gpurun_out/cu${cus}_w$w.json'))
