@@ -52,12 +52,15 @@ inline std::string json_string(const std::string& js, const std::string& key, co
 
 typedef std::string ObjectId;   // object_recognition_core::db::ObjectId
 
-// One shared context per process (one HIP device + stream); cells of one plasm run sequentially.
+// One shared context per process (one HIP device + stream) for the cells that keep no state in it (FeatureDescriptor,
+// GuessGenerator: host-buffer calls only); cells of one plasm run sequentially. A DescriptorMatcher owns a context of its own:
+// the object DB and its search settings (ratio test, LSH mode) live there, and two matcher cells with different
+// search_json_params must not overwrite each other's.
+inline int context_device() { const char* dev = std::getenv("TODHIP_DEVICE"); return dev ? std::atoi(dev) : 0; }
 inline todhip_ctx* shared_context() {
   static todhip_ctx* ctx = nullptr;
   if (!ctx) {
-    const char* dev = std::getenv("TODHIP_DEVICE");
-    if (todhip_create(dev ? std::atoi(dev) : 0, nullptr, &ctx) != TODHIP_OK)
+    if (todhip_create(context_device(), nullptr, &ctx) != TODHIP_OK)
       throw std::runtime_error("todhip_create failed: no usable MI355X / HIP device");
   }
   return ctx;
@@ -102,7 +105,8 @@ struct DescriptorMatcher
     // The reference accepts only "LSH" and `throw;`s otherwise (:182-186). The LSH table parameters
     // (n_tables, key_size, multi_probe_level) select an *approximate* index there; here the search is exact.
     if (json_string(js, "type", "") != "LSH") throw std::runtime_error("Search not implemented for that type");
-    ctx_ = shared_context();
+    if (!ctx_ && todhip_create(context_device(), nullptr, &ctx_) != TODHIP_OK)          // this cell's own: DB + search settings
+      throw std::runtime_error("todhip_create failed: no usable MI355X / HIP device");
     if (todhip_set_ratio_test(ctx_, lowe_ratio_) != TODHIP_OK) throw std::runtime_error("lowe_ratio must lie in [0, 1]");
     // "approximate": 1 (a key of this adapter's own) makes those three parameters mean what they mean to the reference: an
     // LSH index of n_tables x key_size-bit keys probed multi_probe_level bits deep (todhip_set_lsh; FLANN's scheme, own key bits)
@@ -182,6 +186,11 @@ struct DescriptorMatcher
     outputs["spans"] << spans_;
     return ecto::OK;
   }
+
+  DescriptorMatcher() {}
+  ~DescriptorMatcher() { if (ctx_) todhip_destroy(ctx_); }
+  DescriptorMatcher(const DescriptorMatcher&) = delete;                    // (ecto holds a cell's implementation by pointer)
+  DescriptorMatcher& operator=(const DescriptorMatcher&) = delete;
 
   todhip_ctx* ctx_ = nullptr;
   unsigned int radius_ = 0, ratio_ = 0;
@@ -382,12 +391,16 @@ struct FeatureDescriptor {
   }
   int process(const ecto::tendrils& inputs, const ecto::tendrils& outputs) {
     cv::Mat image = inputs.get<cv::Mat>("image");
-#ifdef TOD_AMD_WITH_ORK
-    if (image.channels() == 3) { cv::Mat g; cv::cvtColor(image, g, CV_RGB2GRAY); image = g; }   // cv::ORB converts as well
-#endif
+    // cv::ORB converts a colour image itself (cvtColor(image, gray, CV_BGR2GRAY), third-party, recalled) and asserts 8-bit input;
+    // here 3- and 4-channel 8-bit images are converted with cvtColor's fixed-point weights, anything else is refused -- never read
+    // as if it were gray bytes
+    if (image.type() == CV_8UC3 || image.type() == CV_8UC4) image = bgr_to_gray(image);
+    if (!image.empty() && image.type() != CV_8UC1) throw std::runtime_error("FeatureDescriptor: the image must be 8-bit with 1, 3 or 4 channels");
     const cv::Mat& mask = inputs.get<cv::Mat>("mask");
     if (!image.isContinuous()) image = image.clone();
     const uint32_t H = (uint32_t)image.rows, W = (uint32_t)image.cols;
+    if (!mask.empty() && ((uint32_t)mask.rows != H || (uint32_t)mask.cols != W || mask.type() != CV_8UC1))
+      throw std::runtime_error("FeatureDescriptor: the mask must be 8-bit, one channel, of the image's size");
     std::vector<float> kp(2 * (size_t)n_features_), aux(4 * (size_t)n_features_);
     cv::Mat desc((int)n_features_, 32, CV_8U);
     uint32_t n = n_features_;
@@ -408,6 +421,18 @@ struct FeatureDescriptor {
     outputs["keypoints"] << keypoints;
     outputs["descriptors"] << out;
     return ecto::OK;
+  }
+
+  // Y = (1868 B + 9617 G + 4899 R + 2^13) >> 14: cvtColor's 8-bit BGR2GRAY / BGRA2GRAY
+  static cv::Mat bgr_to_gray(const cv::Mat& src) {
+    const int ch = src.type() == CV_8UC4 ? 4 : 3;
+    cv::Mat g(src.rows, src.cols, CV_8UC1);
+    for (int r = 0; r < src.rows; ++r) {
+      const uint8_t* p = src.template ptr<uint8_t>(r);
+      uint8_t* o = g.template ptr<uint8_t>(r);
+      for (int c = 0; c < src.cols; ++c, p += ch) o[c] = (uint8_t)((1868u * p[0] + 9617u * p[1] + 4899u * p[2] + 8192u) >> 14);
+    }
+    return g;
   }
 
   todhip_ctx* ctx_ = nullptr;

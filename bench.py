@@ -30,6 +30,7 @@ import os
 import statistics
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -53,7 +54,6 @@ HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: HBM3E
 MFMA_FP4_PEAK_TFLOPS = 10000.0                      # MI355X_MICROARCH.md: FP6/FP4 MFMA ~10 PF dense
 MFMA_BF16_PEAK_TFLOPS = 2500.0                      # MI355X_MICROARCH.md: BF16 MFMA ~2.5 PF dense
 MFMA_BF16_MEASURED_TFLOPS = 1840.0                  # profiles/r02_mfma_bf16_peak_microbench.txt: bare loop, random bf16 operands, sustained
-L2_PASS2_US = 115.0                                 # profiles/r02_l2_kernel_stats.csv: l2_gemm_kernel<2, 4> at the C4 shape (111-118 us across runs and boxes)
 FLOP_PER_PAIR = 512.0                               # a 256-bit Hamming distance on the matrix cores = 256 multiply-adds
 # 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) issue at 16 lanes/clk/SIMD on gfx950 (tools/valu_peak.hip,
 # profiles/r01_valu_peak_microbench.txt: 38-40 T lane-op/s): the roof of the vector-ALU engine (--engine valu)
@@ -71,7 +71,8 @@ def parse():
     ap.add_argument("--nq", type=int, default=1000)
     ap.add_argument("--k", type=int, default=2)
     ap.add_argument("--radius", type=int, default=35)
-    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled through")
+    ap.add_argument("--frames", type=int, default=64, help="distinct synthetic frames cycled through (64 = two distinct batches of 32 "
+                                                           "distinct frames: a step is not a replay of the step before)")
     ap.add_argument("--stages", default="orb,match,verify", help="comma list of: orb,match,verify")
     ap.add_argument("--batch", type=int, default=32,
                     help="frames per rank per step of the headline pipeline (tools/batch_sweep.sh: 16 -> 11.8k frames/s, 24 -> 12.0k, 32 -> 12.4k, "
@@ -323,6 +324,7 @@ def run_chained(torch, capi, device, args):
                  matches=torch.zeros((B * nq * k, 4), dtype=torch.int32, device="cuda"),
                  xyz=torch.zeros((B * nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(D)]
     stats = dict(frames=0, right_object=0, pose_ok=0, poses=0, kp_short=0)
+    stats_lock = threading.Lock()
 
     def orb(i):
         s = orb_ring[i % R]
@@ -348,15 +350,19 @@ def run_chained(torch, capi, device, args):
         poses = vctxs[i % NV].verify_batch_device(B, s["kp"].data_ptr(), nq, 0, H, W, o["counts"].data_ptr(), o["matches"].data_ptr(),
                                          o["xyz"].data_ptr(), k, spans, args.min_inliers, args.iterations, 0.01, rngs,
                                          depth=(bt["depth"].data_ptr(), False, scenes.K))
+        tally = dict(frames=0, right_object=0, pose_ok=0, poses=0)           # per call; the verifier workers run this concurrently
         for f, pl in enumerate(poses):
-            stats["frames"] += 1
-            stats["poses"] += len(pl)
+            tally["frames"] += 1
+            tally["poses"] += len(pl)
             hit = [p for p in pl if p["object"] == bt["objects"][f]]
             if hit:
-                stats["right_object"] += 1
+                tally["right_object"] += 1
                 Rt, tt = bt["poses"][f]
                 if np.abs(hit[0]["R"] - Rt).max() < 0.03 and np.abs(hit[0]["t"] - tt).max() < 0.006:
-                    stats["pose_ok"] += 1
+                    tally["pose_ok"] += 1
+        with stats_lock:
+            for key, v in tally.items():
+                stats[key] += v
         return sum(len(p) for p in poses)
 
     pipe = StagePipeline(torch, orb=orb, match=match, verify=verify, wait_for=lambda i, ev: vstreams[i % NV].wait_event(ev), depth=D,
@@ -614,6 +620,16 @@ def run_configs(torch, capi, synth, device, args):
             call()
         c4.synchronize()
         secs.append((time.perf_counter() - t0) / 20)
+    # the GEMM pass alone, live: HIP events around l2_gemm_kernel<2, 4> on the context's stream (todhip_set_kernel_timing), in
+    # further calls of the same shape so that the events do not sit inside the timed region above
+    c4.set_kernel_timing(True)
+    k0 = c4.counters()
+    for _ in range(20):
+        call()
+    c4.synchronize()
+    pass2_ms, pass2_n = launch_ms(k0, c4.counters())
+    c4.set_kernel_timing(False)
+    pass2_s = max(pass2_ms, 1e-6) * 1e-3
     flops = 2.0 * 1000 * d4.shape[0] * 128
     med = statistics.median(secs)
     out["C4"] = {"workload": "C4: 1000 SIFT-128 float descriptors vs 500k-row DB, L2 brute force k=2 as a bf16 MFMA GEMM with exact f32 "
@@ -622,10 +638,12 @@ def run_configs(torch, capi, synth, device, args):
                  "roofline": {"bound": "mfma", "achieved": flops / med / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": flops / med / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                               "note": "2 Q N 128 flop of the distance table / the whole call (seed pass + GEMM pass + exact re-ranking)",
-                              "gemm_pass_kernel": {"name": "l2_gemm_kernel<2,4>", "us": L2_PASS2_US, "TFLOPs": flops / (L2_PASS2_US * 1e-6) / 1e12,
-                                                   "frac_of_nominal": flops / (L2_PASS2_US * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-                                                   "frac_of_measured_roof": flops / (L2_PASS2_US * 1e-6) / 1e12 / MFMA_BF16_MEASURED_TFLOPS,
-                                                   "source": "profiles/r02_l2_kernel_stats.csv (rocprofv3 --kernel-trace of tools/time_l2.py, the same call)"},
+                              "gemm_pass_kernel": {"name": "l2_gemm_kernel<2,4>", "us": pass2_s * 1e6, "launches_timed": pass2_n,
+                                                   "TFLOPs": flops / pass2_s / 1e12,
+                                                   "frac_of_nominal": flops / pass2_s / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                                   "frac_of_measured_roof": flops / pass2_s / 1e12 / MFMA_BF16_MEASURED_TFLOPS,
+                                                   "source": "live: HIP events around the kernel on the context's stream (todhip_set_kernel_timing); "
+                                                             "profiles/r03_l2_kernel_stats.csv is the rocprofv3 kernel trace of the same call"},
                               "measured_mfma_roof": {"TFLOPs_random_operands": MFMA_BF16_MEASURED_TFLOPS, "TFLOPs_zero_operands": 2480.0,
                                                      "source": "profiles/r02_mfma_bf16_peak_microbench.txt (tools/mfma_bf16_peak.hip: bare "
                                                                "v_mfma_f32_32x32x16_bf16 loop, operands in registers; the clock the chip holds "
@@ -676,14 +694,16 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # the library torch.distributed's backend drives on this box, as the bench line names it ("nccl" IS RCCL on ROCm)
+    collective_backend = {"nccl": "RCCL", "gloo": "gloo (CPU rehearsal)"}.get(dist.get_backend() if use_dist else backend, backend)
     progress("building the synthetic workload")
     desc, pts, off = synth.make_db(args.objects)
-    frames = [synth.make_frame(desc, pts, off, args.nq, frame=f, visible_object=(17 * f + 3) % args.objects)
-              for f in range(args.frames)]
-    for f, fr in enumerate(frames):
+    # frame f belongs to rank (f % world): every rank builds and keeps resident only its own --frames frames
+    frame_ids = [rank + world * j for j in range(max(args.frames, 1))]
+    frames = [synth.make_frame(desc, pts, off, args.nq, frame=f, visible_object=(17 * f + 3) % args.objects) for f in frame_ids]
+    for f, fr in zip(frame_ids, frames):
         fr["image"] = synth.make_image(f)
-    # frame f belongs to rank (f % world); every rank keeps its own frames resident in HBM
-    my_frames = [frames[f] for f in range(len(frames)) if f % world == rank] or [frames[rank % len(frames)]]
+    my_frames = frames
 
     # one explicit stream for the matcher: libtodhip kernels, torch copies and (serial form) the RCCL collectives, which order
     # themselves against torch's current stream. The default stream's handle is 0 == "create your own" for todhip_create.
@@ -853,15 +873,15 @@ def main():
                                    "image, matcher and verifier consume the frame's planted descriptors; `chained` times the real dataflow",
                        "n_ransac_iterations": args.iterations, "min_inliers": args.min_inliers,
                        "poses_per_frame_rank0": (sp.pipe.n_poses - poses0) / n_fr,
-                       "frames_per_rank_per_step": B,
+                       "frames_per_rank_per_step": B, "distinct_frames_per_rank": len(my_frames), "distinct_batches_cycled": sp.period,
                        "pipeline": "3 stages, each one batched call per step: ORB | matcher | verifier (%s)" % ("two verifier workers on alternate steps" if len(sp.vstreams) == 2 else "%d verifier worker(s)" % len(sp.vstreams)) +
                                    ("; collectives + merge on a 4th stream, overlapping the neighbouring DB passes" if overlap else ""),
                        "stage_ms_per_step": {key: 1e3 * v / max(n_timed_steps, 1) for key, v in sp.pipe.stage_s.items()},
                        "orb": "ORB-%d, 3 levels, scale 1.2 on the 8(d) synthetic image; %.0f keypoints/frame" %
                               (args.nq, (sp.pipe.n_kp - kp0) / n_fr) if "orb" in stages else None,
                        "frames_per_step": world * B,
-                       "parallelism": ("DB rows sharded x%d (object aligned), %d frames per rank per step, RCCL all_gather of descriptors, "
-                                       "RCCL %s of per-shard candidates, %s" % (world, B, args.exchange, "collectives + merge overlapped "
+                       "parallelism": ("DB rows sharded x%d (object aligned), %d frames per rank per step, {be} all_gather of descriptors, "
+                                       "{be} %s of per-shard candidates, %s".format(be=collective_backend) % (world, B, args.exchange, "collectives + merge overlapped "
                                        "on their own stream" if overlap else "collectives in program order on the matcher's stream")) if sharded_db else
                                       ("%d replicas of the whole DB, %d frames per rank per step, no data-path collective" % (world, B)
                                        if world > 1 else "1 GPU"),
@@ -879,13 +899,13 @@ def main():
                 out["configs"] = run_configs(torch, capi, synth, local_rank, args)
                 progress("configs done")
             if "adapter" in extras:
-                out["adapter_path"] = run_adapter_path(torch, capi, local_rank, desc, pts, off, frames, args)
+                out["adapter_path"] = run_adapter_path(torch, capi, local_rank, desc, pts, off, frames[:8], args)
                 progress("adapter path done")
             if "hbm" in extras:
                 out["hbm_regime"] = run_hbm_regime(torch, capi, local_rank, args)
                 progress("hbm regime done")
             if "n4" in extras:
-                out["n4"] = run_n4(torch, capi, local_rank, desc, pts, off, frames, args)
+                out["n4"] = run_n4(torch, capi, local_rank, desc, pts, off, frames[:8], args)
                 progress("n4 done")
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(desc, pts, off, frames, k, args.radius, args.cpu_seconds, stages,

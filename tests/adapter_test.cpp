@@ -75,6 +75,27 @@ int main(int argc, char** argv) {
         dump(dir + (pass ? "/out_orb_kp_masked.bin" : "/out_orb_kp.bin"), kpf);
         dump(dir + (pass ? "/out_orb_desc_masked.bin" : "/out_orb_desc.bin"), dv);
       }
+      // a BGR image whose three channels equal the gray one gives the gray image's keypoints (the cell converts as cv::ORB does);
+      // a 16-bit image, and a mask of another size, are refused instead of being read as gray bytes
+      {
+        cv::Mat bgr(480, 640, CV_8UC3);
+        for (size_t i = 0; i < img.size(); ++i) { uint8_t* p = bgr.ptr<uint8_t>(0) + 3 * i; p[0] = p[1] = p[2] = img[i]; }
+        fi["image"] << bgr;
+        fi["mask"] << cv::Mat();
+        if (feat.process(fi, fo) != ecto::OK) return 7;
+        const cv::Mat& d = fo.get<cv::Mat>("descriptors");
+        std::vector<uint8_t> dv(d.ptr<uint8_t>(0), d.ptr<uint8_t>(0) + (size_t)d.rows * 32);
+        dump(dir + "/out_orb_desc_bgr.bin", dv);
+        bool threw = false;
+        fi["image"] << cv::Mat(480, 640, CV_16U);
+        try { feat.process(fi, fo); } catch (const std::exception&) { threw = true; }
+        if (!threw) return 9;
+        threw = false;
+        fi["image"] << im;
+        fi["mask"] << cv::Mat(240, 320, CV_8U);
+        try { feat.process(fi, fo); } catch (const std::exception&) { threw = true; }
+        if (!threw) return 9;
+      }
       ecto::tendrils badp;
       tod_amd::FeatureDescriptor::declare_params(badp);
       badp["json_feature_params"] << std::string("{\"type\": \"SIFT\"}");
@@ -94,6 +115,18 @@ int main(int argc, char** argv) {
     tod_amd::GuessGenerator guess;
     matcher.configure(mp, mi, mo);
     guess.configure(gp, gi, go);
+    // a second matcher cell with other search parameters (a ratio test, the approximate index) has a context of its own: it must
+    // not change what the first one computes (its DB stays empty; the frame below goes through `matcher`)
+    tod_amd::DescriptorMatcher other;
+    {
+      ecto::tendrils op, oi, oo;
+      tod_amd::DescriptorMatcher::declare_params(op);
+      tod_amd::DescriptorMatcher::declare_io(op, oi, oo);
+      op["search_json_params"] << std::string("{\"type\": \"LSH\", \"radius\": 20, \"lowe_ratio\": 0.5, \"approximate\": 1, "
+                                              "\"n_tables\": 4, \"key_size\": 12, \"multi_probe_level\": 1}");
+      other.configure(op, oi, oo);
+      if (other.ctx_ == matcher.ctx_ || !other.ctx_) return 10;
+    }
 
     // ---- models (what parameter_callback receives from the DB)
     std::vector<uint32_t> off = slurp<uint32_t>(dir + "/obj_off.bin");

@@ -13,6 +13,10 @@
 #include <vector>
 
 #define CV_8U 0
+#define CV_8UC1 0
+#define CV_8UC3 16
+#define CV_8UC4 24
+#define CV_16U 2
 #define CV_32F 5
 #define CV_64F 6
 #define CV_32FC3 21
@@ -26,7 +30,9 @@ class Mat {
   int rows, cols;
   Mat() : rows(0), cols(0), type_(CV_8U) {}
   Mat(int r, int c, int type) : rows(r), cols(c), type_(type), buf_(new std::vector<uint8_t>((size_t)r * c * esz(type))) {}
-  static size_t esz(int type) { return type == CV_8U ? 1 : type == CV_32F ? 4 : type == CV_64F ? 8 : 12; }
+  static size_t esz(int type) {
+    return type == CV_8U ? 1 : type == CV_8UC3 ? 3 : type == CV_8UC4 ? 4 : type == CV_16U ? 2 : type == CV_32F ? 4 : type == CV_64F ? 8 : 12;
+  }
   bool empty() const { return rows == 0 || cols == 0; }
   bool isContinuous() const { return true; }
   int type() const { return type_; }

@@ -160,9 +160,12 @@ class Cluster:
                                                   _p(self.qi, C.c_uint32), C.c_uint32(self.n)))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_cluster_free(self.h)
-            self.h = None
+        h, self.h = getattr(self, "h", None), None
+        if h and _lib is not None:                    # (at interpreter exit the module's globals may already be gone)
+            try:
+                _lib.orc_cluster_free(h)
+            except Exception:
+                pass
 
     def fill(self, kp_xy, span, err):
         kp = np.ascontiguousarray(kp_xy, np.float32)

@@ -42,6 +42,7 @@ def test_adapter_frame_equals_c_abi():
         assert out.returncode == 0, out.stdout + out.stderr
         orb_out = {tag: (np.fromfile(os.path.join(d, "out_orb_kp%s.bin" % tag), np.float32).reshape(-1, 6),
                          np.fromfile(os.path.join(d, "out_orb_desc%s.bin" % tag), np.uint8).reshape(-1, 32)) for tag in ("", "_masked")}
+        desc_bgr = np.fromfile(os.path.join(d, "out_orb_desc_bgr.bin"), np.uint8).reshape(-1, 32)
         m = np.fromfile(os.path.join(d, "out_matches.bin"), np.int32).reshape(-1, 3)
         dist = np.fromfile(os.path.join(d, "out_dist.bin"), np.float32)
         rt = np.fromfile(os.path.join(d, "out_poses.bin"), np.float32).reshape(-1, 12)
@@ -75,4 +76,6 @@ def test_adapter_frame_equals_c_abi():
         if mk is not None:
             l0 = aux[:, 3] == 0
             assert (mask[kp[l0, 1].astype(int), kp[l0, 0].astype(int)] != 0).all()
+    # a BGR image with three equal channels converts to the gray image itself ((1868 + 9617 + 4899) g + 2^13 >> 14 == g)
+    assert np.array_equal(desc_bgr, orb_out[""][1])
     ctx.close()

@@ -97,6 +97,17 @@ def test_radius_truncation_edges(ctx):
         _assert_same(ctx, desc, pts, off, fr["q_desc"], 5, radius)
 
 
+@pytest.mark.parametrize("n_rows,k", [(5, 8), (33, 8), (40, 2), (95, 5)])
+def test_no_radius_cut_on_short_tiles_keeps_only_real_rows(ctx, n_rows, k):
+    """radius >= 256 (no cut: the threshold starts below every dot product) on DBs whose only tile is shorter than a step or
+    ends in a partial one, with fewer rows than k in one case: the matrix-core engine's 'no pending block' marker must stay below
+    that threshold too, or it would enter the lists as rows at distance 1023."""
+    desc, pts, off = synth.make_db(1, per_object=n_rows)
+    fr = synth.make_frame(desc, pts, off, 70, frame=3, visible_object=0, flip_p=0.3)
+    for radius in (256, 1000):
+        _assert_same(ctx, desc, pts, off, fr["q_desc"], k, radius)
+
+
 def test_error_statuses(ctx):
     desc, pts, off = synth.make_db(1, per_object=100)
     ctx.db_load(desc, pts, off)

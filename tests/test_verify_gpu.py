@@ -531,6 +531,41 @@ def test_batch_of_heavy_and_light_frames_equals_frame_by_frame(ctx):
     assert max(len(p["inliers"]) for f in range(F) for p in got[f]) >= 96         # some object was heavy enough to fly
 
 
+def test_batch_of_44_heavy_and_light_frames_with_several_groups_in_the_air(ctx):
+    """More than 32 frames: a launch group's evaluation lists exceed one launch's argument sets and travel through device memory
+    (launch_many), and several such groups are in the air on different lanes at once -- each lane has its own staging pair, which
+    only grows while the lane is idle. 44 frames mixing heavy frames, frames of small objects and empty ones == frame by frame."""
+    import torch
+    k, nq = 3, 400
+    vis = [((1, 0.45),), ((6, 0.40), (2, 0.04)), (), ((3, 0.30), (5, 0.30)), ((7, 0.5),), ((0, 0.03), (4, 0.03), (6, 0.03)), ((2, 0.35),),
+           ((1, 0.2), (3, 0.2), (5, 0.2)), ((4, 0.6),), ((0, 0.05),)]
+    base = [synth.make_verify_scene(nq, visible=v, seed=640 + i, matches_per_kp=3, n_objects=8) for i, v in enumerate(vis)]
+    packed = [_pack_scene(s, k) for s in base]
+    F = 44
+    idx = [(7 * f) % len(base) for f in range(F)]
+    d_kp = torch.from_numpy(np.stack([base[i]["kp_xy"] for i in idx]).astype(np.float32)).cuda()
+    d_cloud = torch.from_numpy(np.stack([base[i]["cloud"] for i in idx]).astype(np.float32)).cuda()
+    d_counts = torch.from_numpy(np.stack([packed[i][0] for i in idx])).cuda()
+    d_m = torch.from_numpy(np.stack([packed[i][1] for i in idx])).cuda()
+    d_xyz = torch.from_numpy(np.stack([packed[i][2] for i in idx])).cuda()
+    torch.cuda.synchronize()
+    spans = base[0]["spans"]
+    want = []
+    for f in range(F):
+        r = capi.rng_new(3 + f % 5)
+        want.append((ctx.verify_device(d_kp[f].data_ptr(), nq, d_cloud[f].data_ptr(), 480, 640, d_counts[f].data_ptr(),
+                                       d_m[f].data_ptr(), d_xyz[f].data_ptr(), k, spans, 8, 600, 0.01, r), r))
+    for rep in range(2):
+        rngs = (capi.Rng * F)(*[capi.rng_new(3 + f % 5) for f in range(F)])
+        got = ctx.verify_batch_device(F, d_kp.data_ptr(), nq, d_cloud.data_ptr(), 480, 640, d_counts.data_ptr(), d_m.data_ptr(),
+                                      d_xyz.data_ptr(), k, spans, 8, 600, 0.01, rngs)
+        assert sum(len(p) for p in got) >= 30
+        for f in range(F):
+            assert rngs[f].draws == want[f][1].draws and list(rngs[f].s) == list(want[f][1].s) and len(got[f]) == len(want[f][0]), f
+            for a, b in zip(got[f], want[f][0]):
+                assert a["object"] == b["object"] and np.array_equal(a["inliers"], b["inliers"]) and np.array_equal(a["R"], b["R"])
+
+
 @pytest.mark.parametrize("n_obj", [40, 200])
 def test_many_small_distractor_objects(ctx, n_obj):
     """One true object among many that only collect random matches (15-75 each): every distractor burns its iteration

@@ -11,7 +11,9 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtodhip.so")
+# TODHIP_LIB_PATH: another build of the same library (the diagnostics builds of tools/*_ablate.sh, an A/B against HEAD) -- loaded
+# instead of, never copied over, the product file
+LIB_PATH = os.environ.get("TODHIP_LIB_PATH") or os.path.join(_PKG, "libtodhip.so")
 
 OK, EINVAL, ENODB, EHIP, ECAPACITY, ERANGE, ENOMEM, ESCRATCH = 0, -1, -2, -3, -4, -5, -6, -7
 

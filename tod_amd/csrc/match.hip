@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   uint4 pa = load_step(1), pb = PF2 ? load_step(2) : pa;
   mfma_f32x16 acc_even, acc_odd;                                    // acc_odd: pending block of the previous step -- none yet
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc_odd[i] = -1024.f;
+  for (int i = 0; i < 16; ++i) acc_odd[i] = -4096.f;                      // below every threshold (256 - 2 * 1023 at the least)
   uint32_t seen[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) seen[t] = 0xFFFFFFFFu;              // "nothing published"
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void hamming_topk_mfma_q32(const uint32_t* 
   uint4 p0 = load_step(0), p1 = load_step(1), p2 = load_step(2), p3 = load_step(3);
   mfma_f32x16 acc_a, acc_b;                                          // acc_b: pending block of the previous step -- none yet
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc_b[i] = -1024.f;
+  for (int i = 0; i < 16; ++i) acc_b[i] = -4096.f;                        // below every threshold (256 - 2 * 1023 at the least)
   uint32_t* my_bound = bound + (c < nq ? c : nq - 1u);
   uint32_t seen = 0xFFFFFFFFu, next_share = 2u, step = 0;
   for (; step + 4u <= n_full; step += 4u) {                          // four steps per trip: p0..p3 rotate by name, nothing is copied
@@ -771,7 +771,7 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
   // under a whole number of rounds has no straggling last round (measured, tools/k4x_sweep.py, 16 000 x 1M: 16 waves per
   // CU = 2 rounds 1.13 ms, 14 = 1.6 rounds 1.37 ms, 8 = all resident 1.36 ms, 32 .. 128 1.11 ms); four rounds while a tile
   // then still has >= 48 steps (a tile starts with empty lists), two otherwise. Tiles are whole 32-row steps.
-  const int env_wpc = getenv("TODHIP_K4X_WAVES_PER_CU") ? atoi(getenv("TODHIP_K4X_WAVES_PER_CU")) : 0;   // tuning knobs, read per launch
+  static const int env_wpc = getenv("TODHIP_K4X_WAVES_PER_CU") ? atoi(getenv("TODHIP_K4X_WAVES_PER_CU")) : 0;   // tuning knobs, read once per process
   uint32_t wpc = 32;
   if ((uint64_t)n_rows * n_qw < (uint64_t)ctx->n_cu * wpc * 1536u) wpc = 16;
   // A tile starts with empty lists and the radius as its threshold, and every row inside the threshold costs a walk of its block
@@ -798,7 +798,7 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
     tiles_per_xcd = n_tiles / 8u;
     blocks_per_xcd = (tiles_per_xcd * n_qw + kWavesPerBlock - 1) / kWavesPerBlock;
   }
-  const int env_share = getenv("TODHIP_K4X_SHARE") ? atoi(getenv("TODHIP_K4X_SHARE")) : 16;
+  static const int env_share = getenv("TODHIP_K4X_SHARE") ? atoi(getenv("TODHIP_K4X_SHARE")) : 16;
   const uint32_t groups = n_tiles < (uint32_t)kMergeGroups ? n_tiles : (uint32_t)kMergeGroups;
   TOD_HIP(ctx->m_part.reserve((size_t)n_tiles * K * nq_pad * sizeof(uint32_t)));
   const size_t bound_bytes = (size_t)nq_pad * sizeof(uint32_t), flag_bytes = (size_t)n_tiles * n_qw64;
@@ -832,7 +832,7 @@ int launch_topk_mfma_q32(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint
   uint32_t rows_per_tile = ((n_rows + n_tiles - 1) / n_tiles + 31u) & ~31u;
   if (rows_per_tile > kLocalMask) return TODHIP_EINVAL;
   n_tiles = (n_rows + rows_per_tile - 1) / rows_per_tile;
-  const int env_share = getenv("TODHIP_K4X_SHARE") ? atoi(getenv("TODHIP_K4X_SHARE")) : 16;
+  static const int env_share = getenv("TODHIP_K4X_SHARE") ? atoi(getenv("TODHIP_K4X_SHARE")) : 16;
   const uint32_t groups = n_tiles < (uint32_t)kMergeGroups ? n_tiles : (uint32_t)kMergeGroups;
   TOD_HIP(ctx->m_part.reserve((size_t)n_tiles * K * nq_pad * sizeof(uint32_t)));
   const size_t bound_bytes = (size_t)nq_pad * sizeof(uint32_t), flag_bytes = (size_t)n_tiles * n_qw64;
@@ -856,7 +856,8 @@ int launch_topk_mfma_q32(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint
 
 template <int K>
 int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t radius, uint64_t* d_lists, uint32_t* n_lists) {
-  if (nq <= 32u && !(getenv("TODHIP_K4X_QT") && atoi(getenv("TODHIP_K4X_QT")) > 0))
+  static const int env_qt = getenv("TODHIP_K4X_QT") ? atoi(getenv("TODHIP_K4X_QT")) : 0;     // tuning knob, read once per process
+  if (nq <= 32u && !(env_qt > 0))
     return launch_topk_mfma_q32<K>(ctx, d_q, nq, radius, d_lists, n_lists);
   // Query blocks of 32 per wave (QT): as many as the registers hold beside the k-entry lists -- 8 for k <= 2, 6 for k <= 5
   // (the reference's k, DescriptorMatcher.cpp:211), 4 beyond -- and among those the one that pads nq the least (a wave
@@ -864,7 +865,6 @@ int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t
   // With at most 64 queries a wave holds two blocks (QT = 2): 8 MFMAs per 1 KB of rows -- the pass is then bound by HBM,
   // not by the matrix pipe (BASELINE.json's "achieved HBM GB/s on BF-matcher" regime; tools/k4_small_q.py).
   constexpr int kMaxQT = K <= 2 ? 8 : (K <= 5 ? 6 : 4);
-  const int env_qt = getenv("TODHIP_K4X_QT") ? atoi(getenv("TODHIP_K4X_QT")) : 0;
   auto padded = [&](uint32_t qt) { return (nq + 32u * qt - 1u) / (32u * qt) * (32u * qt); };
   int qt = kMaxQT;
   if (kMaxQT >= 8 && padded(6) < padded((uint32_t)qt)) qt = 6;

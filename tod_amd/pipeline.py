@@ -32,17 +32,20 @@ class StagePipeline:
         # callables pick theirs by i % verify_workers) -- the verifier is latency bound, two batches in flight fill its gaps
         self.vpool = ThreadPoolExecutor(verify_workers) if verify else None
         self.vlocks = [threading.Lock() for _ in range(max(verify_workers, 1))]   # one call in flight per context
+        self.stat_lock = threading.Lock()                  # stage_s is updated from the ORB thread, the verifier workers and the caller
         self.stage_s = {"orb": 0.0, "match_issue": 0.0, "verify": 0.0}
         self.n_kp = self.n_poses = self.n_steps = 0
 
     def reset_stats(self):
-        for key in self.stage_s:
-            self.stage_s[key] = 0.0
+        with self.stat_lock:
+            for key in self.stage_s:
+                self.stage_s[key] = 0.0
 
     def _orb_task(self, i):
         t = time.perf_counter()
         n = self.orb(i)
-        self.stage_s["orb"] += time.perf_counter() - t
+        with self.stat_lock:
+            self.stage_s["orb"] += time.perf_counter() - t
         return n
 
     def _verify_task(self, i, ev):
@@ -51,7 +54,8 @@ class StagePipeline:
             ev.synchronize()                              # host side too, so that the stage time is the verifier's own
             t = time.perf_counter()
             n = self.verify(i)
-            self.stage_s["verify"] += time.perf_counter() - t
+            with self.stat_lock:
+                self.stage_s["verify"] += time.perf_counter() - t
         return n
 
     def run(self, n_steps):
@@ -75,7 +79,8 @@ class StagePipeline:
                 orb_done(i + 1)
             t = time.perf_counter()
             out_stream = self.match(i, n_steps)
-            self.stage_s["match_issue"] += time.perf_counter() - t
+            with self.stat_lock:
+                self.stage_s["match_issue"] += time.perf_counter() - t
             if self.verify:
                 ev = self.torch.cuda.Event()
                 ev.record(out_stream)                     # the matcher outputs of this step are complete after this

@@ -1,9 +1,8 @@
 # A/B of two builds of the library on one box: tod_amd/libtodhip.so (new) against tod_amd/libtodhip_head.so (a build of HEAD, not committed)
 cd "$GRAFT_REPO_ROOT"
-cp tod_amd/libtodhip.so /tmp/new.so
 for round in 1 2; do
   for which in new head; do
-    if [ $which = new ]; then cp /tmp/new.so tod_amd/libtodhip.so; else cp tod_amd/libtodhip_head.so tod_amd/libtodhip.so; fi
+    if [ $which = new ]; then unset TODHIP_LIB_PATH; else export TODHIP_LIB_PATH="$PWD/tod_amd/libtodhip_head.so"; fi   # never copied over the product file
     echo "== $which (round $round)"
     TODHIP_VERIFY_FLIGHTS=0 timeout -k 10 200 python tools/time_verify_batch.py 2>&1 | grep verify_batch || exit 1
     timeout -k 10 200 python tools/verify_ticks.py 2>&1 | grep -i "ms per\|per call" | head -3

@@ -1,9 +1,8 @@
 # A/B of wave-priority variants of the library on one box: headline pipeline only (tod_amd/libtodhip_alt{A,B}.so are not committed)
 cd "$GRAFT_REPO_ROOT"
-cp tod_amd/libtodhip.so /tmp/base.so
 for round in 1 2; do
   for which in base altA altB; do
-    if [ $which = base ]; then cp /tmp/base.so tod_amd/libtodhip.so; else cp tod_amd/libtodhip_$which.so tod_amd/libtodhip.so; fi
+    if [ $which = base ]; then unset TODHIP_LIB_PATH; else export TODHIP_LIB_PATH="$PWD/tod_amd/libtodhip_$which.so"; fi   # never copied over the product file
     timeout -k 10 300 python3 bench.py --extras= --no-cpu-baseline --repeats 3 > gpurun_out/abp_$which.json 2> gpurun_out/abp_$which.err || { tail -3 gpurun_out/abp_$which.err; exit 1; }
     python3 - gpurun_out/abp_$which.json $which $round <<'PY'
 import json, sys
@@ -12,4 +11,3 @@ print("%-6s round %s: %.0f frames/s  K4x %.3f ms  %s" % (sys.argv[2], sys.argv[3
 PY
   done
 done
-cp /tmp/base.so tod_amd/libtodhip.so

@@ -1,9 +1,8 @@
 # A/B on one box: tod_amd/libtodhip.so (new) against tod_amd/libtodhip_head.so (a build of HEAD, not committed): verifier timings
 cd "$GRAFT_REPO_ROOT"
-cp tod_amd/libtodhip.so /tmp/new.so
 for round in 1 2; do
   for which in new head; do
-    if [ $which = new ]; then cp /tmp/new.so tod_amd/libtodhip.so; else cp tod_amd/libtodhip_head.so tod_amd/libtodhip.so; fi
+    if [ $which = new ]; then unset TODHIP_LIB_PATH; else export TODHIP_LIB_PATH="$PWD/tod_amd/libtodhip_head.so"; fi   # never copied over the product file
     echo "== $which (round $round)"
     timeout -k 10 100 python tools/verify_ticks.py 2>&1 | tail -1
     timeout -k 10 200 python tools/time_verify_batch.py 2>&1 | grep verify_batch
@@ -13,4 +12,3 @@ d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]
 print('chained', [round(v) for v in d['chained']['frames_per_s']['values']], {k: round(v, 2) for k, v in d['chained']['stage_ms_per_step'].items()})"
   done
 done
-cp /tmp/new.so tod_amd/libtodhip.so

@@ -3,9 +3,8 @@
 # each also with TODHIP_L2_NO_CANDIDATES=1 (no epilogue hits)
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
-cp tod_amd/libtodhip.so /tmp/base.so
-for which in base l2abl1 l2abl2 l2abl3; do
-  if [ $which = base ]; then cp /tmp/base.so tod_amd/libtodhip.so; else cp tod_amd/libtodhip_$which.so tod_amd/libtodhip.so; fi
+for which in base l2abl1 l2abl2 l2abl3; do   # the diagnostics builds are loaded through TODHIP_LIB_PATH: the product file is never touched
+  if [ $which = base ]; then unset TODHIP_LIB_PATH; else export TODHIP_LIB_PATH="$PWD/tod_amd/libtodhip_$which.so"; fi
   for nc in 0 1; do
     rm -rf gpurun_out/prof_l2abl
     if [ $nc = 1 ]; then export TODHIP_L2_NO_CANDIDATES=1; else unset TODHIP_L2_NO_CANDIDATES; fi
@@ -18,4 +17,3 @@ for f in sorted(glob.glob("gpurun_out/prof_l2abl/**/*_kernel_stats.csv", recursi
 PY
   done
 done
-cp /tmp/base.so tod_amd/libtodhip.so
