@@ -522,11 +522,22 @@ def run_hbm_regime(torch, capi, device, args):
     ctx.close()
     alg_bytes = rows * 32 + Q * (32 + k * 8)
     gbs = alg_bytes / (out["mfma"][0] * 1e-3) / 1e9
+    # HBM traffic of this launch from the PMC passes (tools/profile_k4x_q32.sh: FETCH_SIZE and WRITE_SIZE in runs of their own,
+    # FETCH_SIZE doubled as profiles/r03_fetch_calibration.json measures for vector loads); only quoted for the shape it was taken on
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r03_k4x_q32_pmc.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        if pmc.get("queries_per_launch") == Q and pmc.get("db_rows") == rows and k == 2 and radius == 35:
+            traffic = pmc["hbm_traffic_bytes_per_launch"]
+            traffic_src = "profiles/r03_k4x_q32_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; kernel trace %.1f us)" % (
+                pmc.get("avg_duration_ns_kernel_trace", 0.0) / 1e3)
     return {"what": "%d queries per pass over a %d-row DB (%.2f GB of descriptors: five times the Infinity Cache), k=%d, radius %d; "
                     "todhip_match_device, kernel hamming_topk_mfma_q32 (one 32-query block per wave: 4 MFMAs per KB of rows)"
                     % (Q, rows, rows * 32 / 1e9, k, radius),
             "roofline": {"kernel": "hamming_topk_mfma_q32", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "launch_ms": out["mfma"][0], "algorithmic_bytes": alg_bytes, "traffic": None},
+                         "frac": gbs / HBM_PEAK_GBS, "launch_ms": out["mfma"][0], "algorithmic_bytes": alg_bytes, "traffic": traffic,
+                         "traffic_source": traffic_src},
             "vector_engine_launch_ms": out["valu"][0], "vector_engine_GBs": alg_bytes / (out["valu"][0] * 1e-3) / 1e9,
             "queries_with_a_match": out["mfma"][1], "engines_agree_on_match_count": out["mfma"][1] == out["valu"][1]}
 
