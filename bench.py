@@ -395,6 +395,33 @@ def run_chained(torch, capi, device, args):
            "pose_tolerance": "max |dR| < 0.03, max |dt| < 6 mm against the pose the view was rendered from",
            "setup_s": setup_s}
     pipe.close()
+    # the matcher's DB pass at the HEADLINE's launch shape (32 frames = 32 000 queries per pass) on this block's DB and descriptors --
+    # the data it will see: biased, correlated rBRIEF bits and self-similar textures -- alone on the GPU, on an unpartitioned stream
+    if B * 2 * nq == 32000 and R >= 2:
+        fctx = capi.Context(device)
+        fctx.set_matcher_engine(args.engine)
+        fctx.db_load(desc, pts, off)
+        de32 = torch.cat([orb_ring[0]["desc"], orb_ring[1]["desc"]]).contiguous()
+        n32 = 2 * B * nq
+        c32 = torch.zeros(n32, dtype=torch.int32, device="cuda"); m32 = torch.zeros((n32 * k, 4), dtype=torch.int32, device="cuda")
+        x32 = torch.zeros((n32 * k, 3), dtype=torch.float32, device="cuda")
+        call32 = lambda: fctx.match_device(de32.data_ptr(), n32, k, radius, c32.data_ptr(), m32.data_ptr(), x32.data_ptr())
+        for _ in range(2):
+            call32()
+        fctx.synchronize(); fctx.set_kernel_timing(True); f0 = fctx.counters()
+        for _ in range(6):
+            call32()
+        fctx.synchronize(); ms32, n32l = launch_ms(f0, fctx.counters()); fctx.set_kernel_timing(False)
+        tf32 = float(n32) * int(off[-1]) * FLOP_PER_PAIR / (ms32 * 1e-3) / 1e12 if ms32 > 0 else 0.0
+        walks = None
+        wp = os.path.join(ROOT, "profiles", "r03_k4x_on_chained_db.json")
+        if os.path.exists(wp):
+            walks = json.load(open(wp)).get("chained_db", {}).get("walk_fraction")
+        out["matcher_at_headline_shape"] = {"what": "32 000 of this block's ORB descriptors x its %d-row trained DB per launch, alone" % int(off[-1]),
+                                            "launch_ms": ms32, "launches": n32l, "TFLOPs": tf32, "frac": tf32 / MFMA_FP4_PEAK_TFLOPS,
+                                            "blocks_that_walked_rows": walks,
+                                            "blocks_source": "profiles/r03_k4x_on_chained_db.json (diagnostics build, tools/k4x_walks.sh)" if walks is not None else None}
+        fctx.close()
     for c in [mctx, octx] + vctxs:
         c.close()
     if lat_cus > 0:
@@ -643,6 +670,33 @@ def run_configs(torch, capi, synth, device, args):
     pass2_s = max(pass2_ms, 1e-6) * 1e-3
     flops = 2.0 * 1000 * d4.shape[0] * 128
     med = statistics.median(secs)
+    # ---- the batch form: 16 frames' queries share one pass over the DB (todhip_match_l2_device with F x Q queries)
+    F4 = 16
+    q16 = np.concatenate([synth.make_sift_queries(d4, 1000, frame=f)[0] for f in range(F4)])
+    dq16 = torch.from_numpy(q16).cuda()
+    cnt16 = torch.zeros(F4 * 1000, dtype=torch.int32, device="cuda"); mm16 = torch.zeros((F4 * 2000, 4), dtype=torch.int32, device="cuda")
+    xx16 = torch.zeros((F4 * 2000, 3), dtype=torch.float32, device="cuda")
+    call16 = lambda: c4.match_l2_device(dq16.data_ptr(), F4 * 1000, 2, 400.0, cnt16.data_ptr(), mm16.data_ptr(), xx16.data_ptr())
+    for _ in range(3):
+        call16()
+    c4.synchronize()
+    secs16 = []
+    for _ in range(args.repeats):
+        t0 = time.perf_counter()
+        for _ in range(10):
+            call16()
+        c4.synchronize()
+        secs16.append((time.perf_counter() - t0) / 10)
+    c4.set_kernel_timing(True)
+    k0 = c4.counters()
+    for _ in range(10):
+        call16()
+    c4.synchronize()
+    pass2_ms16, pass2_n16 = launch_ms(k0, c4.counters())
+    c4.set_kernel_timing(False)
+    med16 = statistics.median(secs16)
+    flops16 = flops * F4
+    same_as_single = bool(torch.equal(cnt16[:1000], cnt))                  # frame 0 of the batch is the single call's frame
     out["C4"] = {"workload": "C4: 1000 SIFT-128 float descriptors vs 500k-row DB, L2 brute force k=2 as a bf16 MFMA GEMM with exact f32 "
                              "refinement (todhip_match_l2_device; matcher only)",
                  "frames_per_s": spread([1.0 / s for s in secs]), "ms_per_call": med * 1e3,
@@ -659,7 +713,16 @@ def run_configs(torch, capi, synth, device, args):
                                                      "source": "profiles/r02_mfma_bf16_peak_microbench.txt (tools/mfma_bf16_peak.hip: bare "
                                                                "v_mfma_f32_32x32x16_bf16 loop, operands in registers; the clock the chip holds "
                                                                "depends on the data)"}},
-                 "queries_with_a_match": int((cnt > 0).sum().item())}
+                 "queries_with_a_match": int((cnt > 0).sum().item()),
+                 "batched": {"what": "%d frames per call: %d queries share one pass over the DB (todhip_match_l2_device, queryIdx counts through the call)" % (F4, F4 * 1000),
+                             "frames_per_s": spread([F4 / s for s in secs16]), "ms_per_call": med16 * 1e3, "ms_per_frame": med16 * 1e3 / F4,
+                             "roofline": {"bound": "mfma", "achieved": flops16 / med16 / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": flops16 / med16 / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                          "note": "2 F Q N 128 flop / the whole call",
+                                          "gemm_pass_kernel": {"name": "l2_gemm_kernel<2,4>", "us": pass2_ms16 * 1e3, "launches_timed": pass2_n16,
+                                                               "frac_of_nominal": flops16 / max(pass2_ms16 * 1e-3, 1e-9) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                                               "frac_of_measured_roof": flops16 / max(pass2_ms16 * 1e-3, 1e-9) / 1e12 / MFMA_BF16_MEASURED_TFLOPS}},
+                             "frame_0_counts_equal_the_single_call": same_as_single}}
     c4.close()
     return out
 
@@ -905,6 +968,8 @@ def main():
             progress("headline done: %.0f frames/s" % out["value"])
             if "chained" in extras:
                 out["chained"] = run_chained(torch, capi, local_rank, args)
+                if "matcher_at_headline_shape" in out["chained"]:           # the dominant kernel on the data it will see
+                    out["roofline"]["on_the_chained_db"] = out["chained"]["matcher_at_headline_shape"]
                 progress("chained done")
             if "configs" in extras:
                 out["configs"] = run_configs(torch, capi, synth, local_rank, args)

@@ -145,7 +145,10 @@ int todhip_match_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t
  * 195-252): order (distance asc, global row asc), truncated at the first distance > radius; DMatch.distance =
  * sqrtf(d2), d2 = sum over i = 0..127 in index order of (q[i] - r[i])^2 in IEEE binary32 without fused multiply-add
  * (the CPU checker of this definition is oracle/l2_oracle.c). The candidates come from a
- * bf16 MFMA GEMM with a proven error bound, the final order from the exact distances. */
+ * bf16 MFMA GEMM with a proven error bound, the final order from the exact distances.
+ * Batch form: the nq queries may be those of F frames (F x Q rows, frame f's query q at row f Q + q, which is also its
+ * queryIdx): they share ONE pass over the DB, and every query's matches are those of a call that carried its frame alone
+ * (16 frames of 1000 queries against 500k rows: 0.12 ms per frame instead of 0.19). */
 int todhip_match_l2(todhip_ctx*, const float* q_desc, uint32_t nq, uint32_t k, float radius, uint32_t* row_ptr,
                     todhip_dmatch* matches, float* matches_xyz);
 int todhip_match_l2_device(todhip_ctx*, const void* d_q_desc, uint32_t nq, uint32_t k, float radius, void* d_counts,

@@ -108,6 +108,41 @@ def test_c4_full_size_properties(ctx):
         assert np.array_equal(m[f][sel], o_m[f]), f
 
 
+def test_sixteen_frames_per_call_equal_their_single_frame_calls_and_the_oracle(ctx):
+    """The batch form: F x Q queries of F frames share one pass over the DB (queryIdx counts through the call: frame f's query q
+    is f Q + q). 16 frames x 1000 queries against the 500k-row DB: every frame's matches equal its own single-frame call's (the
+    query preparation, the seed, the thresholds and the re-ranking are per query), and 32 queries spread over the frames equal the
+    oracle bit for bit. A smaller DB (the classic two-GEMM path) with 5 frames of ragged size against the oracle in full."""
+    desc, pts, off = synth.make_sift_db(100, per_object=5000)
+    ctx.db_load(desc, pts, off)
+    F, Q, k = 16, 1000, 2
+    qs = [synth.make_sift_queries(desc, Q, frame=40 + f)[0] for f in range(F)]
+    row_ptr, m, xyz = ctx.match_l2(np.concatenate(qs), k, 400.0)
+    assert len(row_ptr) == F * Q + 1
+    for f in range(F):
+        rp1, m1, x1 = ctx.match_l2(qs[f], k, 400.0)
+        lo, hi = int(row_ptr[f * Q]), int(row_ptr[(f + 1) * Q])
+        assert np.array_equal(row_ptr[f * Q:(f + 1) * Q + 1] - row_ptr[f * Q], rp1), f
+        assert np.array_equal(m["queryIdx"][lo:hi], m1["queryIdx"] + f * Q)
+        for fld in ("trainIdx", "imgIdx", "distance"):
+            assert np.array_equal(m[fld][lo:hi], m1[fld]), (f, fld)
+        assert np.array_equal(xyz[lo:hi], x1)
+    pick = np.arange(32) * 499 + 7                                            # two queries of every frame
+    allq = np.concatenate(qs)
+    rc, o_rp, o_m, o_xyz = O.l2_match(desc, off, pts, allq[pick], k, 400.0)
+    assert rc == 0
+    for j, g in enumerate(pick):
+        lo, hi = int(row_ptr[g]), int(row_ptr[g + 1])
+        olo, ohi = int(o_rp[j]), int(o_rp[j + 1])
+        assert hi - lo == ohi - olo
+        for fld in ("trainIdx", "imgIdx", "distance"):
+            assert np.array_equal(m[fld][lo:hi], o_m[fld][olo:ohi]), (g, fld)
+    desc, pts, off = synth.make_sift_db(4, per_object=1500)                  # 6000 rows: two GEMM passes
+    ctx.db_load(desc, pts, off)
+    qs = [synth.make_sift_queries(desc, n, frame=60 + i)[0] for i, n in enumerate((130, 1, 257, 64, 300))]
+    _assert_same(ctx, desc, pts, off, np.concatenate(qs), 3, 500.0)
+
+
 def test_one_gemm_path_with_overflowing_candidate_lists(ctx):
     """A DB large enough for the one-GEMM path (>= 64k rows: the seed of an evenly spaced sample IS the candidate threshold)
     that holds 1500 near-copies of one vector: queries next to it collect more candidates than a list holds and are redone

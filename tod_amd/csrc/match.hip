@@ -325,9 +325,15 @@ __device__ __forceinline__ mfma_f32x16 dot_block(const Fp4Row& a, const Fp4Row& 
 // or beyond n_lim do not exist (the last, partial step of the DB). IMAX: thresholds are >= 0 (radius < 128; they only rise),
 // so the 16-way maximum may be taken on the raw bits as integers -- among non-negative floats the order is the same, and a
 // negative dot product can never beat a non-negative threshold -- which spares the float maximum's NaN-quieting moves.
+#ifdef TOD_K4X_COUNT_WALKS                                   // diagnostics build only (tools/k4x_walks.sh): blocks tested / blocks that walked
+__device__ unsigned long long g_k4x_blocks[2];
+#endif
 template <int K, bool MASK, bool IMAX>
 __device__ __forceinline__ void mfma_block_test(const mfma_f32x16& acc, float& thr, uint32_t r_lane, uint32_t n_lim,
                                                 uint32_t (&best)[K]) {
+#ifdef TOD_K4X_COUNT_WALKS
+  if (!MASK && (threadIdx.x & 63u) == 0u) atomicAdd(&g_k4x_blocks[0], 1ull);
+#endif
   if (!MASK) {
     bool any;
     if (IMAX) {
@@ -344,6 +350,9 @@ __device__ __forceinline__ void mfma_block_test(const mfma_f32x16& acc, float& t
       any = m > thr;
     }
     if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
+#ifdef TOD_K4X_COUNT_WALKS
+    if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_k4x_blocks[1], 1ull);
+#endif
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -1016,3 +1025,14 @@ int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_s
   TOD_HIP(hipGetLastError());
   return TODHIP_OK;
 }
+
+#ifdef TOD_K4X_COUNT_WALKS
+// diagnostics build only: {32 x 32 blocks tested, blocks whose best dot product beat a threshold (16 rows walked)} since the last reset
+extern "C" int todhip_debug_k4x_walks(unsigned long long out[2], int reset) {
+  unsigned long long zero[2] = {0ull, 0ull};
+  if (hipDeviceSynchronize() != hipSuccess) return TODHIP_EHIP;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k4x_blocks), sizeof(zero)) != hipSuccess) return TODHIP_EHIP;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_k4x_blocks), zero, sizeof(zero)) != hipSuccess) return TODHIP_EHIP;
+  return TODHIP_OK;
+}
+#endif
