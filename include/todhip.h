@@ -260,7 +260,11 @@ int todhip_orb_batch_device(todhip_ctx*, const void* d_gray, uint32_t n_frames, 
  *       it (up to 4 poses); consensus set of a pose = matches whose model point reprojects within the threshold, in front of
  *       the camera. The largest consensus set wins, the first (h, root) on ties; it must reach min_inliers.
  *     the winner is refined by 5 Gauss-Newton steps on its consensus set and the consensus set recomputed; the pose is
- *       reported if that still reaches min_inliers. One pose per object.
+ *       reported if that still reaches min_inliers. ONE pose per object, by design: the 3D branch finds further instances by
+ *       taking a pose's inlier keypoints out and trying the object again (GuessGenerator.cpp:192-231), guarded by its clique
+ *       gate; reprojection alone is too weak a constraint for that -- at the reference's min_inliers of 8 a second round
+ *       assembles chance poses from the leftovers of repeating texture (measured: 7 poses instead of 1 on the rendered-view
+ *       test). A caller that expects several instances of an object supplies depth.
  *   rng: ONE draw per call supplies the seed (hypotheses do not walk the stream, which is what lets them run side by side).
  *   outputs as todhip_verify: poses (object -> camera), inlier_kp = keypoint indices of each pose's consensus set, ascending. */
 int todhip_verify_2d(todhip_ctx*, const float* kp_xy, uint32_t nq, const float* K9, const uint32_t* row_ptr,
@@ -269,7 +273,9 @@ int todhip_verify_2d(todhip_ctx*, const float* kp_xy, uint32_t nq, const float* 
                      uint32_t* n_inlier_kp);
 
 /* The same with the keypoints and the matcher's fixed-stride outputs in HBM (what todhip_match_device / todhip_merge_shards_device
- * left there): d_kp_xy[nq*2] f32, d_counts[nq] u32, d_matches[nq*k], d_matches_xyz[nq*k*3]. Same result as the call above. */
+ * left there): d_kp_xy[nq*2] f32, d_counts[nq] u32, d_matches[nq*k], d_matches_xyz[nq*k*3]. Same result as the call above. The
+ * matches never come to the host: ClusterPerObject runs on the device, the host reads the number of objects worth a RANSAC
+ * (one word) and, at the end, the poses and their consensus flags. */
 int todhip_verify_2d_device(todhip_ctx*, const void* d_kp_xy, uint32_t nq, const float* K9, const void* d_counts, const void* d_matches,
                             const void* d_matches_xyz, uint32_t k, const float* spans, uint32_t n_objs, const todhip_verify_params*,
                             todhip_rng* rng, todhip_pose* poses, uint32_t* n_poses, uint32_t* inlier_kp, uint32_t* n_inlier_kp);

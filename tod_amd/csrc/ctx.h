@@ -126,6 +126,10 @@ int tod_match_finalize(todhip_ctx* ctx, const uint64_t* d_keys_all, uint32_t n_s
                        hipStream_t stream = nullptr);   // nullptr: the context's stream
 // verify.hip / orb.hip
 void tod_verify_ws_free(todhip_ctx* ctx);
+// verify.hip: ClusterPerObject of F frames on the device without a cloud (pnp.hip's 2D-only branch); d_err: 8 words per frame
+int tod_cluster_frames_nocloud(todhip_ctx* ctx, uint32_t F, const float* d_kp_xy, uint32_t nq, const uint32_t* d_counts,
+                               const todhip_dmatch* d_matches, const float* d_mxyz, uint32_t k, uint32_t n_objs, float* d_X,
+                               uint32_t* d_qidx, uint32_t* d_hist, uint32_t* d_goff, uint32_t* d_err);
 void tod_l2_ws_free(todhip_ctx* ctx);
 void tod_pnp_ws_free(todhip_ctx* ctx);      // pnp.hip
 // lsh.hip: the optional LSH-approximate mode (todhip_set_lsh)

@@ -389,7 +389,43 @@ __global__ __launch_bounds__(128) void pnp_refine_kernel(const ObjSpanP* __restr
   }
 }
 
-struct PnpWs { DevBuf objs, kp, q_idx, X, best, flags, results; };
+// The objects worth a RANSAC (>= 3 matches and >= min_inliers of them), in the order the host form visits them (frame major,
+// object ascending), from the per-frame histograms and offsets of the device-side ClusterPerObject. One block.
+__global__ __launch_bounds__(256) void pnp_active_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ goff,
+                                                         const float* __restrict__ spans, const uint32_t* __restrict__ seeds, uint32_t F,
+                                                         uint32_t n_objs, uint32_t per_frame, uint32_t min_inliers, uint32_t cap,
+                                                         ObjSpanP* __restrict__ objs, uint32_t* __restrict__ n_active) {
+  __shared__ uint32_t part[256], s_base;
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_base = 0u;
+  __syncthreads();
+  const uint32_t chunk = (n_objs + 255u) / 256u;
+  for (uint32_t f = 0; f < F; ++f) {
+    const uint32_t lo = min(n_objs, tid * chunk), hi = min(n_objs, lo + chunk);
+    uint32_t c = 0;
+    for (uint32_t o = lo; o < hi; ++o) { const uint32_t n = hist[(size_t)f * n_objs + o]; c += (n >= 3u && n >= min_inliers) ? 1u : 0u; }
+    part[tid] = c;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = s_base;
+      for (uint32_t i = 0; i < 256u; ++i) { const uint32_t v = part[i]; part[i] = acc; acc += v; }
+      s_base = acc;
+    }
+    __syncthreads();
+    uint32_t at = part[tid];
+    for (uint32_t o = lo; o < hi; ++o) {
+      const uint32_t n = hist[(size_t)f * n_objs + o];
+      if (n >= 3u && n >= min_inliers) {
+        if (at < cap) objs[at] = ObjSpanP{f * per_frame + goff[(size_t)f * n_objs + o], n, o, spans[o], seeds[f], f};
+        ++at;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *n_active = s_base;
+}
+
+struct PnpWs { DevBuf objs, kp, q_idx, X, best, flags, results, hist, goff, err, spans, seeds, na; };
 
 inline uint32_t rng_next(todhip_rng& r) {                            // glibc random_r TYPE_3, as in verify.hip
   r.s[r.f] += r.s[r.b];
@@ -404,7 +440,8 @@ inline uint32_t rng_next(todhip_rng& r) {                            // glibc ra
 void tod_pnp_ws_free(todhip_ctx* ctx) {
   PnpWs* ws = reinterpret_cast<PnpWs*>(ctx->pnp_ws);
   if (!ws) return;
-  DevBuf* bufs[] = {&ws->objs, &ws->kp, &ws->q_idx, &ws->X, &ws->best, &ws->flags, &ws->results};
+  DevBuf* bufs[] = {&ws->objs, &ws->kp, &ws->q_idx, &ws->X, &ws->best, &ws->flags, &ws->results, &ws->hist, &ws->goff, &ws->err, &ws->spans,
+                    &ws->seeds, &ws->na};
   for (DevBuf* b : bufs) b->release();
   delete ws;
   ctx->pnp_ws = nullptr;
@@ -523,8 +560,10 @@ extern "C" int todhip_verify_2d(todhip_ctx* ctx, const float* kp_xy, uint32_t nq
 }
 
 // Device-resident forms: keypoints and the matcher's fixed-stride outputs (exactly what todhip_match_device / todhip_merge_shards_device
-// produced, for n_frames * nq queries) are in HBM. The matches are a few tens of KB per frame: they are brought to the host, compacted to
-// CSR and handed to the core above -- hypotheses and refinement run on the GPU either way, and each frame's result is the single call's.
+// produced, for n_frames * nq queries) are in HBM and stay there: ClusterPerObject runs on the device (verify.hip's cluster_frame_kernel
+// in its cloudless mode, one block per frame), pnp_active_kernel lists the objects worth a RANSAC, the host reads ONE word (their
+// number, for the grids) and launches hypotheses + refinement; the flags, the results and the keypoint indices of the matches come
+// back once, at the end. Each frame's result is the host-buffer call's (tests/test_pnp_gpu.py).
 extern "C" int todhip_verify_2d_batch_device(todhip_ctx* ctx, uint32_t n_frames, const void* d_kp_xy, uint32_t nq, const float* K9,
                                              const void* d_counts, const void* d_matches, const void* d_matches_xyz, uint32_t k,
                                              const float* spans, uint32_t n_objs, const todhip_verify_params* prm, todhip_rng* rng,
@@ -532,40 +571,90 @@ extern "C" int todhip_verify_2d_batch_device(todhip_ctx* ctx, uint32_t n_frames,
                                              uint32_t* n_inlier_kp) {
   if (!ctx || !K9 || !prm || !rng || !n_poses || !n_inlier_kp || k == 0 || n_frames == 0) return TODHIP_EINVAL;
   if (nq && (!d_kp_xy || !d_counts || !d_matches || !d_matches_xyz)) return TODHIP_EINVAL;
+  if (!(prm->sensor_error > 0.f) || !(K9[0] > 0.f) || !(K9[4] > 0.f)) return TODHIP_EINVAL;
+  if ((*n_poses && !poses) || (*n_inlier_kp && !inlier_kp)) return TODHIP_EINVAL;
+  const uint32_t F = n_frames;
+  const uint64_t per64 = (uint64_t)nq * k;
+  if (per64 * F > 0xFFFFFFFFull || (uint64_t)F * nq > 0xFFFFFFFFull) return TODHIP_EINVAL;
   TOD_HIP(hipSetDevice(ctx->device));
-  const size_t nqa = (size_t)n_frames * nq;
-  std::vector<float> kp(2 * nqa), xyz_s(3 * nqa * k);
-  std::vector<uint32_t> counts(nqa);
-  std::vector<todhip_dmatch> m_s(nqa * k);
-  if (nqa) {
-    hipStream_t st = ctx->stream;
-    TOD_HIP(hipMemcpyAsync(kp.data(), d_kp_xy, kp.size() * 4, hipMemcpyDeviceToHost, st));
-    TOD_HIP(hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, st));
-    TOD_HIP(hipMemcpyAsync(m_s.data(), d_matches, m_s.size() * sizeof(todhip_dmatch), hipMemcpyDeviceToHost, st));
-    TOD_HIP(hipMemcpyAsync(xyz_s.data(), d_matches_xyz, xyz_s.size() * 4, hipMemcpyDeviceToHost, st));
-    TOD_HIP(hipStreamSynchronize(st));
-  }
-  std::vector<std::vector<uint32_t>> row_ptr(n_frames, std::vector<uint32_t>(nq + 1, 0u));
-  std::vector<std::vector<todhip_dmatch>> m(n_frames);
-  std::vector<std::vector<float>> xyz(n_frames);
-  std::vector<Frame2d> fr(n_frames);
-  for (uint32_t f = 0; f < n_frames; ++f) {
-    for (uint32_t q = 0; q < nq; ++q) {
-      const uint32_t c = counts[(size_t)f * nq + q];
-      if (c > k) return TODHIP_EINVAL;
-      row_ptr[f][q + 1] = row_ptr[f][q] + c;
+  const uint32_t cap_poses = *n_poses, cap_inl = *n_inlier_kp;
+  *n_poses = 0; *n_inlier_kp = 0;
+  if (pose_ptr) for (uint32_t f = 0; f <= F; ++f) pose_ptr[f] = 0;
+  std::vector<uint32_t> seeds(F);
+  for (uint32_t f = 0; f < F; ++f) seeds[f] = rng_next(rng[f]);        // the one draw a frame costs (as the host form)
+  if (nq == 0 || n_objs == 0 || !spans) return nq && n_objs && !spans ? TODHIP_EINVAL : TODHIP_OK;
+  const uint32_t per = (uint32_t)per64;
+  const size_t n_slots = (size_t)F * per;
+  // an object needs max(3, min_inliers) matches of its frame's nq k: that bounds the list of active objects
+  const uint32_t cap = F * std::min<uint32_t>(n_objs, per / std::max(3u, prm->min_inliers)) + 1u;
+  if (!ctx->pnp_ws) ctx->pnp_ws = new PnpWs();
+  PnpWs* ws = reinterpret_cast<PnpWs*>(ctx->pnp_ws);
+  hipStream_t st = ctx->stream;
+  TOD_HIP(ws->X.reserve(n_slots * 12)); TOD_HIP(ws->q_idx.reserve(n_slots * 4));
+  TOD_HIP(ws->hist.reserve((size_t)F * n_objs * 4)); TOD_HIP(ws->goff.reserve((size_t)F * n_objs * 4));
+  TOD_HIP(ws->err.reserve((size_t)F * 8 * 4)); TOD_HIP(ws->spans.reserve((size_t)n_objs * 4)); TOD_HIP(ws->seeds.reserve((size_t)F * 4));
+  TOD_HIP(ws->objs.reserve((size_t)cap * sizeof(ObjSpanP))); TOD_HIP(ws->na.reserve(64));
+  TOD_HIP(ws->best.reserve((size_t)cap * 8)); TOD_HIP(ws->flags.reserve(n_slots)); TOD_HIP(ws->results.reserve((size_t)cap * sizeof(ObjResult)));
+  TOD_HIP(hipMemcpyAsync(ws->spans.p, spans, (size_t)n_objs * 4, hipMemcpyHostToDevice, st));
+  TOD_HIP(hipMemcpyAsync(ws->seeds.p, seeds.data(), (size_t)F * 4, hipMemcpyHostToDevice, st));
+  int rc = tod_cluster_frames_nocloud(ctx, F, reinterpret_cast<const float*>(d_kp_xy), nq, reinterpret_cast<const uint32_t*>(d_counts),
+                                      reinterpret_cast<const todhip_dmatch*>(d_matches), reinterpret_cast<const float*>(d_matches_xyz), k,
+                                      n_objs, ws->X.as<float>(), ws->q_idx.as<uint32_t>(), ws->hist.as<uint32_t>(), ws->goff.as<uint32_t>(),
+                                      ws->err.as<uint32_t>());
+  if (rc != TODHIP_OK) return rc;
+  hipLaunchKernelGGL(pnp_active_kernel, dim3(1), dim3(256), 0, st, ws->hist.as<uint32_t>(), ws->goff.as<uint32_t>(), ws->spans.as<float>(),
+                     ws->seeds.as<uint32_t>(), F, n_objs, per, prm->min_inliers, cap, ws->objs.as<ObjSpanP>(), ws->na.as<uint32_t>());
+  TOD_HIP(hipGetLastError());
+  uint32_t na = 0;
+  std::vector<uint32_t> err(8 * (size_t)F);
+  TOD_HIP(hipMemcpyAsync(&na, ws->na.p, 4, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipMemcpyAsync(err.data(), ws->err.p, err.size() * 4, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
+  for (uint32_t f = 0; f < F; ++f)
+    if (err[8 * (size_t)f] != 0u) return TODHIP_EINVAL;                 // an object index outside the DB, a count beyond k
+  if (na > cap - 1u) return TODHIP_ESCRATCH;                            // (cannot happen: cap bounds the list)
+  if (na == 0 || prm->n_ransac_iterations == 0) return TODHIP_OK;
+  TOD_HIP(hipMemsetAsync(ws->best.p, 0, (size_t)na * 8, st));
+  const Cam cam{(double)K9[0], (double)K9[4], (double)K9[2], (double)K9[5]};
+  const double err2 = (double)prm->sensor_error * (double)prm->sensor_error;
+  const float* kp = reinterpret_cast<const float*>(d_kp_xy);
+  hipLaunchKernelGGL(pnp_hypotheses_kernel, dim3((prm->n_ransac_iterations + 255u) / 256u, na), dim3(256), 0, st, ws->objs.as<ObjSpanP>(),
+                     kp, ws->q_idx.as<uint32_t>(), ws->X.as<float>(), cam, prm->n_ransac_iterations, err2, ws->best.as<unsigned long long>());
+  hipLaunchKernelGGL(pnp_refine_kernel, dim3(na), dim3(64), 0, st, ws->objs.as<ObjSpanP>(), kp, ws->q_idx.as<uint32_t>(), ws->X.as<float>(),
+                     cam, err2, prm->min_inliers, ws->best.as<unsigned long long>(), ws->flags.as<uint8_t>(), ws->results.as<ObjResult>());
+  TOD_HIP(hipGetLastError());
+  std::vector<ObjResult> res(na);
+  std::vector<ObjSpanP> active(na);
+  std::vector<uint8_t> flags(n_slots);
+  std::vector<uint32_t> q_idx(n_slots);
+  TOD_HIP(hipMemcpyAsync(res.data(), ws->results.p, (size_t)na * sizeof(ObjResult), hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipMemcpyAsync(active.data(), ws->objs.p, (size_t)na * sizeof(ObjSpanP), hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipMemcpyAsync(flags.data(), ws->flags.p, n_slots, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipMemcpyAsync(q_idx.data(), ws->q_idx.p, n_slots * 4, hipMemcpyDeviceToHost, st));
+  TOD_HIP(hipStreamSynchronize(st));
+  uint32_t np = 0, ni = 0;
+  for (uint32_t a = 0; a < na; ++a) {                                   // frame major, objects ascending inside a frame
+    if (!res[a].valid) continue;
+    if (np >= cap_poses) return TODHIP_ECAPACITY;
+    todhip_pose& out = poses[np];
+    out.object = active[a].object;
+    std::memcpy(out.R, res[a].R, sizeof(out.R)); std::memcpy(out.t, res[a].t, sizeof(out.t));
+    out.inlier_begin = ni;
+    uint32_t last = 0xFFFFFFFFu;
+    for (uint32_t m = 0; m < active[a].n; ++m) {                       // keypoint indices of the frame, ascending, each once
+      const uint32_t q = q_idx[active[a].begin + m] - active[a].frame * nq;
+      if (!flags[active[a].begin + m] || q == last) continue;
+      if (ni >= cap_inl) return TODHIP_ECAPACITY;
+      inlier_kp[ni++] = last = q;
     }
-    m[f].resize(row_ptr[f][nq]); xyz[f].resize(3 * (size_t)row_ptr[f][nq]);
-    for (uint32_t q = 0; q < nq; ++q)
-      for (uint32_t j = 0; j < counts[(size_t)f * nq + q]; ++j) {
-        const size_t src = ((size_t)f * nq + q) * k + j;
-        m[f][row_ptr[f][q] + j] = m_s[src];
-        m[f][row_ptr[f][q] + j].queryIdx = (int32_t)q;                  // the matcher numbered the batch's queries through; per frame here
-        std::memcpy(&xyz[f][3 * (size_t)(row_ptr[f][q] + j)], &xyz_s[3 * src], 12);
-      }
-    fr[f] = Frame2d{kp.data() + 2 * (size_t)f * nq, row_ptr[f].data(), m[f].data(), xyz[f].data()};
+    out.inlier_end = ni;
+    ++np;
+    if (pose_ptr) pose_ptr[active[a].frame + 1] = np;
   }
-  return verify_2d_core(ctx, n_frames, fr.data(), nq, K9, spans, n_objs, prm, rng, poses, n_poses, pose_ptr, inlier_kp, n_inlier_kp);
+  if (pose_ptr) for (uint32_t f = 0; f < F; ++f) pose_ptr[f + 1] = std::max(pose_ptr[f + 1], pose_ptr[f]);   // frames without a pose
+  *n_poses = np; *n_inlier_kp = ni;
+  ctx->counters.last_poses = np;
+  return TODHIP_OK;
 }
 
 extern "C" int todhip_verify_2d_device(todhip_ctx* ctx, const void* d_kp_xy, uint32_t nq, const float* K9, const void* d_counts,

@@ -1842,7 +1842,7 @@ __global__ __launch_bounds__(256) void cluster_group_kernel(Slots<GroupArgs> SL)
 // between the scatter and the grouping were 0.4-0.5 ms per batch there (45 us alone).
 struct ClusterArgs {
   const float* kp_xy; const float* cloud; const void* depth; const uint32_t* counts; const todhip_dmatch* matches; const float* mxyz;
-  uint32_t nq, k, H, Wimg, n_objs; int depth_is_u16; float fx, fy, cx, cy;
+  uint32_t nq, k, H, Wimg, n_objs, qidx_add; int depth_is_u16; float fx, fy, cx, cy;   // qidx_add: added to the keypoint index stored per match
   uint32_t *kept, *offs, *obj_of, *src, *hist, *goff, *cnt; float* qpt;          // device scratch
   float *train, *query, *kpxy; uint32_t* qidx;                                    // grouped outputs
   uint32_t *m_hist, *m_ctl;                                                       // mailbox (pinned): histogram; [0] error, [4] n_all
@@ -1858,9 +1858,12 @@ __global__ __launch_bounds__(256) void cluster_frame_kernel(Slots<ClusterArgs> S
   // ---- the keypoint's 3D point (adjacency_ransac.cpp:184-189), see cluster_lookup_kernel
   for (uint32_t q = tid; q < nq; q += 256u) {
     const int row = (int)a.kp_xy[2 * q + 1], col = (int)a.kp_xy[2 * q];    // float -> int truncation (:185)
-    if (row < 0 || col < 0 || (uint32_t)row >= a.H || (uint32_t)col >= a.Wimg) { atomicExch(&s_err, 1u); a.kept[q] = 0; continue; }
+    const bool lookup = a.cloud || a.depth;                                // neither: the 2D-only branch (GuessGenerator.cpp:147-152), no 3D point
+    if (lookup && (row < 0 || col < 0 || (uint32_t)row >= a.H || (uint32_t)col >= a.Wimg)) { atomicExch(&s_err, 1u); a.kept[q] = 0; continue; }
     float x, y, z;
-    if (a.cloud) {
+    if (!lookup) {
+      x = y = z = 0.f;
+    } else if (a.cloud) {
       const float* p = a.cloud + 3 * ((size_t)row * a.Wimg + col);
       x = p[0]; y = p[1]; z = p[2];
     } else {
@@ -1873,7 +1876,9 @@ __global__ __launch_bounds__(256) void cluster_frame_kernel(Slots<ClusterArgs> S
       x = ((float)col - a.cx) * z / a.fx; y = ((float)row - a.cy) * z / a.fy;
     }
     a.qpt[3 * q] = x; a.qpt[3 * q + 1] = y; a.qpt[3 * q + 2] = z;
-    a.kept[q] = isnan(x) ? 0u : a.counts[q];                               // only .x is tested (:189)
+    uint32_t c_q = a.counts[q];
+    if (c_q > k) { atomicExch(&s_err, 3u); c_q = k; }                      // (a count beyond the fixed stride: refused)
+    a.kept[q] = isnan(x) ? 0u : c_q;                                       // only .x is tested (:189)
   }
   __syncthreads();
   // ---- exclusive scan of kept -> offs: the flat order (query asc, rank asc) of the reference's push_back
@@ -1945,7 +1950,7 @@ __global__ __launch_bounds__(256) void cluster_frame_kernel(Slots<ClusterArgs> S
       const uint32_t d = a.goff[o] + seen + before;
       const uint32_t t = a.src[f], q = t / k;
       for (int c = 0; c < 3; ++c) { a.train[3 * d + c] = a.mxyz[(size_t)t * 3 + c]; a.query[3 * d + c] = a.qpt[3 * q + c]; }
-      a.qidx[d] = q;
+      a.qidx[d] = q + a.qidx_add;
       a.kpxy[2 * d] = a.kp_xy[2 * q]; a.kpxy[2 * d + 1] = a.kp_xy[2 * q + 1];
       if (after == 0u) a.cnt[o] = seen + before + 1u;       // the object's last match of the chunk
     }
@@ -2332,7 +2337,7 @@ struct Engine {
     if (s.ph == PH_CLUSTER) {                               // ClusterPerObject, one launch (cluster_frame_kernel)
       ClusterArgs ca;
       ca.kp_xy = s.d_kp_xy; ca.cloud = s.use_depth ? nullptr : s.d_cloud; ca.depth = s.dep.d_depth; ca.counts = s.d_counts;
-      ca.matches = s.d_matches; ca.mxyz = s.d_mxyz; ca.nq = nq; ca.k = k; ca.H = H; ca.Wimg = Wimg; ca.n_objs = n_objs;
+      ca.matches = s.d_matches; ca.mxyz = s.d_mxyz; ca.nq = nq; ca.k = k; ca.H = H; ca.Wimg = Wimg; ca.n_objs = n_objs; ca.qidx_add = 0u;
       ca.depth_is_u16 = s.dep.is_u16; ca.fx = s.dep.fx; ca.fy = s.dep.fy; ca.cx = s.dep.cx; ca.cy = s.dep.cy;
       ca.kept = ws->c_kept.as<uint32_t>(); ca.offs = ws->c_offs.as<uint32_t>(); ca.obj_of = ws->c_obj.as<uint32_t>();
       ca.src = ws->c_src.as<uint32_t>(); ca.hist = ws->c_hist.as<uint32_t>(); ca.goff = ws->c_goff.as<uint32_t>();
@@ -3111,6 +3116,38 @@ struct Engine {
 };
 
 }  // namespace
+
+// ClusterPerObject of F frames without a cloud, for the 2D-only branch (pnp.hip): per frame f the matches grouped by object -- model
+// points into d_X and keypoint indices f nq + q into d_qidx, both at [f nq k, ...) -- and per object its count and offset
+// (d_hist, d_goff: F x n_objs). One launch, nothing comes to the host; d_err[f] != 0: the frame's inputs were refused.
+int tod_cluster_frames_nocloud(todhip_ctx* ctx, uint32_t F, const float* d_kp_xy, uint32_t nq, const uint32_t* d_counts,
+                               const todhip_dmatch* d_matches, const float* d_mxyz, uint32_t k, uint32_t n_objs, float* d_X,
+                               uint32_t* d_qidx, uint32_t* d_hist, uint32_t* d_goff, uint32_t* d_err) {
+  Engine E = {ctx, ctx->stream, nq, 0xFFFFFFFFu, 0xFFFFFFFFu, k, n_objs, nullptr, nullptr, {}};
+  std::vector<ClusterArgs> v;
+  const size_t per = (size_t)nq * k;
+  for (uint32_t f = 0; f < F; ++f) {
+    Slot s;
+    s.ws = ws_of(ctx, f);
+    int rc = E.reserve_common(s);
+    if (rc == TODHIP_OK) rc = E.reserve_cluster(s);
+    if (rc != TODHIP_OK) return rc;
+    VerifyWs* ws = s.ws;
+    ClusterArgs ca;
+    ca.kp_xy = d_kp_xy + 2 * (size_t)f * nq; ca.cloud = nullptr; ca.depth = nullptr; ca.counts = d_counts + (size_t)f * nq;
+    ca.matches = d_matches + f * per; ca.mxyz = d_mxyz + 3 * f * per; ca.nq = nq; ca.k = k; ca.H = ca.Wimg = 0xFFFFFFFFu; ca.n_objs = n_objs;
+    ca.qidx_add = f * nq; ca.depth_is_u16 = 0; ca.fx = ca.fy = 1.f; ca.cx = ca.cy = 0.f;
+    ca.kept = ws->c_kept.as<uint32_t>(); ca.offs = ws->c_offs.as<uint32_t>(); ca.obj_of = ws->c_obj.as<uint32_t>();
+    ca.src = ws->c_src.as<uint32_t>(); ca.hist = d_hist + (size_t)f * n_objs; ca.goff = d_goff + (size_t)f * n_objs;
+    ca.cnt = ws->c_cnt.as<uint32_t>(); ca.qpt = ws->c_qpt.as<float>();
+    ca.train = d_X + 3 * f * per; ca.query = ws->query.as<float>(); ca.kpxy = ws->kpxy.as<float>(); ca.qidx = d_qidx + f * per;
+    ca.m_hist = ws->m_hist.as<uint32_t>(); ca.m_ctl = d_err + 8 * (size_t)f;       // [0] error, [4] matches kept (device words here)
+    v.push_back(ca);
+  }
+  launch_list(ctx->stream, cluster_frame_kernel, v, 256, 0, 0, [](const ClusterArgs&) { return dim3(1); });
+  TOD_HIP(hipGetLastError());
+  return TODHIP_OK;
+}
 
 void tod_verify_ws_free(todhip_ctx* ctx) {
   if (!ctx->verify_ws) return;
