@@ -103,6 +103,10 @@ int  todhip_set_matcher_engine(todhip_ctx*, int engine);
  * points and the object table are always complete. spans_out (n_objs floats) may be NULL. */
 int todhip_db_load(todhip_ctx*, const todhip_object* objs, uint32_t n_objs, uint32_t desc_bytes,
                    uint32_t shard_rank, uint32_t shard_count, float* spans_out);
+/* The same ingest from attachments that are already in this device's memory (objs[i].desc / .pts_xyz are device pointers, e.g.
+ * todhip_model_device's): device-to-device copies, the spans computed there (identical values), n_objs floats come back. */
+int todhip_db_load_device(todhip_ctx*, const todhip_object* objs, uint32_t n_objs, uint32_t desc_bytes,
+                          uint32_t shard_rank, uint32_t shard_count, float* spans_out);
 int todhip_db_info(const todhip_ctx*, uint64_t* total_rows, uint64_t* shard_first_row, uint64_t* shard_rows,
                    uint32_t* n_objs);
 
@@ -314,6 +318,10 @@ int  todhip_rescale_depth_device(todhip_ctx*, const void* d_depth_in, int depth_
                                  void* d_depth_out, uint32_t H, uint32_t W, int nearest);
 /* *n: capacity in rows in, rows out. desc: rows x 32, pts_xyz: rows x 3 (object/world frame). */
 int  todhip_model_finish(todhip_ctx*, todhip_model*, uint8_t* desc, float* pts_xyz, uint32_t* n);
+/* The model where it is: device pointers of its descriptors (n x 32 u8) and points (n x 3 f32), valid until todhip_model_free.
+ * With todhip_db_load_device a freshly trained model reaches the matcher without visiting the host (the reference writes it to
+ * CouchDB, ModelFiller.cpp:23-24, and DescriptorMatcher::parameter_callback reads it back, DescriptorMatcher.cpp:60-129). */
+int  todhip_model_device(todhip_ctx*, todhip_model*, const void** d_desc, const void** d_pts_xyz, uint32_t* n);
 void todhip_model_free(todhip_ctx*, todhip_model*);
 
 /* ---- diagnostics --------------------------------------------------------------------------------- */

@@ -54,6 +54,46 @@ def test_model_from_three_observations(u16):
     ctx.close()
 
 
+def test_trained_models_load_device_to_device():
+    """todhip_model_device + todhip_db_load_device: three models (one of them empty) go from the trainer's device buffers into the
+    matcher's DB without a host copy; spans, shard layout and matches equal those of the finish() -> todhip_db_load path."""
+    ctx, ref = capi.Context(0), capi.Context(0)
+    models, descs, ptss = [], [], []
+    for o in range(3):
+        model = capi.Model(ctx, 3000)
+        for view in range(0 if o == 1 else 2):                                  # object 1 stays empty
+            img, mask, depth, z, K, R, T = _observation(view + o, False)
+            model.add_observation(img, mask, depth, K, R, T)
+        d, p = model.finish()
+        models.append(model); descs.append(d); ptss.append(p)
+    spans_dev, off_dev = ctx.db_load_models(models)
+    desc, pts = np.concatenate(descs), np.concatenate(ptss)
+    off = np.concatenate([[0], np.cumsum([len(d) for d in descs])]).astype(np.uint32)
+    spans_host = ref.db_load(desc, pts, off)
+    assert np.array_equal(off_dev, off) and len(descs[1]) == 0 and len(descs[0]) > 500
+    assert np.array_equal(spans_dev.view(np.uint32), np.asarray(spans_host, np.float32).view(np.uint32))
+    for m in models:
+        m.close()                                                               # the DB holds its own copy
+    q = np.concatenate([descs[0][5:60], descs[2][100:140]])
+    a, b = ctx.match(q, 3, 40), ref.match(q, 3, 40)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert (a[1]["distance"][a[0][:-1]] == 0).all()
+    for rank in range(2):                                                       # the sharded form of the same load
+        models2 = []
+        for o in range(3):
+            model = capi.Model(ctx, 3000)
+            for view in range(0 if o == 1 else 2):
+                img, mask, depth, z, K, R, T = _observation(view + o, False)
+                model.add_observation(img, mask, depth, K, R, T)
+            models2.append(model)
+        ctx.db_load_models(models2, rank, 2)
+        ref.db_load(desc, pts, off, rank, 2)
+        assert ctx.db_info() == ref.db_info()
+        for m in models2:
+            m.close()
+    ctx.close(); ref.close()
+
+
 def test_masked_orb_only_returns_keypoints_inside_the_mask():
     ctx = capi.Context(0)
     img, mask, depth, z, K, R, T = _observation(0, False)

@@ -55,14 +55,14 @@ class Counters(C.Structure):
 # every symbol include/todhip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "todhip_version", "todhip_create", "todhip_destroy", "todhip_stream", "todhip_last_hip_error",
-    "todhip_synchronize", "todhip_get_counters", "todhip_set_cu_partition", "todhip_stream_create", "todhip_stream_destroy", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_set_ratio_test", "todhip_db_load", "todhip_db_info",
+    "todhip_synchronize", "todhip_get_counters", "todhip_set_cu_partition", "todhip_stream_create", "todhip_stream_destroy", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_set_ratio_test", "todhip_db_load", "todhip_db_load_device", "todhip_db_info",
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device", "todhip_merge_shards_device_on",
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_orb_masked", "todhip_test_clique", "todhip_test_clique_gate",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
     "todhip_orb_device", "todhip_verify_device_depth", "todhip_orb_batch_device",
     "todhip_verify_batch_device", "todhip_verify_batch_device_depth",
     "todhip_match_l2", "todhip_match_l2_device",
-    "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_free",
+    "todhip_model_begin", "todhip_model_add_observation", "todhip_model_finish", "todhip_model_device", "todhip_model_free",
     "todhip_rescale_depth", "todhip_rescale_depth_device", "todhip_verify_2d", "todhip_verify_2d_device", "todhip_verify_2d_batch_device", "todhip_set_lsh",
 ]
 
@@ -178,6 +178,20 @@ class Context:
                                   C.c_uint32(shard_count), _np_ptr(spans))
         _check(rc, "todhip_db_load")
         return spans[:n_obj]
+
+    def db_load_models(self, models, shard_rank=0, shard_count=1):
+        """Object DB straight from trained models (capi.Model) in this device's memory: no host copy of descriptors or points
+        (todhip_model_device + todhip_db_load_device). Returns (spans, obj_off)."""
+        objs = (TodObject * len(models))()
+        off = [0]
+        for i, m in enumerate(models):
+            d, p, n = m.device()
+            objs[i].desc, objs[i].pts_xyz, objs[i].n = d, p, n
+            off.append(off[-1] + n)
+        spans = np.zeros(len(models), np.float32)
+        _check(lib().todhip_db_load_device(self._h, objs, C.c_uint32(len(models)), C.c_uint32(32), C.c_uint32(shard_rank),
+                                           C.c_uint32(shard_count), _np_ptr(spans)), "todhip_db_load_device")
+        return spans, np.asarray(off, np.uint32)
 
     def db_info(self):
         tot, first, rows, nobj = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
@@ -550,6 +564,12 @@ class Model:
                                                 C.c_float(scale_factor), None, C.byref(n))
         _check(rc, "todhip_model_add_observation")
         return n.value
+
+    def device(self):
+        """(device pointer of the descriptors, device pointer of the points, rows) -- valid until close()."""
+        d, p, n = C.c_void_p(), C.c_void_p(), C.c_uint32()
+        _check(lib().todhip_model_device(self._ctx._h, self._h, C.byref(d), C.byref(p), C.byref(n)), "todhip_model_device")
+        return d.value, p.value, n.value
 
     def finish(self):
         desc = np.zeros((self._cap, 32), np.uint8)

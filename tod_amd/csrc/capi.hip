@@ -168,8 +168,29 @@ static void shard_bounds(const std::vector<uint32_t>& off, uint32_t n_objs, uint
   *obj_hi = hi;
 }
 
-int todhip_db_load(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, uint32_t desc_bytes,
-                   uint32_t shard_rank, uint32_t shard_count, float* spans_out) {
+// span of every object on the device (DescriptorMatcher.cpp:104-121): min / max are exact, the sum and the root are the host's
+__global__ __launch_bounds__(256) void spans_kernel(const float* __restrict__ pts, const uint32_t* __restrict__ obj_off, float* __restrict__ spans) {
+  __shared__ float s_mn[3][256], s_mx[3][256];
+  const uint32_t o = blockIdx.x, lo = obj_off[o], hi = obj_off[o + 1], tid = threadIdx.x;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t i = lo + tid; i < hi; i += 256u)
+    for (int c = 0; c < 3; ++c) { const float v = pts[3 * (size_t)i + c]; mn[c] = std::min(mn[c], v); mx[c] = std::max(mx[c], v); }
+  for (int c = 0; c < 3; ++c) { s_mn[c][tid] = mn[c]; s_mx[c][tid] = mx[c]; }
+  __syncthreads();
+  for (uint32_t st = 128; st > 0; st >>= 1) {
+    if (tid < st)
+      for (int c = 0; c < 3; ++c) { s_mn[c][tid] = std::min(s_mn[c][tid], s_mn[c][tid + st]); s_mx[c][tid] = std::max(s_mx[c][tid], s_mx[c][tid + st]); }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float s = (s_mx[0][0] - s_mn[0][0]) * (s_mx[0][0] - s_mn[0][0]) + (s_mx[1][0] - s_mn[1][0]) * (s_mx[1][0] - s_mn[1][0]) +
+                    (s_mx[2][0] - s_mn[2][0]) * (s_mx[2][0] - s_mn[2][0]);
+    spans[o] = sqrtf(s);
+  }
+}
+
+static int db_load_impl(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, uint32_t desc_bytes,
+                        uint32_t shard_rank, uint32_t shard_count, float* spans_out, bool device_src) {
   if (!ctx || (!objs && n_objs) || shard_count == 0 || shard_rank >= shard_count) return TODHIP_EINVAL;
   // 32: 256-bit binary descriptors (ORB), Hamming; 512: 128 x f32 (SIFT-like), L2 -- one device only
   if (desc_bytes != 32 && !(desc_bytes == 512 && shard_count == 1)) return TODHIP_EINVAL;
@@ -185,7 +206,7 @@ int todhip_db_load(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, 
   ctx->h_obj_off[n_objs] = (uint32_t)total;
   // spans: diagonal of the axis-aligned bounding box of the model points, DescriptorMatcher.cpp:104-121
   ctx->h_spans.assign(n_objs, 0.f);
-  for (uint32_t o = 0; o < n_objs; ++o) {
+  for (uint32_t o = 0; o < n_objs && !device_src; ++o) {
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     const float* p = objs[o].pts_xyz;
     for (uint32_t i = 0; i < objs[o].n; ++i)
@@ -216,15 +237,29 @@ int todhip_db_load(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, 
   for (uint32_t o = obj_lo; o < obj_hi; ++o) {
     if (objs[o].n)
       TOD_HIP(hipMemcpyAsync(ctx->db_desc.as<uint8_t>() + row * desc_bytes, objs[o].desc,
-                             (size_t)objs[o].n * desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+                             (size_t)objs[o].n * desc_bytes, device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     row += objs[o].n;
   }
   for (uint32_t o = 0; o < n_objs; ++o)
     if (objs[o].n)
       TOD_HIP(hipMemcpyAsync(ctx->db_pts.as<float>() + (size_t)ctx->h_obj_off[o] * 3, objs[o].pts_xyz,
-                             (size_t)objs[o].n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+                             (size_t)objs[o].n * 3 * sizeof(float), device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   TOD_HIP(hipMemcpyAsync(ctx->db_obj_off.p, ctx->h_obj_off.data(), (size_t)(n_objs + 1) * sizeof(uint32_t),
                          hipMemcpyHostToDevice, ctx->stream));
+  if (device_src && n_objs) {                               // the model points never left the device: spans there, n_objs floats back
+    DevBuf d_spans;
+    TOD_HIP(d_spans.reserve((size_t)n_objs * sizeof(float)));
+    hipLaunchKernelGGL(spans_kernel, dim3(n_objs), dim3(256), 0, ctx->stream, ctx->db_pts.as<float>(), ctx->db_obj_off.as<uint32_t>(),
+                       d_spans.as<float>());
+    hipError_t e = hipMemcpyAsync(ctx->h_spans.data(), d_spans.p, (size_t)n_objs * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d_spans.release();
+    if (e != hipSuccess) { ctx->last_hip_error = (int)e; return TODHIP_EHIP; }
+    for (uint32_t o = 0; o < n_objs; ++o) {
+      if (objs[o].n == 0) ctx->h_spans[o] = std::sqrt(3.f * (-FLT_MAX - FLT_MAX) * (-FLT_MAX - FLT_MAX));   // the host loop's result for no points
+      if (spans_out) spans_out[o] = ctx->h_spans[o];
+    }
+  }
   if (desc_bytes == 512) {
     int rc = tod_l2_db_prepare(ctx);
     if (rc != TODHIP_OK) return rc;
@@ -235,6 +270,16 @@ int todhip_db_load(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, 
   }
   TOD_HIP(hipStreamSynchronize(ctx->stream));
   return TODHIP_OK;
+}
+
+int todhip_db_load(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, uint32_t desc_bytes,
+                   uint32_t shard_rank, uint32_t shard_count, float* spans_out) {
+  return db_load_impl(ctx, objs, n_objs, desc_bytes, shard_rank, shard_count, spans_out, false);
+}
+
+int todhip_db_load_device(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_objs, uint32_t desc_bytes,
+                          uint32_t shard_rank, uint32_t shard_count, float* spans_out) {
+  return db_load_impl(ctx, objs, n_objs, desc_bytes, shard_rank, shard_count, spans_out, true);
 }
 
 int todhip_db_info(const todhip_ctx* ctx, uint64_t* total_rows, uint64_t* shard_first_row, uint64_t* shard_rows,

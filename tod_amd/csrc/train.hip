@@ -293,6 +293,20 @@ int todhip_rescale_depth(todhip_ctx* ctx, const void* depth_in, int depth_is_u16
 }
 
 // mergePoints (training.cpp:147-173) + ModelFiller (ModelFiller.cpp:20-26): the stacked descriptors and points.
+// the model where it is: device pointers of its descriptors (n x 32) and points (n x 3 f32), valid until todhip_model_free --
+// todhip_db_load_device takes them as a todhip_object, so a freshly trained model reaches the matcher without visiting the host
+int todhip_model_device(todhip_ctx* ctx, todhip_model* m, const void** d_desc, const void** d_pts_xyz, uint32_t* n) {
+  if (!ctx || !m || !n) return TODHIP_EINVAL;
+  TOD_HIP(hipSetDevice(ctx->device));
+  uint32_t rows = 0;
+  TOD_HIP(hipMemcpyAsync(&rows, m->small.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  TOD_HIP(hipStreamSynchronize(ctx->stream));                 // (every observation's kernels have run: the buffers are complete)
+  *n = rows;
+  if (d_desc) *d_desc = m->desc.p;
+  if (d_pts_xyz) *d_pts_xyz = m->pts.p;
+  return TODHIP_OK;
+}
+
 int todhip_model_finish(todhip_ctx* ctx, todhip_model* m, uint8_t* desc, float* pts, uint32_t* n) {
   if (!ctx || !m || !n) return TODHIP_EINVAL;
   TOD_HIP(hipSetDevice(ctx->device));
