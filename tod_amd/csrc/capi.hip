@@ -59,6 +59,7 @@ void todhip_destroy(todhip_ctx* ctx) {
   ctx->db_desc.release(); ctx->db_pts.release(); ctx->db_obj_off.release();
   ctx->m_q.release(); ctx->m_part.release(); ctx->m_keys.release(); ctx->m_counts.release();
   ctx->m_matches.release(); ctx->m_xyz.release(); ctx->m_bound.release(); ctx->h_stage.release();
+  ctx->k4x_stats_host.release(); ctx->k4x_stats_dev.release();
   for (int i = 0; i < 2 * todhip_ctx::kEvPairs; ++i)
     if (ctx->evp[i]) (void)hipEventDestroy(ctx->evp[i]);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

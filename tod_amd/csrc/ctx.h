@@ -97,6 +97,10 @@ struct todhip_ctx {
   uint64_t ev_head = 0, ev_tail = 0;   // pairs [ev_tail, ev_head) are recorded and not yet read
   todhip_counters counters = {};
   int matcher_engine = TODHIP_ENGINE_AUTO;   // todhip_set_matcher_engine
+  // K4x's half-block mode (match.hip, launch_topk_mfma_qt): cumulative {blocks that went on, blocks} of the launches in that mode,
+  // as the merge kernel leaves them in pinned memory; launches left before the next probe
+  HostBuf k4x_stats_host; DevBuf k4x_stats_dev;
+  uint32_t k4x_seq_sent = 0, k4x_seq_seen = 0, k4x_skip = 0, k4x_last[2] = {0, 0};
   float ratio = 0.f;                         // todhip_set_ratio_test (0 = off)
 
   std::vector<todhip_round_trace> traces;

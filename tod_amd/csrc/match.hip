@@ -23,6 +23,9 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <cstdio>
+#include <cstring>
+
 #include "ctx.h"
 
 namespace {
@@ -369,17 +372,49 @@ __device__ __forceinline__ void mfma_block_test(const mfma_f32x16& acc, float& t
   thr = fmaxf(thr, thr_of_limit(best[K - 1] >> kLocalBits));       // thresholds only ever tighten
 }
 
+// The same in two halves: bit positions {0..63} + {128..191} first (MFMAs 0, 1), the rest behind a test (mfma_block_test_half)
+__device__ __forceinline__ mfma_f32x16 dot_half0(const Fp4Row& a, const Fp4Row& b) {
+  mfma_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a.s[0], b.s[0], acc, 4, 4, 0, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a.s[1], b.s[1], acc, 4, 4, 0, 0, 0, 0);
+  return acc;
+}
+// Partial-distance elimination on the matrix cores (K4's idea, a block at a time): after 128 of the 256 bit positions the
+// accumulator holds 128 - 2 d128 with d128 <= d, so a pair whose partial dot product is not above thr - 128 (d128 >= limit) cannot
+// be a hit whatever the other 128 positions say -- exact for any data. On independent bits d128 of a non-match is 64 +- 5.7 and
+// the radius 35: one block in five thousand goes on to its other two MFMAs. Needs thr - 128 >= 0 for the integer maximum (limits
+// up to 64; thresholds only tighten). rows / q: the fragments the block's first half was computed from.
+template <int K>
+__device__ __forceinline__ bool mfma_block_test_half(mfma_f32x16& acc, const Fp4Row& rows, const Fp4Row& q, float& thr, uint32_t r_lane,
+                                                     uint32_t n_lim, uint32_t (&best)[K]) {
+  int m = max(max(__float_as_int(acc[0]), __float_as_int(acc[1])), __float_as_int(acc[2]));
+#pragma unroll
+  for (int i = 3; i < 15; i += 2) m = max(max(m, __float_as_int(acc[i])), __float_as_int(acc[i + 1]));
+  m = max(m, __float_as_int(acc[15]));
+  if (__builtin_amdgcn_ballot_w64(m > __float_as_int(thr - 128.f)) == 0ull) return false;
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rows.s[2], q.s[2], acc, 4, 4, 0, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rows.s[3], q.s[3], acc, 4, 4, 0, 0, 0, 0);
+  mfma_block_test<K, false, true>(acc, thr, r_lane, n_lim, best);
+  return true;
+}
+
 // One 32-row step: QT x 4 MFMAs against the resident query fragments. The test of block t-1 (and, in the first four
 // blocks, the fp4 expansion of the NEXT step's packed rows) sits in the same basic block as the MFMAs of block t, so the
 // vector ALU works in the matrix pipe's shadow; the last block's test is carried into the next step: QT is even, so it
 // waits in acc_odd while block 0 of the next step fills acc_even.
-template <int K, int QT, bool MASK, bool IMAX>
-__device__ __forceinline__ void mfma_step(const Fp4Row& a, Fp4Row& a_next, const uint4& p_next, const Fp4Row (&qb)[QT],
-                                          float (&thr)[QT], uint32_t (&best)[QT][K], mfma_f32x16& acc_even,
-                                          mfma_f32x16& acc_odd, uint32_t r_lane, uint32_t n_lim, const Fp4Consts& kc) {
+// HALF (never with MASK): every block starts with its first two MFMAs (dot_half0) and only completes behind mfma_block_test_half;
+// the block carried in from the previous step (t == 0) completes with that step's rows, which are a_next's registers 2 and 3 until
+// this step's expansion overwrites them at t == 2, 3.
+template <int K, int QT, bool MASK, bool IMAX, bool HALF = false>
+__device__ __forceinline__ uint32_t mfma_step(const Fp4Row& a, Fp4Row& a_next, const uint4& p_next, const Fp4Row (&qb)[QT],
+                                              float (&thr)[QT], uint32_t (&best)[QT][K], mfma_f32x16& acc_even,
+                                              mfma_f32x16& acc_odd, uint32_t r_lane, uint32_t n_lim, const Fp4Consts& kc) {
+  uint32_t n_pass = 0;                                     // HALF: blocks that went on to their second half (wave-uniform)
+  static_assert(!(HALF && MASK) && !(HALF && !IMAX) && !(HALF && QT < 4), "half blocks: unmasked steps, integer maximum, >= 4 query blocks");
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    if (t & 1) acc_odd = dot_block(a, qb[t]); else acc_even = dot_block(a, qb[t]);
+    if (HALF) { if (t & 1) acc_odd = dot_half0(a, qb[t]); else acc_even = dot_half0(a, qb[t]); }
+    else { if (t & 1) acc_odd = dot_block(a, qb[t]); else acc_even = dot_block(a, qb[t]); }
 #if defined(TOD_K4X_ABLATE) && TOD_K4X_ABLATE == 3           // diagnostics build only: no fp4 expansion (the packed words are "used")
     if (t == 0) { a_next = a; asm volatile("" :: "v"(p_next.x), "v"(p_next.y), "v"(p_next.z), "v"(p_next.w)); }
 #else
@@ -396,13 +431,21 @@ __device__ __forceinline__ void mfma_step(const Fp4Row& a, Fp4Row& a_next, const
 #if defined(TOD_K4X_ABLATE) && TOD_K4X_ABLATE == 2           // diagnostics build only: no block test (the MFMAs stay: their results are "used")
     if (t == 0) asm volatile("" :: "v"(acc_odd)); else if (t & 1) asm volatile("" :: "v"(acc_even)); else asm volatile("" :: "v"(acc_odd));
 #else
-    if (t == 0) mfma_block_test<K, MASK, IMAX>(acc_odd, thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]);   // previous step's last block
-    else mfma_block_test<K, MASK, IMAX>((t & 1) ? acc_even : acc_odd, thr[t - 1], r_lane, n_lim, best[t - 1]);
+    if (HALF) {
+      if (t == 0) n_pass += mfma_block_test_half<K>(acc_odd, a_next, qb[QT - 1], thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]) ? 1u : 0u;   // previous step's last block, its rows
+      else n_pass += mfma_block_test_half<K>((t & 1) ? acc_even : acc_odd, a, qb[t - 1], thr[t - 1], r_lane, n_lim, best[t - 1]) ? 1u : 0u;
+    } else {
+      if (t == 0) mfma_block_test<K, MASK, IMAX>(acc_odd, thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]);   // previous step's last block
+      else mfma_block_test<K, MASK, IMAX>((t & 1) ? acc_even : acc_odd, thr[t - 1], r_lane, n_lim, best[t - 1]);
+    }
 #endif
   }
+  return n_pass;
 }
 
-template <int K, int QT, bool IMAX, bool PF2>
+// MODE 0: float maximum in the block test (any radius); 1: integer maximum (cut <= 128: thresholds >= 0); 2: integer maximum and
+// half blocks (cut <= 64: mfma_block_test_half)
+template <int K, int QT, int MODE, bool PF2>
 __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* __restrict__ db,
                                                                const uint32_t* __restrict__ q, uint32_t n_rows,
                                                                uint32_t nq, uint32_t nq_pad, uint32_t rows_per_tile,
@@ -410,8 +453,9 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
                                                                uint32_t blocks_per_xcd, uint32_t tiles_per_xcd, uint32_t cut,
                                                                uint32_t share_period,
                                                                uint32_t* __restrict__ part, uint32_t* bound,
-                                                               uint8_t* __restrict__ stored) {
+                                                               uint8_t* __restrict__ stored, uint32_t* half_stats) {
   static_assert(QT % 2 == 0 && QT >= 2, "two query blocks share a 64-query flag byte");
+  constexpr bool IMAX = MODE >= 1, HALF = MODE == 2 && QT >= 4;
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   uint32_t tile, qw;
   if (tiles_per_xcd) {
@@ -473,16 +517,21 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   uint32_t next_share = 2u;                                         // first exchange after 64 rows, as K4
 
   uint32_t step = 0;
+  // HALF: every block of the unmasked steps starts as a half; the wave counts the blocks that went on to their second half, and
+  // the HOST decides from the launch's totals whether the next launches use this mode at all (launch_topk_mfma_qt: on self-similar
+  // texture most blocks go on and the half test only adds work). An in-kernel switch between the two loop bodies was tried: 79
+  // spilled registers at the 256 this kernel lives on, 2.1 ms instead of 1.64.
+  uint32_t n_pass = 0;
   for (; step + 2u <= n_full; step += 2u) {
     // two steps per trip: the expanded rows ping-pong between a0 and a1, the packed ones between pa and pb
-    mfma_step<K, QT, false, IMAX>(a0, a1, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 4u * h, n_local, kc);
+    n_pass += mfma_step<K, QT, false, IMAX, HALF>(a0, a1, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 4u * h, n_local, kc);
     if (PF2) {
       pa = load_step(step + 3u);
-      mfma_step<K, QT, false, IMAX>(a1, a0, pb, qb, thr, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
+      n_pass += mfma_step<K, QT, false, IMAX, HALF>(a1, a0, pb, qb, thr, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
       pb = load_step(step + 4u);
     } else {
       pa = load_step(step + 2u);
-      mfma_step<K, QT, false, IMAX>(a1, a0, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
+      n_pass += mfma_step<K, QT, false, IMAX, HALF>(a1, a0, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
       pa = load_step(step + 3u);
     }
     if (step + 2u >= next_share) {                                  // wave-uniform
@@ -500,6 +549,14 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
         seen[t] = __hip_atomic_load(my_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+  }
+  // the last unmasked step's last block is still a half: it completes here, with that step's rows (a1: the second step of the
+  // loop's last trip ran on them) -- the masked steps and the drain below work on whole blocks
+  if (HALF && step > 0u) {
+    n_pass += mfma_block_test_half<K>(acc_odd, a1, qb[QT - 1], thr[QT - 1], 32u * (step - 1u) + 4u * h, n_local, best[QT - 1]) ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_odd[i] = -4096.f;
+    if (lane == 0 && half_stats) { atomicAdd(half_stats, n_pass); atomicAdd(half_stats + 1, step * (uint32_t)QT); }
   }
   // at most one full and one partial step are left: the masked form serves both
   for (; step < n_steps; ++step) {
@@ -629,10 +686,18 @@ __global__ __launch_bounds__(kBlock) void merge_tiles_kernel(const uint32_t* __r
                                                              uint32_t nq_pad, uint32_t n_tiles,
                                                              uint32_t rows_per_tile, uint64_t first_global_row,
                                                              uint32_t n_groups, const uint8_t* __restrict__ stored,
-                                                             uint32_t n_qw, uint64_t* __restrict__ keys) {
+                                                             uint32_t n_qw, uint64_t* __restrict__ keys,
+                                                             const uint32_t* stat_src = nullptr, uint32_t* stat_dst = nullptr,
+                                                             uint32_t stat_seq = 0) {
   TOD_LATENCY_PRIO();   // latency-bound: win issue arbitration against the VALU-saturating matcher
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t grp = blockIdx.y;
+  if (stat_dst && qi == 0u && grp == 0u) {                  // the DB pass's half-block counters -> pinned host memory (launch_topk_mfma_qt)
+    stat_dst[0] = __hip_atomic_load(stat_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stat_dst[1] = __hip_atomic_load(stat_src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    stat_dst[2] = stat_seq;
+  }
   if (qi >= nq) return;
   uint64_t best[K];
 #pragma unroll
@@ -817,15 +882,46 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
   int slot = -1;
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
   // radius < 128: every threshold is >= 0 and the block test may compare raw bits (see mfma_block_test)
-  auto kern = cut <= 128u ? hamming_topk_mfma<K, QT, true, PF2> : hamming_topk_mfma<K, QT, false, PF2>;
+  // radius < 128: every threshold is >= 0 and the block test may compare raw bits; cut <= 64: thr - 128 >= 0 as well, blocks start
+  // as halves (TODHIP_K4X_HALF=0 switches that off: experiments)
+  // as halves -- unless the data says otherwise: a launch in that mode counts the blocks that went on to their second half, the
+  // merge kernel behind it leaves the totals in pinned memory, and when more than a quarter did (self-similar texture inside the
+  // radius: the half test then only adds work, +27 % on the rendered-view DB) the next 32 launches of this context run whole
+  // blocks before one probes again. TODHIP_K4X_HALF=0 / =1: never / always (experiments).
+  static const int env_half = getenv("TODHIP_K4X_HALF") ? atoi(getenv("TODHIP_K4X_HALF")) : -1;
+  bool use_half = cut <= 64u && QT >= 4 && env_half != 0;
+  if (use_half && env_half < 0) {
+    if (!ctx->k4x_stats_host.p) {
+      TOD_HIP(ctx->k4x_stats_host.reserve(64));
+      std::memset(ctx->k4x_stats_host.p, 0, 64);
+      TOD_HIP(ctx->k4x_stats_dev.reserve(64));
+      TOD_HIP(hipMemsetAsync(ctx->k4x_stats_dev.p, 0, 64, ctx->stream));
+    }
+    volatile uint32_t* hs = ctx->k4x_stats_host.as<uint32_t>();
+    const uint32_t seq_now = hs[2];
+    if (seq_now != ctx->k4x_seq_seen) {                                              // a launch in half mode has reported since the last look
+      const uint32_t pass = hs[0] - ctx->k4x_last[0], blocks = hs[1] - ctx->k4x_last[1];
+      ctx->k4x_last[0] = hs[0]; ctx->k4x_last[1] = hs[1];
+      ctx->k4x_seq_seen = seq_now;
+      static const bool dbg = getenv("TODHIP_K4X_HALF_DEBUG") != nullptr;
+      if (dbg) fprintf(stderr, "[todhip] K4x half blocks: %u of %u went on (%.3f)\n", pass, blocks, blocks ? (double)pass / blocks : 0.0);
+      if (blocks && (uint64_t)pass * 4u > blocks) ctx->k4x_skip = 32;
+    }
+    if (ctx->k4x_skip > 0) { --ctx->k4x_skip; use_half = false; }
+  }
+  auto kern = use_half ? hamming_topk_mfma<K, QT, 2, PF2>
+              : (cut <= 128u ? hamming_topk_mfma<K, QT, 1, PF2> : hamming_topk_mfma<K, QT, 0, PF2>);
+  uint32_t* const d_stats = use_half && env_half < 0 ? ctx->k4x_stats_dev.as<uint32_t>() : nullptr;
   hipLaunchKernelGGL(kern, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw, n_qw64,
                      blocks_per_xcd, tiles_per_xcd, cut, (uint32_t)std::max(2, env_share), ctx->m_part.as<uint32_t>(),
-                     ctx->m_bound.as<uint32_t>(), d_stored);
+                     ctx->m_bound.as<uint32_t>(), d_stored, d_stats);
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
+  if (d_stats) ++ctx->k4x_seq_sent;
   hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
                      ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
-                     d_stored, n_qw64, d_lists);
+                     d_stored, n_qw64, d_lists, (const uint32_t*)d_stats, d_stats ? ctx->k4x_stats_host.as<uint32_t>() : (uint32_t*)nullptr,
+                     ctx->k4x_seq_sent);
   TOD_HIP(hipGetLastError());
   *n_lists = groups;
   return TODHIP_OK;
