@@ -886,9 +886,9 @@ def main():
     pairs = float(q_launch) * info["shard_rows"]
     hbm_gbs = alg_bytes / (k4_ms * 1e-3) / 1e9 if k4_ms > 0 else 0.0
     # HBM traffic of the dominant kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, each in its own rocprofv3 run,
-    # tools/profile_k4.sh -> profiles/r02_k4x_pmc.json); only quoted for the workload it was measured on
+    # tools/profile_k4.sh -> profiles/r03_k4x_pmc.json); only quoted for the workload it was measured on
     traffic, traffic_src, pmc = None, None, {}
-    pmc_path = os.path.join(ROOT, "profiles", "r02_k4x_pmc.json" if engine_used == "mfma" else "r01_k4_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r03_k4x_pmc.json" if engine_used == "mfma" else "r01_k4_pmc.json")
     if os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
     if (world == 1 and k == 2 and info["shard_rows"] == 1000000 and args.radius == 35 and pmc.get("queries_per_launch") == q_launch):
@@ -910,8 +910,18 @@ def main():
                                         "pass over a DB beyond the Infinity Cache" % q_launch},
                         "measured_mfma_roof": pmc.get("measured_mfma_roof"),
                         "note": "exact 256-bit Hamming distances as fp4 (+-1) dot products on the matrix cores: 512 flop per (query, row) "
-                                "pair, v_mfma_f32_32x32x64_f8f6f4; data independent. launch_ms = HIP events around the launch on its "
-                                "own stream, averaged over the timed regions"}
+                                "pair, v_mfma_f32_32x32x64_f8f6f4. `achieved` counts those ALGORITHMIC flops (SURVEY 8(d)); since round 3 a "
+                                "32 x 32 block only executes its second 128 bit positions when its first 128 leave a pair inside the "
+                                "limit (partial-distance elimination, exact for any data; `half_blocks`), so on this workload about half "
+                                "of them are executed and `frac` measures the pass against the roof of the arithmetic it replaces, not "
+                                "matrix-pipe occupancy. launch_ms = HIP events around the launch on its own stream, averaged over the "
+                                "timed regions"}
+            hc = sp.ctx.counters()
+            if hc.k4x_half_blocks:
+                done = hc.k4x_half_blocks_completed / hc.k4x_half_blocks
+                roofline["half_blocks"] = {"blocks_started_as_halves": int(hc.k4x_half_blocks), "fraction_completed": done,
+                                           "executed_over_algorithmic_flops": 0.5 + 0.5 * done,
+                                           "executed_TFLOPs": tflops * (0.5 + 0.5 * done), "executed_frac_of_peak": tflops * (0.5 + 0.5 * done) / MFMA_FP4_PEAK_TFLOPS}
         else:
             laneops = float(pmc.get("valu_insts_per_row_and_wave", LANEOPS_DENSE)) if traffic is not None else float(LANEOPS_DENSE)
             valu_rate = laneops * pairs / (k4_ms * 1e-3) if k4_ms > 0 else 0.0

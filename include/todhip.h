@@ -65,6 +65,9 @@ typedef struct {
   uint32_t last_sprint_rounds;        /* ... and the Ransac rounds (adjacency_ransac.cpp:234-309) it ran without the host */
   uint32_t last_verify_ticks;         /* host round trips (launch + synchronize) of the last verify call */
   uint32_t reserved0;
+  /* matrix-core matcher, launches in half-block mode (partial-distance elimination): accumulator blocks started as
+   * halves, and those that went on to their second half -- cumulative over the context's life, as of the last report read */
+  uint64_t k4x_half_blocks, k4x_half_blocks_completed;
 } todhip_counters;
 
 /* ---- lifetime ---------------------------------------------------------------------------------- */

@@ -49,7 +49,8 @@ class Counters(C.Structure):
                 ("last_hypotheses", C.c_uint32), ("last_gate_calls", C.c_uint32), ("last_poses", C.c_uint32),
                 ("last_match_kernel_ms", C.c_double), ("sum_match_kernel_ms", C.c_double),
                 ("n_match_kernel_launches", C.c_uint64), ("last_sprint_launches", C.c_uint32), ("last_sprint_rounds", C.c_uint32),
-                ("last_verify_ticks", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("last_verify_ticks", C.c_uint32), ("reserved0", C.c_uint32), ("k4x_half_blocks", C.c_uint64),
+                ("k4x_half_blocks_completed", C.c_uint64)]
 
 
 # every symbol include/todhip.h declares (checked by tests/test_abi.py against the header text)

@@ -902,6 +902,7 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
     if (seq_now != ctx->k4x_seq_seen) {                                              // a launch in half mode has reported since the last look
       const uint32_t pass = hs[0] - ctx->k4x_last[0], blocks = hs[1] - ctx->k4x_last[1];
       ctx->k4x_last[0] = hs[0]; ctx->k4x_last[1] = hs[1];
+      ctx->counters.k4x_half_blocks += blocks; ctx->counters.k4x_half_blocks_completed += pass;
       ctx->k4x_seq_seen = seq_now;
       static const bool dbg = getenv("TODHIP_K4X_HALF_DEBUG") != nullptr;
       if (dbg) fprintf(stderr, "[todhip] K4x half blocks: %u of %u went on (%.3f)\n", pass, blocks, blocks ? (double)pass / blocks : 0.0);
