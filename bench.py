@@ -94,6 +94,7 @@ def parse():
                     help="several ranks: issue the collectives on the matcher's stream, in program order (gather -> match -> "
                          "exchange -> merge), instead of on their own stream where they overlap the neighbouring DB passes")
     ap.add_argument("--chained-workers", type=int, default=2, help="verifier batches in flight in the chained block (0: --verify-workers)")
+    ap.add_argument("--chained-batch", type=int, default=16, help="frames per step of the chained block")
     ap.add_argument("--chained-latency-cus", type=int, default=96,
                     help="chained block: the matcher's stream keeps off this many compute units (todhip_set_cu_partition), on which the "
                          "verifier's single-wave launch groups (sprints, clique gates, growth: its side streams) then run alone; ORB's and "
@@ -292,7 +293,7 @@ def run_chained(torch, capi, device, args):
     from tod_amd import scenes
     from tod_amd.pipeline import StagePipeline
     t_setup = time.perf_counter()
-    B, nq, k, radius = 16, args.nq, args.k, args.radius                    # (its own batch size: the block was tuned at 16 frames per step)
+    B, nq, k, radius = args.chained_batch, args.nq, args.k, args.radius
     n_obj = args.objects
     textures = scenes.make_textures(n_obj)
     tctx = capi.Context(device)

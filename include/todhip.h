@@ -64,9 +64,9 @@ typedef struct {
   uint32_t last_sprint_launches;      /* verifier: launches of the single-wave small-object kernel in the last call ... */
   uint32_t last_sprint_rounds;        /* ... and the Ransac rounds (adjacency_ransac.cpp:234-309) it ran without the host */
   uint32_t last_verify_ticks;         /* host round trips (launch + synchronize) of the last verify call */
-  uint32_t reserved0;
-  /* matrix-core matcher, launches in half-block mode (partial-distance elimination): accumulator blocks started as
-   * halves, and those that went on to their second half -- cumulative over the context's life, as of the last report read */
+  uint32_t last_block_split;          /* matrix-core matcher: the block form of the last launch (4 = whole, 2 / 3: todhip_set_matcher_block_split) */
+  /* matrix-core matcher, launches with split blocks (partial-distance elimination): accumulator blocks started as
+   * parts, and those that went on to their second part -- cumulative over the context's life, as of the last report read */
   uint64_t k4x_half_blocks, k4x_half_blocks_completed;
 } todhip_counters;
 
@@ -98,6 +98,11 @@ int  todhip_set_kernel_timing(todhip_ctx*, int enable);   /* bracket the matcher
  * data independent). AUTO picks by launch shape. */
 enum { TODHIP_ENGINE_AUTO = 0, TODHIP_ENGINE_VALU = 1, TODHIP_ENGINE_MFMA = 2 };
 int  todhip_set_matcher_engine(todhip_ctx*, int engine);
+/* The matrix-core engine's partial-distance elimination: a 32 x 32 block's 256 bit positions are 4 matrix instructions, and the
+ * block may stop after the first `split` of them when no partial sum can still reach a threshold (exact for any data). Which split
+ * pays depends on the data, so the default (-1) adapts per context from the launches' own statistics; 0 = whole blocks, 2 / 3 = always
+ * that split where the radius allows it (2: radius < 64, 3: radius < 96). Identical results in every setting. */
+int  todhip_set_matcher_block_split(todhip_ctx*, int split);
 
 /* ---- stage B: DescriptorMatcher ---------------------------------------------------------------- */
 /* Replaces DescriptorMatcher::parameter_callback (DescriptorMatcher.cpp:60-129): ingest every object,

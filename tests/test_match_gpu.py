@@ -12,12 +12,16 @@ pytestmark = pytest.mark.gpu
 ENGINE = {"name": "auto"}     # the engine of the context under test; the sharded helper's own contexts follow it
 
 
-@pytest.fixture(scope="module", params=["valu", "mfma"])
+@pytest.fixture(scope="module", params=["valu", "mfma", "mfma-whole", "mfma-split2", "mfma-split3"])
 def ctx(request):
-    """Every test of this module runs on both engines of the exact search: K4 (vector ALU) and K4x (matrix cores)."""
+    """Every test of this module runs on both engines of the exact search: K4 (vector ALU) and K4x (matrix cores) -- the latter with
+    its adaptive partial-distance elimination and with each of its three block forms forced (todhip_set_matcher_block_split)."""
     c = capi.Context(0)
-    c.set_matcher_engine(request.param)
-    ENGINE["name"] = request.param
+    engine, _, form = request.param.partition("-")
+    c.set_matcher_engine(engine)
+    if form:
+        c.set_matcher_block_split({"whole": 0, "split2": 2, "split3": 3}[form])
+    ENGINE["name"] = engine
     yield c
     c.close()
     ENGINE["name"] = "auto"
@@ -428,3 +432,48 @@ def test_ratio_test_sharded_equals_unsharded(ctx):
     m = mm.cpu().numpy().view(capi.DMATCH_DTYPE).reshape(nq, k)[keep]
     for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
         assert np.array_equal(m[f], o_m[f]), f
+
+
+def test_block_split_adapts_to_the_data():
+    """The matrix-core engine's partial-distance elimination picks its block form from the launches' own statistics:
+    rows that agree with the queries on the bit positions of the first 2 (3) of a block's 4 matrix instructions and differ on all
+    the others make every block survive that split, so the context moves up a level after one report, holds it for 32 launches,
+    probes one level down once, and goes on; on independent bits it stays with the 2-split. Results == oracle on every launch."""
+    rng = np.random.default_rng(3)
+    q1 = rng.integers(0, 256, 32, dtype=np.uint8)
+    nq, n_rows = 1024, 20000
+
+    def db_of(flip_words):                                   # matrix instruction s covers words s and 4 + s of a 256-bit row
+        row = q1.copy().view(np.uint32)
+        row[flip_words] ^= 0xFFFFFFFF
+        desc = np.tile(row.view(np.uint8), (n_rows, 1))
+        for r, nb in ((777, 3), (15000, 5), (15001, 5)):     # three true neighbours: ranks and ties as usual
+            d = q1.copy()
+            d[:nb] ^= 1
+            desc[r] = d
+        return desc
+
+    cases = {"first two agree": (db_of([2, 3, 6, 7]), [2] + [3] * 32 + [2, 3]),
+             "first three agree": (db_of([3, 7]), [2, 3] + [4] * 32 + [3, 4]),
+             "independent bits": (rng.integers(0, 256, (n_rows, 32), dtype=np.uint8), [2] * 6)}
+    pts = rng.standard_normal((n_rows, 3)).astype(np.float32)
+    off = np.array([0, n_rows], dtype=np.int64)
+    q = np.tile(q1, (nq, 1))
+    q[5:40, 31] ^= 0x80                                      # a few queries one bit away from the rest
+    for name, (desc, forms) in cases.items():
+        c = capi.Context(0)
+        c.set_matcher_engine("mfma")
+        c.db_load(desc, pts, off)
+        rc, o_row_ptr, o_m, _ = O.match(desc, off, pts, q, 2, 35)
+        assert rc == 0
+        seen = []
+        for _ in forms:
+            row_ptr, m, _ = c.match(q, 2, 35)
+            seen.append(c.counters().last_block_split)
+            assert np.array_equal(row_ptr, o_row_ptr), name
+            for f in ("trainIdx", "distance"):
+                assert np.array_equal(m[f], o_m[f]), (name, f)
+        assert seen == forms, (name, seen)
+        cnt = c.counters()
+        assert cnt.k4x_half_blocks > 0 and cnt.k4x_half_blocks_completed <= cnt.k4x_half_blocks
+        c.close()

@@ -49,14 +49,14 @@ class Counters(C.Structure):
                 ("last_hypotheses", C.c_uint32), ("last_gate_calls", C.c_uint32), ("last_poses", C.c_uint32),
                 ("last_match_kernel_ms", C.c_double), ("sum_match_kernel_ms", C.c_double),
                 ("n_match_kernel_launches", C.c_uint64), ("last_sprint_launches", C.c_uint32), ("last_sprint_rounds", C.c_uint32),
-                ("last_verify_ticks", C.c_uint32), ("reserved0", C.c_uint32), ("k4x_half_blocks", C.c_uint64),
+                ("last_verify_ticks", C.c_uint32), ("last_block_split", C.c_uint32), ("k4x_half_blocks", C.c_uint64),
                 ("k4x_half_blocks_completed", C.c_uint64)]
 
 
 # every symbol include/todhip.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = [
     "todhip_version", "todhip_create", "todhip_destroy", "todhip_stream", "todhip_last_hip_error",
-    "todhip_synchronize", "todhip_get_counters", "todhip_set_cu_partition", "todhip_stream_create", "todhip_stream_destroy", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_set_ratio_test", "todhip_db_load", "todhip_db_load_device", "todhip_db_info",
+    "todhip_synchronize", "todhip_get_counters", "todhip_set_cu_partition", "todhip_stream_create", "todhip_stream_destroy", "todhip_set_kernel_timing", "todhip_set_matcher_engine", "todhip_set_matcher_block_split", "todhip_set_ratio_test", "todhip_db_load", "todhip_db_load_device", "todhip_db_info",
     "todhip_match", "todhip_match_device", "todhip_match_shard_device", "todhip_merge_shards_device", "todhip_merge_shards_device_on",
     "todhip_rng_seed", "todhip_verify", "todhip_orb", "todhip_orb_masked", "todhip_test_clique", "todhip_test_clique_gate",
     "todhip_verify_trace", "todhip_test_adjacency", "todhip_test_consensus", "todhip_verify_device",
@@ -147,6 +147,11 @@ class Context:
         """0 auto, 1 vector ALU (K4), 2 matrix cores (K4x): identical results"""
         _check(lib().todhip_set_matcher_engine(self._h, C.c_int({"auto": 0, "valu": 1, "mfma": 2}.get(engine, engine))),
                "todhip_set_matcher_engine")
+
+    def set_matcher_block_split(self, split):
+        """-1 adaptive (default), 0 whole blocks, 2 / 3: the matrix-core engine's blocks stop after that many of their 4 matrix
+        instructions when no partial sum can still reach a threshold: identical results"""
+        _check(lib().todhip_set_matcher_block_split(self._h, C.c_int(split)), "todhip_set_matcher_block_split")
 
     def set_ratio_test(self, ratio):
         """Lowe's ratio test on the two nearest neighbours (0 = off, the reference's effective setting)"""

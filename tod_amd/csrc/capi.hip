@@ -145,6 +145,12 @@ int todhip_set_matcher_engine(todhip_ctx* ctx, int engine) {
   return TODHIP_OK;
 }
 
+int todhip_set_matcher_block_split(todhip_ctx* ctx, int split) {
+  if (!ctx || !(split == -1 || split == 0 || split == 2 || split == 3)) return TODHIP_EINVAL;
+  ctx->k4x_force = split;
+  return TODHIP_OK;
+}
+
 int todhip_set_ratio_test(todhip_ctx* ctx, float ratio) {
   if (!ctx || !(ratio >= 0.f) || ratio > 1.f) return TODHIP_EINVAL;
   ctx->ratio = ratio;

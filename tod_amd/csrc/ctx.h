@@ -100,7 +100,8 @@ struct todhip_ctx {
   // K4x's half-block mode (match.hip, launch_topk_mfma_qt): cumulative {blocks that went on, blocks} of the launches in that mode,
   // as the merge kernel leaves them in pinned memory; launches left before the next probe
   HostBuf k4x_stats_host; DevBuf k4x_stats_dev;
-  uint32_t k4x_seq_sent = 0, k4x_seq_seen = 0, k4x_skip = 0, k4x_last[2] = {0, 0};
+  int k4x_force = -1;                         // todhip_set_matcher_block_split
+  uint32_t k4x_seq_sent = 0, k4x_seq_seen = 0, k4x_split = 2, k4x_hold = 0, k4x_hold_len = 32, k4x_last[4] = {0, 0, 0, 0};   // launch_topk_mfma_qt
   float ratio = 0.f;                         // todhip_set_ratio_test (0 = off)
 
   std::vector<todhip_round_trace> traces;

@@ -372,28 +372,34 @@ __device__ __forceinline__ void mfma_block_test(const mfma_f32x16& acc, float& t
   thr = fmaxf(thr, thr_of_limit(best[K - 1] >> kLocalBits));       // thresholds only ever tighten
 }
 
-// The same in two halves: bit positions {0..63} + {128..191} first (MFMAs 0, 1), the rest behind a test (mfma_block_test_half)
-__device__ __forceinline__ mfma_f32x16 dot_half0(const Fp4Row& a, const Fp4Row& b) {
+// The same in two parts: the first SPLIT (2 or 3) of the block's 4 MFMAs, the rest behind a test (mfma_block_test_part)
+template <int SPLIT>
+__device__ __forceinline__ mfma_f32x16 dot_part0(const Fp4Row& a, const Fp4Row& b) {
   mfma_f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a.s[0], b.s[0], acc, 4, 4, 0, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a.s[1], b.s[1], acc, 4, 4, 0, 0, 0, 0);
+#pragma unroll
+  for (int s = 0; s < SPLIT; ++s) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a.s[s], b.s[s], acc, 4, 4, 0, 0, 0, 0);
   return acc;
 }
-// Partial-distance elimination on the matrix cores (K4's idea, a block at a time): after 128 of the 256 bit positions the
-// accumulator holds 128 - 2 d128 with d128 <= d, so a pair whose partial dot product is not above thr - 128 (d128 >= limit) cannot
-// be a hit whatever the other 128 positions say -- exact for any data. On independent bits d128 of a non-match is 64 +- 5.7 and
-// the radius 35: one block in five thousand goes on to its other two MFMAs. Needs thr - 128 >= 0 for the integer maximum (limits
-// up to 64; thresholds only tighten). rows / q: the fragments the block's first half was computed from.
-template <int K>
-__device__ __forceinline__ bool mfma_block_test_half(mfma_f32x16& acc, const Fp4Row& rows, const Fp4Row& q, float& thr, uint32_t r_lane,
+// Partial-distance elimination on the matrix cores (K4's idea, a block at a time): after P = 64 SPLIT of the 256 bit positions the
+// accumulator holds P - 2 dP with dP <= d, so a pair whose partial dot product is not above thr - (256 - P) (dP >= limit) cannot
+// be a hit whatever the other positions say -- exact for any data. On independent bits d128 of a non-match is 64 +- 5.7 and
+// the radius 35: one block in five thousand goes on to its other two MFMAs (SPLIT 2). Real rBRIEF bits are biased and correlated
+// (mean distance ~100 of 256 on this library's ORB descriptors of rendered views): there almost every block survives 128 positions
+// and SPLIT 3 is the form that prunes (d192 ~ 75 +- 9.5). Needs thr - (256 - P) >= 0 for the integer maximum (limits up to 64 for
+// SPLIT 2, up to 96 for SPLIT 3; thresholds only tighten). rows / q: the fragments the block's first part was computed from.
+template <int K, int SPLIT>
+__device__ __forceinline__ bool mfma_block_test_part(mfma_f32x16& acc, const Fp4Row& rows, const Fp4Row& q, float& thr, uint32_t r_lane,
                                                      uint32_t n_lim, uint32_t (&best)[K]) {
-  int m = max(max(__float_as_int(acc[0]), __float_as_int(acc[1])), __float_as_int(acc[2]));
+  // the 16-way maximum as a tree (5 independent max3, then 2 + 1): in this form the kernel is bound by vector issue, not by the matrix
+  // pipe (tools/mfma_valu_overlap.hip: 2 MFMAs + chain + expansion 113 cycles per block and SIMD, + tree 103), and the tree's
+  // independent operations fill the issue slots a chain leaves to its own latency
+  int g[5];
 #pragma unroll
-  for (int i = 3; i < 15; i += 2) m = max(max(m, __float_as_int(acc[i])), __float_as_int(acc[i + 1]));
-  m = max(m, __float_as_int(acc[15]));
-  if (__builtin_amdgcn_ballot_w64(m > __float_as_int(thr - 128.f)) == 0ull) return false;
-  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rows.s[2], q.s[2], acc, 4, 4, 0, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rows.s[3], q.s[3], acc, 4, 4, 0, 0, 0, 0);
+  for (int j = 0; j < 5; ++j) g[j] = max(max(__float_as_int(acc[3 * j]), __float_as_int(acc[3 * j + 1])), __float_as_int(acc[3 * j + 2]));
+  const int m = max(max(max(g[0], g[1]), g[2]), max(max(g[3], g[4]), __float_as_int(acc[15])));
+  if (__builtin_amdgcn_ballot_w64(m > __float_as_int(thr - 64.f * (float)(4 - SPLIT))) == 0ull) return false;
+#pragma unroll
+  for (int s = SPLIT; s < 4; ++s) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rows.s[s], q.s[s], acc, 4, 4, 0, 0, 0, 0);
   mfma_block_test<K, false, true>(acc, thr, r_lane, n_lim, best);
   return true;
 }
@@ -402,18 +408,20 @@ __device__ __forceinline__ bool mfma_block_test_half(mfma_f32x16& acc, const Fp4
 // blocks, the fp4 expansion of the NEXT step's packed rows) sits in the same basic block as the MFMAs of block t, so the
 // vector ALU works in the matrix pipe's shadow; the last block's test is carried into the next step: QT is even, so it
 // waits in acc_odd while block 0 of the next step fills acc_even.
-// HALF (never with MASK): every block starts with its first two MFMAs (dot_half0) and only completes behind mfma_block_test_half;
-// the block carried in from the previous step (t == 0) completes with that step's rows, which are a_next's registers 2 and 3 until
-// this step's expansion overwrites them at t == 2, 3.
-template <int K, int QT, bool MASK, bool IMAX, bool HALF = false>
+// SPLIT 2 / 3 (never with MASK; 0 = whole blocks): every block starts with its first SPLIT MFMAs (dot_part0) and only completes
+// behind mfma_block_test_part; the block carried in from the previous step (t == 0) completes with that step's rows, which are
+// a_next's registers 2 and 3 until this step's expansion overwrites them at t == 2, 3.
+template <int K, int QT, bool MASK, bool IMAX, int SPLIT = 0>
 __device__ __forceinline__ uint32_t mfma_step(const Fp4Row& a, Fp4Row& a_next, const uint4& p_next, const Fp4Row (&qb)[QT],
                                               float (&thr)[QT], uint32_t (&best)[QT][K], mfma_f32x16& acc_even,
                                               mfma_f32x16& acc_odd, uint32_t r_lane, uint32_t n_lim, const Fp4Consts& kc) {
-  uint32_t n_pass = 0;                                     // HALF: blocks that went on to their second half (wave-uniform)
-  static_assert(!(HALF && MASK) && !(HALF && !IMAX) && !(HALF && QT < 4), "half blocks: unmasked steps, integer maximum, >= 4 query blocks");
+  constexpr bool HALF = SPLIT != 0;
+  uint32_t n_pass = 0;                                     // SPLIT: blocks that went on to their second part (wave-uniform)
+  static_assert(!(HALF && MASK) && !(HALF && !IMAX) && !(HALF && QT < 4), "split blocks: unmasked steps, integer maximum, >= 4 query blocks");
+  static_assert(SPLIT == 0 || SPLIT == 2 || SPLIT == 3, "2 or 3 of the 4 MFMAs first");
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    if (HALF) { if (t & 1) acc_odd = dot_half0(a, qb[t]); else acc_even = dot_half0(a, qb[t]); }
+    if (HALF) { if (t & 1) acc_odd = dot_part0<HALF ? SPLIT : 2>(a, qb[t]); else acc_even = dot_part0<HALF ? SPLIT : 2>(a, qb[t]); }
     else { if (t & 1) acc_odd = dot_block(a, qb[t]); else acc_even = dot_block(a, qb[t]); }
 #if defined(TOD_K4X_ABLATE) && TOD_K4X_ABLATE == 3           // diagnostics build only: no fp4 expansion (the packed words are "used")
     if (t == 0) { a_next = a; asm volatile("" :: "v"(p_next.x), "v"(p_next.y), "v"(p_next.z), "v"(p_next.w)); }
@@ -432,8 +440,8 @@ __device__ __forceinline__ uint32_t mfma_step(const Fp4Row& a, Fp4Row& a_next, c
     if (t == 0) asm volatile("" :: "v"(acc_odd)); else if (t & 1) asm volatile("" :: "v"(acc_even)); else asm volatile("" :: "v"(acc_odd));
 #else
     if (HALF) {
-      if (t == 0) n_pass += mfma_block_test_half<K>(acc_odd, a_next, qb[QT - 1], thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]) ? 1u : 0u;   // previous step's last block, its rows
-      else n_pass += mfma_block_test_half<K>((t & 1) ? acc_even : acc_odd, a, qb[t - 1], thr[t - 1], r_lane, n_lim, best[t - 1]) ? 1u : 0u;
+      if (t == 0) n_pass += mfma_block_test_part<K, HALF ? SPLIT : 2>(acc_odd, a_next, qb[QT - 1], thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]) ? 1u : 0u;   // previous step's last block, its rows
+      else n_pass += mfma_block_test_part<K, HALF ? SPLIT : 2>((t & 1) ? acc_even : acc_odd, a, qb[t - 1], thr[t - 1], r_lane, n_lim, best[t - 1]) ? 1u : 0u;
     } else {
       if (t == 0) mfma_block_test<K, MASK, IMAX>(acc_odd, thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]);   // previous step's last block
       else mfma_block_test<K, MASK, IMAX>((t & 1) ? acc_even : acc_odd, thr[t - 1], r_lane, n_lim, best[t - 1]);
@@ -443,8 +451,8 @@ __device__ __forceinline__ uint32_t mfma_step(const Fp4Row& a, Fp4Row& a_next, c
   return n_pass;
 }
 
-// MODE 0: float maximum in the block test (any radius); 1: integer maximum (cut <= 128: thresholds >= 0); 2: integer maximum and
-// half blocks (cut <= 64: mfma_block_test_half)
+// MODE 0: float maximum in the block test (any radius); 1: integer maximum (cut <= 128: thresholds >= 0); 2 / 3: integer maximum and
+// blocks split after 2 / 3 of their 4 MFMAs (cut <= 64 / <= 96: mfma_block_test_part)
 template <int K, int QT, int MODE, bool PF2>
 __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* __restrict__ db,
                                                                const uint32_t* __restrict__ q, uint32_t n_rows,
@@ -455,7 +463,8 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
                                                                uint32_t* __restrict__ part, uint32_t* bound,
                                                                uint8_t* __restrict__ stored, uint32_t* half_stats) {
   static_assert(QT % 2 == 0 && QT >= 2, "two query blocks share a 64-query flag byte");
-  constexpr bool IMAX = MODE >= 1, HALF = MODE == 2 && QT >= 4;
+  constexpr bool IMAX = MODE >= 1;
+  constexpr int HALF = (MODE >= 2 && QT >= 4) ? MODE : 0;           // the split (0: whole blocks)
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   uint32_t tile, qw;
   if (tiles_per_xcd) {
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   // the last unmasked step's last block is still a half: it completes here, with that step's rows (a1: the second step of the
   // loop's last trip ran on them) -- the masked steps and the drain below work on whole blocks
   if (HALF && step > 0u) {
-    n_pass += mfma_block_test_half<K>(acc_odd, a1, qb[QT - 1], thr[QT - 1], 32u * (step - 1u) + 4u * h, n_local, best[QT - 1]) ? 1u : 0u;
+    n_pass += mfma_block_test_part<K, HALF ? HALF : 2>(acc_odd, a1, qb[QT - 1], thr[QT - 1], 32u * (step - 1u) + 4u * h, n_local, best[QT - 1]) ? 1u : 0u;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc_odd[i] = -4096.f;
     if (lane == 0 && half_stats) { atomicAdd(half_stats, n_pass); atomicAdd(half_stats + 1, step * (uint32_t)QT); }
@@ -693,10 +702,9 @@ __global__ __launch_bounds__(kBlock) void merge_tiles_kernel(const uint32_t* __r
   const uint32_t qi = blockIdx.x * kBlock + threadIdx.x;
   const uint32_t grp = blockIdx.y;
   if (stat_dst && qi == 0u && grp == 0u) {                  // the DB pass's half-block counters -> pinned host memory (launch_topk_mfma_qt)
-    stat_dst[0] = __hip_atomic_load(stat_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stat_dst[1] = __hip_atomic_load(stat_src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 4; ++i) stat_dst[i] = __hip_atomic_load(stat_src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_system();
-    stat_dst[2] = stat_seq;
+    stat_dst[4] = stat_seq;
   }
   if (qi >= nq) return;
   uint64_t best[K];
@@ -881,42 +889,66 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
   uint8_t* const d_stored = ctx->m_bound.as<uint8_t>() + bound_bytes;
   int slot = -1;
   if (ctx->time_kernels) { int rc = tod_timing_begin(ctx, &slot); if (rc != TODHIP_OK) return rc; }
-  // radius < 128: every threshold is >= 0 and the block test may compare raw bits (see mfma_block_test)
-  // radius < 128: every threshold is >= 0 and the block test may compare raw bits; cut <= 64: thr - 128 >= 0 as well, blocks start
-  // as halves (TODHIP_K4X_HALF=0 switches that off: experiments)
-  // as halves -- unless the data says otherwise: a launch in that mode counts the blocks that went on to their second half, the
-  // merge kernel behind it leaves the totals in pinned memory, and when more than a quarter did (self-similar texture inside the
-  // radius: the half test then only adds work, +27 % on the rendered-view DB) the next 32 launches of this context run whole
-  // blocks before one probes again. TODHIP_K4X_HALF=0 / =1: never / always (experiments).
-  static const int env_half = getenv("TODHIP_K4X_HALF") ? atoi(getenv("TODHIP_K4X_HALF")) : -1;
-  bool use_half = cut <= 64u && QT >= 4 && env_half != 0;
-  if (use_half && env_half < 0) {
+  // radius < 128: every threshold is >= 0 and the block test may compare raw bits (see mfma_block_test). cut <= 64 / <= 96: the
+  // thresholds minus 128 / 64 are >= 0 as well and a block may be split after 2 / 3 of its 4 MFMAs (mfma_block_test_part). Which
+  // split pays is a property of the DATA (independent bits: 2; this library's ORB descriptors of rendered views: 3, since nearly
+  // every block survives 128 positions there and the 2-split then costs +30 %), so the launch adapts: a split launch counts the blocks
+  // that went on to their second part, the merge kernel behind it leaves the totals in pinned memory, and the context moves one
+  // level up (2 -> 3 -> whole blocks) when more than a quarter (2) / half (3) went on, and probes one level down every k4x_hold_len
+  // launches (32, doubling to 256 while the probes keep failing). todhip_set_matcher_block_split, or TODHIP_K4X_HALF=0 / 2 / 3 as the
+  // process's default: never / always that split (1 = 2).
+  static const int env_default = getenv("TODHIP_K4X_HALF") ? atoi(getenv("TODHIP_K4X_HALF")) : -1;
+  const int env_half = ctx->k4x_force >= 0 ? ctx->k4x_force : env_default;                 // todhip_set_matcher_block_split wins
+  const uint32_t min_split = QT < 4 ? 4u : (cut <= 64u ? 2u : (cut <= 96u ? 3u : 4u));   // the lowest split the thresholds allow
+  uint32_t split = 4;                                                                   // 4 = whole blocks
+  const bool adaptive = env_half < 0;
+  if (env_half == 0 || min_split == 4u) split = 4;
+  else {
     if (!ctx->k4x_stats_host.p) {
       TOD_HIP(ctx->k4x_stats_host.reserve(64));
       std::memset(ctx->k4x_stats_host.p, 0, 64);
       TOD_HIP(ctx->k4x_stats_dev.reserve(64));
       TOD_HIP(hipMemsetAsync(ctx->k4x_stats_dev.p, 0, 64, ctx->stream));
     }
-    volatile uint32_t* hs = ctx->k4x_stats_host.as<uint32_t>();
-    const uint32_t seq_now = hs[2];
-    if (seq_now != ctx->k4x_seq_seen) {                                              // a launch in half mode has reported since the last look
-      const uint32_t pass = hs[0] - ctx->k4x_last[0], blocks = hs[1] - ctx->k4x_last[1];
-      ctx->k4x_last[0] = hs[0]; ctx->k4x_last[1] = hs[1];
-      ctx->counters.k4x_half_blocks += blocks; ctx->counters.k4x_half_blocks_completed += pass;
+    if (ctx->k4x_split < min_split) ctx->k4x_split = min_split;
+    volatile uint32_t* hs = ctx->k4x_stats_host.as<uint32_t>();   // [0..1] split 2: blocks that went on, blocks; [2..3] split 3; [4] launches reported
+    const uint32_t seq_now = hs[4];
+    if (seq_now != ctx->k4x_seq_seen) {                                              // a split launch has reported since the last look
       ctx->k4x_seq_seen = seq_now;
       static const bool dbg = getenv("TODHIP_K4X_HALF_DEBUG") != nullptr;
-      if (dbg) fprintf(stderr, "[todhip] K4x half blocks: %u of %u went on (%.3f)\n", pass, blocks, blocks ? (double)pass / blocks : 0.0);
-      if (blocks && (uint64_t)pass * 4u > blocks) ctx->k4x_skip = 32;
+      for (uint32_t m = 2; m <= 3; ++m) {
+        const uint32_t pass = hs[2 * (m - 2)] - ctx->k4x_last[2 * (m - 2)], blocks = hs[2 * (m - 2) + 1] - ctx->k4x_last[2 * (m - 2) + 1];
+        if (!blocks) continue;
+        ctx->k4x_last[2 * (m - 2)] += pass; ctx->k4x_last[2 * (m - 2) + 1] += blocks;
+        ctx->counters.k4x_half_blocks += blocks; ctx->counters.k4x_half_blocks_completed += pass;
+        const bool pays = m == 2 ? (uint64_t)pass * 4u <= blocks : (uint64_t)pass * 2u <= blocks;
+        if (dbg) fprintf(stderr, "[todhip] K4x blocks split after %u MFMAs: %u of %u went on (%.3f)%s, split in use %u\n", m, pass, blocks,
+                         (double)pass / blocks, pays ? "" : ": does not pay", ctx->k4x_split);
+        if (!adaptive) continue;
+        if (m == ctx->k4x_split && !pays) {                  // the level in use stopped paying: one level up
+          ctx->k4x_split = m + 1; ctx->k4x_hold = ctx->k4x_hold_len = 32;
+        } else if (m + 1 == ctx->k4x_split) {                // a probe's report
+          if (pays) { ctx->k4x_split = m; ctx->k4x_hold_len = 32; }
+          else ctx->k4x_hold_len = std::min(256u, ctx->k4x_hold_len * 2u);
+        }
+      }
     }
-    if (ctx->k4x_skip > 0) { --ctx->k4x_skip; use_half = false; }
+    split = adaptive ? ctx->k4x_split : std::max<uint32_t>(min_split, env_half == 1 ? 2u : (uint32_t)std::min(env_half, 3));
+    if (adaptive && split > min_split) {
+      if (ctx->k4x_hold == 0) { split -= 1; ctx->k4x_hold = ctx->k4x_hold_len ? ctx->k4x_hold_len : 32; }   // probe one level down
+      else --ctx->k4x_hold;
+    }
   }
-  auto kern = use_half ? hamming_topk_mfma<K, QT, 2, PF2>
+  auto kern = split == 2 ? hamming_topk_mfma<K, QT, 2, PF2>
+              : split == 3 ? hamming_topk_mfma<K, QT, 3, PF2>
               : (cut <= 128u ? hamming_topk_mfma<K, QT, 1, PF2> : hamming_topk_mfma<K, QT, 0, PF2>);
-  uint32_t* const d_stats = use_half && env_half < 0 ? ctx->k4x_stats_dev.as<uint32_t>() : nullptr;
+  const bool report = split < 4;
+  ctx->counters.last_block_split = split;
+  uint32_t* const d_stats = report ? ctx->k4x_stats_dev.as<uint32_t>() : nullptr;
   hipLaunchKernelGGL(kern, dim3(blocks_per_xcd * 8u), dim3(kBlock), 0, ctx->stream,
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw, n_qw64,
                      blocks_per_xcd, tiles_per_xcd, cut, (uint32_t)std::max(2, env_share), ctx->m_part.as<uint32_t>(),
-                     ctx->m_bound.as<uint32_t>(), d_stored, d_stats);
+                     ctx->m_bound.as<uint32_t>(), d_stored, d_stats ? d_stats + 2u * (split - 2u) : nullptr);
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
   if (d_stats) ++ctx->k4x_seq_sent;
   hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,

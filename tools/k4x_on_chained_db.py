@@ -45,6 +45,7 @@ for b, bt in enumerate(bts):
 ctx.synchronize()
 timed(ctx, de, F * nq, "chained_db")
 ctx.close()
+if os.environ.get("ONLY_CHAINED"): sys.exit(0)
 # ---- independent bits, planted queries
 desc, pts, off = synth.make_db(200)
 ctx = capi.Context(0); ctx.db_load(desc, pts, off); ctx.set_matcher_engine("mfma")
