@@ -94,12 +94,16 @@ def parse():
                     help="several ranks: issue the collectives on the matcher's stream, in program order (gather -> match -> "
                          "exchange -> merge), instead of on their own stream where they overlap the neighbouring DB passes")
     ap.add_argument("--chained-workers", type=int, default=2, help="verifier batches in flight in the chained block (0: --verify-workers)")
-    ap.add_argument("--chained-batch", type=int, default=16, help="frames per step of the chained block")
-    ap.add_argument("--chained-latency-cus", type=int, default=96,
+    ap.add_argument("--orb-workers", type=int, default=1, help="ORB batches in flight (one context, stream and host thread each), headline and chained block")
+    ap.add_argument("--chained-batch", type=int, default=32, help="frames per step of the chained block (tools/chained_shape_sweep.sh: 16 frames per "
+                    "step leave the matcher's DB pass half as many queries to amortise its rows over: 6.5-7.1k frames/s where 32 give 8.8-10k)")
+    ap.add_argument("--chained-latency-cus", type=int, default=0,
                     help="chained block: the matcher's stream keeps off this many compute units (todhip_set_cu_partition), on which the "
                          "verifier's single-wave launch groups (sprints, clique gates, growth: its side streams) then run alone; ORB's and "
-                         "the verifier's wide kernels keep the whole chip. The block is verifier-bound: 2 batches in flight 6.4k frames/s "
-                         "without, 7.0k with 64, 7.4k with 96, 6.4k with 128 (the matcher becomes the bound); 0 = no partition")
+                         "the verifier's wide kernels keep the whole chip. Paid while the block was verifier-bound (16 frames per step, the "
+                         "matcher's waves filling every register file: 6.4k frames/s without, 7.4k with 96); since the matcher's waves leave "
+                         "80 registers per SIMD free (launch_topk_mfma) the block is matcher-bound and the partition only costs (32 frames "
+                         "per step: 8.9k without, 7.5k with 96); 0 = no partition")
     ap.add_argument("--latency-cus", type=int, default=0, help="reserve this many compute units for the latency-bound stages' streams "
                     "(todhip_set_cu_partition): ORB and verifier kernels then never share a SIMD with the matcher's DB pass")
     ap.add_argument("--iterations", type=int, default=2500, help="n_ransac_iterations (conf/detection.ork:38)")
@@ -173,7 +177,7 @@ class SyntheticPipeline:
     used for the C1 / C2 / C5 blocks): ORB on the 8(d) image, matcher + verifier on the frame's planted descriptors."""
 
     def __init__(self, torch, capi, device, desc, pts, off, frames, nq, k, radius, B, stages, iterations, min_inliers,
-                 engine="auto", H=480, W=640, shard=None, n_levels=3, match_fn=None, main_stream=None, verify_workers=2):
+                 engine="auto", H=480, W=640, shard=None, n_levels=3, match_fn=None, main_stream=None, verify_workers=2, orb_workers=1):
         from tod_amd.pipeline import StagePipeline
         self.torch, self.capi = torch, capi
         self.nq, self.k, self.radius, self.B, self.H, self.W = nq, k, radius, B, H, W
@@ -201,24 +205,25 @@ class SyntheticPipeline:
         self.outs = [dict(counts=torch.zeros(B * nq, dtype=torch.int32, device="cuda"),
                           matches=torch.zeros((B * nq * k, 4), dtype=torch.int32, device="cuda"),
                           xyz=torch.zeros((B * nq * k, 3), dtype=torch.float32, device="cuda")) for _ in range(self.D)]
-        self.ostream = pooled_stream(torch, "orb", 0, -1)
-        self.octx = capi.Context(device, self.ostream.cuda_stream) if do_orb else None
+        # ORB workers (context + stream + output set each) take alternate steps, as the verifier's do: a batch is ~25 dependent launches
+        self.ostreams = [pooled_stream(torch, "orb", j, -1) for j in range(orb_workers)] if do_orb else []
+        self.octxs = [capi.Context(device, s.cuda_stream) for s in self.ostreams]
         # two verifier workers (context + stream each) take alternate steps: the verifier is latency bound (host round trips,
         # single-wave clique searches), so two batches in flight fill each other's gaps
         self.vstreams = [pooled_stream(torch, "verify", j, -1) for j in range(verify_workers)] if do_verify else []
         self.vctxs = [capi.Context(device, s.cuda_stream) for s in self.vstreams]
-        self.orb_out = (torch.empty((B, nq, 2), device="cuda"), torch.empty((B, nq, 4), device="cuda"),
-                        torch.empty((B, nq, 32), dtype=torch.uint8, device="cuda")) if do_orb else None
+        self.orb_out = [(torch.empty((B, nq, 2), device="cuda"), torch.empty((B, nq, 4), device="cuda"),
+                         torch.empty((B, nq, 32), dtype=torch.uint8, device="cuda")) for _ in self.octxs]
         self.n_levels = n_levels
         self.match_fn = match_fn or self._match_local
         self.pipe = StagePipeline(torch, orb=self._orb if do_orb else None, match=lambda i, n_steps: self.match_fn(self, i, n_steps),
                                   verify=self._verify if do_verify else None,
                                   wait_for=lambda i, ev: self.vstreams[i % len(self.vstreams)].wait_event(ev), depth=self.D,
-                                  verify_workers=max(verify_workers, 1))
+                                  verify_workers=max(verify_workers, 1), orb_workers=max(orb_workers, 1))
 
     def _orb(self, i):
-        o = self.orb_out
-        n = self.octx.orb_batch_device(self.IMG_B[i % self.period].data_ptr(), self.B, self.H * self.W, self.H, self.W, self.W,
+        o = self.orb_out[i % len(self.octxs)]
+        n = self.octxs[i % len(self.octxs)].orb_batch_device(self.IMG_B[i % self.period].data_ptr(), self.B, self.H * self.W, self.H, self.W, self.W,
                                        self.nq, self.n_levels, 1.2, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), self.nq)
         return sum(n)
 
@@ -241,7 +246,7 @@ class SyntheticPipeline:
 
     def close(self):
         self.pipe.close()
-        for c in [self.octx, self.ctx] + self.vctxs:
+        for c in self.octxs + [self.ctx] + self.vctxs:
             if c is not None:
                 c.close()
 
@@ -310,10 +315,11 @@ def run_chained(torch, capi, device, args):
         mstream = _STREAMS[key]
     else:
         mstream = pooled_stream(torch, "match")
-    ostream = pooled_stream(torch, "orb", 0, -1)
+    NO = max(args.orb_workers, 1)
+    ostreams = [pooled_stream(torch, "orb", j, -1) for j in range(NO)]
     NV = args.chained_workers if args.chained_workers > 0 else (args.verify_workers if args.verify_workers > 0 else 4)
     vstreams = [pooled_stream(torch, "verify", j, -1) for j in range(NV)]
-    mctx, octx = capi.Context(device, mstream.cuda_stream), capi.Context(device, ostream.cuda_stream)
+    mctx, octxs = capi.Context(device, mstream.cuda_stream), [capi.Context(device, s.cuda_stream) for s in ostreams]
     vctxs = [capi.Context(device, s.cuda_stream) for s in vstreams]
     mctx.set_matcher_engine(args.engine)
     spans = mctx.db_load(desc, pts, off)
@@ -329,7 +335,7 @@ def run_chained(torch, capi, device, args):
 
     def orb(i):
         s = orb_ring[i % R]
-        s["n"] = octx.orb_batch_device(batches[i % P]["images"].data_ptr(), B, H * W, H, W, W, nq, 3, 1.2, s["kp"].data_ptr(),
+        s["n"] = octxs[i % NO].orb_batch_device(batches[i % P]["images"].data_ptr(), B, H * W, H, W, W, nq, 3, 1.2, s["kp"].data_ptr(),
                                        s["aux"].data_ptr(), s["desc"].data_ptr(), nq)
         return sum(s["n"])
 
@@ -367,7 +373,7 @@ def run_chained(torch, capi, device, args):
         return sum(len(p) for p in poses)
 
     pipe = StagePipeline(torch, orb=orb, match=match, verify=verify, wait_for=lambda i, ev: vstreams[i % NV].wait_event(ev), depth=D,
-                         verify_workers=NV)
+                         verify_workers=NV, orb_workers=NO)
     setup_s = time.perf_counter() - t_setup
     pipe.run(max(3, 2 * D))                                               # fill the pipeline: D batches are in flight in steady state
     torch.cuda.synchronize()
@@ -423,7 +429,7 @@ def run_chained(torch, capi, device, args):
                                             "blocks_that_walked_rows": walks,
                                             "blocks_source": "profiles/r03_k4x_on_chained_db.json (diagnostics build, tools/k4x_walks.sh)" if walks is not None else None}
         fctx.close()
-    for c in [mctx, octx] + vctxs:
+    for c in [mctx] + octxs + vctxs:
         c.close()
     if lat_cus > 0:
         capi.set_cu_partition(_LATENCY_CUS)
@@ -804,7 +810,8 @@ def main():
                            # 16 frames per step: 9.8k frames/s with two verifier workers, 10.9k with one; plain path 11.6k). At 32 frames
                            # per step that loss is spread over a step twice as long and one worker no longer keeps up
                            # (tools/batch_sweep_dist.sh: 9.3k with one worker, 11.4k with two; plain path 12.4k)
-                           verify_workers=int(os.environ.get("TOD_BENCH_HEADLINE_VW", "1" if sharded_db and not args.serial_exchange and B < 24 else "2")))
+                           verify_workers=int(os.environ.get("TOD_BENCH_HEADLINE_VW", "1" if sharded_db and not args.serial_exchange and B < 24 else "2")),
+                           orb_workers=args.orb_workers)
     sp.pipe.next_orb = overlap
     info = sp.info
     check = None

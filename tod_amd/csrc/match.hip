@@ -388,7 +388,7 @@ __device__ __forceinline__ mfma_f32x16 dot_part0(const Fp4Row& a, const Fp4Row& 
 // and SPLIT 3 is the form that prunes (d192 ~ 75 +- 9.5). Needs thr - (256 - P) >= 0 for the integer maximum (limits up to 64 for
 // SPLIT 2, up to 96 for SPLIT 3; thresholds only tighten). rows / q: the fragments the block's first part was computed from.
 template <int K, int SPLIT>
-__device__ __forceinline__ bool mfma_block_test_part(mfma_f32x16& acc, const Fp4Row& rows, const Fp4Row& q, float& thr, uint32_t r_lane,
+__device__ __forceinline__ bool mfma_block_test_part(mfma_f32x16& acc, const Fp4Row& rows, const Fp4Row& q, float& thr_part, uint32_t r_lane,
                                                      uint32_t n_lim, uint32_t (&best)[K]) {
   // the 16-way maximum as a tree (5 independent max3, then 2 + 1): in this form the kernel is bound by vector issue, not by the matrix
   // pipe (tools/mfma_valu_overlap.hip: 2 MFMAs + chain + expansion 113 cycles per block and SIMD, + tree 103), and the tree's
@@ -397,10 +397,14 @@ __device__ __forceinline__ bool mfma_block_test_part(mfma_f32x16& acc, const Fp4
 #pragma unroll
   for (int j = 0; j < 5; ++j) g[j] = max(max(__float_as_int(acc[3 * j]), __float_as_int(acc[3 * j + 1])), __float_as_int(acc[3 * j + 2]));
   const int m = max(max(max(g[0], g[1]), g[2]), max(max(g[3], g[4]), __float_as_int(acc[15])));
-  if (__builtin_amdgcn_ballot_w64(m > __float_as_int(thr - 64.f * (float)(4 - SPLIT))) == 0ull) return false;
+  // thr_part = the lane's threshold minus what the missing positions could still add (kept in that form by the kernel's main loop:
+  // one vector operation less per block, and the kernel is bound by those)
+  if (__builtin_amdgcn_ballot_w64(m > __float_as_int(thr_part)) == 0ull) return false;
 #pragma unroll
   for (int s = SPLIT; s < 4; ++s) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rows.s[s], q.s[s], acc, 4, 4, 0, 0, 0, 0);
+  float thr = thr_part + 64.f * (float)(4 - SPLIT);
   mfma_block_test<K, false, true>(acc, thr, r_lane, n_lim, best);
+  thr_part = thr - 64.f * (float)(4 - SPLIT);
   return true;
 }
 
@@ -465,6 +469,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   static_assert(QT % 2 == 0 && QT >= 2, "two query blocks share a 64-query flag byte");
   constexpr bool IMAX = MODE >= 1;
   constexpr int HALF = (MODE >= 2 && QT >= 4) ? MODE : 0;           // the split (0: whole blocks)
+  constexpr float kPartOff = HALF ? 64.f * (float)(4 - HALF) : 0.f;   // what the positions behind the split can still add to a dot product
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   uint32_t tile, qw;
   if (tiles_per_xcd) {
@@ -493,7 +498,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
 #pragma unroll
     for (int j = 0; j < K; ++j) best[t][j] = 0xFFFFFFFFu;
     // cut = radius + 1: a row beyond the radius is dropped by the truncation (DescriptorMatcher.cpp:212-220) whatever its rank
-    thr[t] = thr_of_limit(cut);
+    thr[t] = thr_of_limit(cut) - kPartOff;                        // split blocks: the main loop keeps the part thresholds
   }
 
   const uint32_t row0 = tile * rows_per_tile;
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
         const uint32_t worst_d = best[t][K - 1] >> kLocalBits;
         if (worst_d < (0xFFFFFFFFu >> kLocalBits) && worst_d < seen[t]) atomicMin(my_bound, worst_d);
         // a foreign bound is applied with <=: a smaller row index elsewhere may still win a tie
-        if (seen[t] != 0xFFFFFFFFu) thr[t] = fmaxf(thr[t], thr_of_limit(seen[t] + 1u));
+        if (seen[t] != 0xFFFFFFFFu) thr[t] = fmaxf(thr[t], thr_of_limit(seen[t] + 1u) - kPartOff);
         seen[t] = __hip_atomic_load(my_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -566,6 +571,10 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc_odd[i] = -4096.f;
     if (lane == 0 && half_stats) { atomicAdd(half_stats, n_pass); atomicAdd(half_stats + 1, step * (uint32_t)QT); }
+  }
+  if (HALF) {
+#pragma unroll
+    for (int t = 0; t < QT; ++t) thr[t] += kPartOff;               // whole thresholds from here on
   }
   // at most one full and one partial step are left: the masked form serves both
   for (; step < n_steps; ++step) {
@@ -997,17 +1006,23 @@ int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t
   static const int env_qt = getenv("TODHIP_K4X_QT") ? atoi(getenv("TODHIP_K4X_QT")) : 0;     // tuning knob, read once per process
   if (nq <= 32u && !(env_qt > 0))
     return launch_topk_mfma_q32<K>(ctx, d_q, nq, radius, d_lists, n_lists);
-  // Query blocks of 32 per wave (QT): as many as the registers hold beside the k-entry lists -- 8 for k <= 2, 6 for k <= 5
-  // (the reference's k, DescriptorMatcher.cpp:211), 4 beyond -- and among those the one that pads nq the least (a wave
-  // computes all its blocks; 1000 queries are 4 x 256 but 6 x 192). TODHIP_K4X_QT forces one (experiments).
+  // Query blocks of 32 per wave (QT): the registers hold 8 beside the k-entry lists for k <= 2, 6 for k <= 5 (the reference's k,
+  // DescriptorMatcher.cpp:211), 4 beyond. Six is the default even where eight fit: with eight a wave takes 256 registers, two waves
+  // fill a SIMD's file, and every kernel of the other stages (ORB, verifier) then waits for a matcher workgroup to retire before
+  // one of its own can start -- a quarter of a DB pass, 25 dependent launches per ORB batch. With six (216 registers) 80 per SIMD
+  // stay free and those kernels run beside the matcher's waves: alone the pass is 2 % slower (2.36 vs 2.32 ms whole blocks), in the
+  // pipeline ORB's stage falls from 1.9 to 1.2 ms, the verifier's from 2.05 to 1.5, and the matcher's own launch is no slower
+  // (tools/ab_k4x_residency.sh: headline 16.2k -> 16.6k frames/s, chained 8.7k -> 9.9k). Among the candidates the one that pads nq
+  // the least wins when that saves more than 3 % (a wave computes all its blocks; 1000 queries are 4 x 256 but 6 x 192).
+  // TODHIP_K4X_QT forces one (experiments).
   // With at most 64 queries a wave holds two blocks (QT = 2): 8 MFMAs per 1 KB of rows -- the pass is then bound by HBM,
   // not by the matrix pipe (BASELINE.json's "achieved HBM GB/s on BF-matcher" regime; tools/k4_small_q.py).
   constexpr int kMaxQT = K <= 2 ? 8 : (K <= 5 ? 6 : 4);
-  auto padded = [&](uint32_t qt) { return (nq + 32u * qt - 1u) / (32u * qt) * (32u * qt); };
-  int qt = kMaxQT;
-  if (kMaxQT >= 8 && padded(6) < padded((uint32_t)qt)) qt = 6;
-  if (kMaxQT >= 6 && padded(4) < padded((uint32_t)qt)) qt = 4;
-  if (padded(2) < padded((uint32_t)qt)) qt = 2;
+  auto padded = [&](uint32_t qt) { return (uint64_t)((nq + 32u * qt - 1u) / (32u * qt) * (32u * qt)); };
+  int qt = kMaxQT >= 6 ? 6 : 4;
+  if (kMaxQT >= 8 && padded(8) * 103u < padded(6) * 100u) qt = 8;
+  if (qt > 4 && padded(4) * 103u < padded((uint32_t)qt) * 100u) qt = 4;
+  if (padded(2) * 103u < padded((uint32_t)qt) * 100u) qt = 2;
   if (nq <= 2048u && qt > 4) qt = 4;                                  // a frame or two: longer tiles, see launch_topk_mfma_qt
   if ((env_qt == 2 || env_qt == 4 || env_qt == 6 || env_qt == 8) && env_qt <= kMaxQT) qt = env_qt;
   if (qt == 8) return launch_topk_mfma_qt<K, (kMaxQT >= 8 ? 8 : 4)>(ctx, d_q, nq, radius, d_lists, n_lists);

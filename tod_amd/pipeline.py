@@ -24,10 +24,12 @@ class StagePipeline:
                                 multi-rank step gathers the next step's descriptors one step early)"""
 
     def __init__(self, torch, orb=None, match=None, verify=None, wait_for=None, depth=3, match_needs_next_orb=False,
-                 verify_workers=1):
+                 verify_workers=1, orb_workers=1):
         self.torch, self.orb, self.match, self.verify, self.wait_for = torch, orb, match, verify, wait_for
         self.D, self.next_orb = depth, match_needs_next_orb
-        self.opool = ThreadPoolExecutor(1) if orb else None
+        # orb_workers > 1: consecutive steps' ORB calls overlap the same way (the callable picks its context by i % orb_workers)
+        self.opool = ThreadPoolExecutor(orb_workers) if orb else None
+        self.olocks = [threading.Lock() for _ in range(max(orb_workers, 1))]
         # verify_workers > 1: consecutive steps' verifier calls overlap (each worker has its own context and stream; the
         # callables pick theirs by i % verify_workers) -- the verifier is latency bound, two batches in flight fill its gaps
         self.vpool = ThreadPoolExecutor(verify_workers) if verify else None
@@ -42,10 +44,11 @@ class StagePipeline:
                 self.stage_s[key] = 0.0
 
     def _orb_task(self, i):
-        t = time.perf_counter()
-        n = self.orb(i)
-        with self.stat_lock:
-            self.stage_s["orb"] += time.perf_counter() - t
+        with self.olocks[i % len(self.olocks)]:
+            t = time.perf_counter()
+            n = self.orb(i)
+            with self.stat_lock:
+                self.stage_s["orb"] += time.perf_counter() - t
         return n
 
     def _verify_task(self, i, ev):
