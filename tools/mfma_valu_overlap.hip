@@ -86,6 +86,76 @@ __global__ __launch_bounds__(256, 2) void k(float* out, int seed, float thr, uns
   if (hits) atomicAdd(sink, hits);
 }
 
+// the same 1024 pairs x 128 bit positions as four 16 x 16 x 128 tiles: one MFMA each, no accumulator input, 4 result registers
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int XV>
+__global__ __launch_bounds__(256, 2) void k16(float* out, int seed, float thr, unsigned* sink) {
+  i32x8 a[4], b[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      a[s][i] = i < 4 ? (int)((mix(threadIdx.x * 131u + s * 17u + i + seed) & 0x88888888u) | 0x22222222u) : 0;
+      b[s][i] = i < 4 ? (int)((mix(threadIdx.x * 977u + s * 29u + i * 7u + blockIdx.x) & 0x88888888u) | 0x22222222u) : 0;
+    }
+  f32x4 e[4], o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) { e[j][i] = -4096.f; o[j][i] = -4096.f; }
+  unsigned x = mix(threadIdx.x + seed), hits = 0;
+  const unsigned sign = 0x88888888u, one = 0x22222222u;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  auto test16 = [&](const f32x4 (&v)[4]) {
+    int m = max(max(__float_as_int(v[0][0]), __float_as_int(v[0][1])), __float_as_int(v[0][2]));
+    m = max(max(m, __float_as_int(v[0][3])), __float_as_int(v[1][0]));
+    m = max(max(m, __float_as_int(v[1][1])), __float_as_int(v[1][2]));
+    m = max(max(m, __float_as_int(v[1][3])), __float_as_int(v[2][0]));
+    m = max(max(m, __float_as_int(v[2][1])), __float_as_int(v[2][2]));
+    m = max(max(m, __float_as_int(v[2][3])), __float_as_int(v[3][0]));
+    m = max(max(m, __float_as_int(v[3][1])), __float_as_int(v[3][2]));
+    m = max(m, __float_as_int(v[3][3]));
+    return m > __float_as_int(thr);
+  };
+  for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[j], b[j], z, 4, 4, 0, 0, 0, 0);
+    if (XV) {
+      a[0][0] = (int)(((x << 3) & sign) | one); a[0][1] = (int)(((x << 2) & sign) | one);
+      a[0][2] = (int)(((x << 1) & sign) | one); a[0][3] = (int)((x & sign) | one);
+      x += 0x9e3779b9u;
+    }
+    if (__builtin_amdgcn_ballot_w64(test16(o)) != 0ull) { ++hits; thr += 1.f; asm volatile("global_store_dword %0, %1, off" :: "v"(sink + (threadIdx.x & 63u)), "v"(hits) : "memory"); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[j], b[j], z, 4, 4, 0, 0, 0, 0);
+    if (XV) {
+      b[0][0] = (int)(((x << 3) & sign) | one); b[0][1] = (int)(((x << 2) & sign) | one);
+      b[0][2] = (int)(((x << 1) & sign) | one); b[0][3] = (int)((x & sign) | one);
+      x += 0x9e3779b9u;
+    }
+    if (__builtin_amdgcn_ballot_w64(test16(e)) != 0ull) { ++hits; thr += 1.f; asm volatile("global_store_dword %0, %1, off" :: "v"(sink + (threadIdx.x & 63u)), "v"(hits) : "memory"); }
+  }
+  float r = 0.f;
+  for (int j = 0; j < 4; ++j) for (int i = 0; i < 4; ++i) r += e[j][i] + o[j][i];
+  out[blockIdx.x * 256 + threadIdx.x] = r + (float)a[0][0] + (float)b[1][2];
+  if (hits) atomicAdd(sink, hits);
+}
+
+template <int XV>
+void run16(const char* what, int n_cu, float* d_out, unsigned* d_sink) {
+  const int grid = n_cu * 2;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL((k16<XV>), dim3(grid), dim3(256), 0, 0, d_out, 1, 1e30f, d_sink);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int r = 0; r < 6; ++r) {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k16<XV>), dim3(grid), dim3(256), 0, 0, d_out, r + 2, 1e30f, d_sink);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+  }
+  const double ns = best * 1e6 / (2.0 * kIters * 2.0);
+  printf("%-58s %.3f ms  %6.1f ns per block per SIMD (%5.1f cycles @2.1 GHz)\n", what, best, ns, ns * 2.1);
+}
+
 template <int NM, int TEST, int XV>
 double run(const char* what, int n_cu, float* d_out, unsigned* d_sink) {
   const int grid = n_cu * 2;
@@ -118,6 +188,8 @@ int main() {
   run<2, 3, 0>("2 MFMAs + chain over 8 registers", n_cu, d_out, d_sink);
   run<2, 1, 4>("2 MFMAs + chain test + expansion (the product's half)", n_cu, d_out, d_sink);
   run<2, 2, 4>("2 MFMAs + tree test + expansion", n_cu, d_out, d_sink);
+  run16<0>("4 x (16x16x128, C = 0) + chain test", n_cu, d_out, d_sink);
+  run16<4>("4 x (16x16x128, C = 0) + chain test + expansion", n_cu, d_out, d_sink);
   run<3, 0, 0>("3 MFMAs per block, nothing else", n_cu, d_out, d_sink);
   run<3, 1, 4>("3 MFMAs + chain test + expansion", n_cu, d_out, d_sink);
   run<4, 0, 0>("4 MFMAs per block, nothing else", n_cu, d_out, d_sink);
