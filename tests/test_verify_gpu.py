@@ -531,6 +531,28 @@ def test_batch_of_heavy_and_light_frames_equals_frame_by_frame(ctx):
     assert max(len(p["inliers"]) for f in range(F) for p in got[f]) >= 96         # some object was heavy enough to fly
 
 
+
+def _frame_diffs(got, rngs, want):
+    """why frame results of a batch differ from the frame-by-frame calls' (want[f] = (poses, generator)); [] when they do not"""
+    out = []
+    for f, (w, wr) in enumerate(want):
+        why = []
+        if rngs[f].draws != wr.draws or list(rngs[f].s) != list(wr.s):
+            why.append("generator at draw %d, frame by frame %d" % (rngs[f].draws, wr.draws))
+        if len(got[f]) != len(w):
+            why.append("%d poses, frame by frame %d" % (len(got[f]), len(w)))
+        for j, (a, b) in enumerate(zip(got[f], w)):
+            if a["object"] != b["object"]:
+                why.append("pose %d: object %d, frame by frame %d" % (j, a["object"], b["object"]))
+            elif not np.array_equal(a["inliers"], b["inliers"]):
+                why.append("pose %d (object %d): %d inliers, frame by frame %d" % (j, a["object"], len(a["inliers"]), len(b["inliers"])))
+            elif not np.array_equal(a["R"], b["R"]):
+                why.append("pose %d (object %d): R differs by %.3g" % (j, a["object"], np.abs(a["R"] - b["R"]).max()))
+        if why:
+            out.append("frame %d: %s" % (f, "; ".join(why)))
+    return out
+
+
 def test_batch_of_44_heavy_and_light_frames_with_several_groups_in_the_air(ctx):
     """More than 32 frames: a launch group's evaluation lists exceed one launch's argument sets and travel through device memory
     (launch_many), and several such groups are in the air on different lanes at once -- each lane has its own staging pair, which
@@ -560,10 +582,8 @@ def test_batch_of_44_heavy_and_light_frames_with_several_groups_in_the_air(ctx):
         got = ctx.verify_batch_device(F, d_kp.data_ptr(), nq, d_cloud.data_ptr(), 480, 640, d_counts.data_ptr(), d_m.data_ptr(),
                                       d_xyz.data_ptr(), k, spans, 8, 600, 0.01, rngs)
         assert sum(len(p) for p in got) >= 30
-        for f in range(F):
-            assert rngs[f].draws == want[f][1].draws and list(rngs[f].s) == list(want[f][1].s) and len(got[f]) == len(want[f][0]), f
-            for a, b in zip(got[f], want[f][0]):
-                assert a["object"] == b["object"] and np.array_equal(a["inliers"], b["inliers"]) and np.array_equal(a["R"], b["R"])
+        diffs = _frame_diffs(got, rngs, want)
+        assert not diffs, "repetition %d: %s" % (rep, " | ".join(diffs))
 
 
 @pytest.mark.parametrize("n_obj", [40, 200])
@@ -619,3 +639,31 @@ def test_maximum_object_size_and_one_beyond(ctx):
     with pytest.raises(capi.TodError) as e:
         ctx.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 6, 0.01, rng)
     assert e.value.status == capi.ESCRATCH
+
+
+def test_the_same_frame_again_and_again_is_the_same_frame(ctx):
+    """A frame of distractor objects only (a few dozen matches each, several objects sharing every 256-match chunk of the cluster
+    kernel's grouping pass), 15 times per generator seed through todhip_verify_device: every run's round traces and final generator
+    position equal the oracle's. (cluster_frame_kernel once read an object's running count while a faster wave of the same chunk was
+    already updating it: one run in three put matches in the wrong order -- same poses, other draws.)"""
+    import torch
+    k, nq = 3, 400
+    sc = synth.make_verify_scene(nq, visible=(), seed=642, matches_per_kp=3, n_objects=8)
+    c, m, x = _pack_scene(sc, k)
+    d_kp = torch.from_numpy(sc["kp_xy"].astype(np.float32)).cuda()
+    d_cloud = torch.from_numpy(sc["cloud"].astype(np.float32)).cuda()
+    d_c, d_m, d_x = torch.from_numpy(c).cuda(), torch.from_numpy(m).cuda(), torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    key = lambda r: (r.iterations, r.best_iteration, r.best_count, r.draws_before, r.draws_after)
+    for seed in (4, 5, 6):
+        rng_o = O.rng_new(seed)
+        rc, want, o_rounds = O.verify(sc["kp_xy"], sc["cloud"], sc["row_ptr"], sc["matches"], sc["matches_xyz"], sc["spans"], 8, 600, 0.01, rng_o)
+        assert rc == 0
+        o_rounds = [key(r) for r in o_rounds if not (r.iterations == 0 and r.draws_after == r.draws_before and r.best_count == 0)]
+        assert len(o_rounds) >= 6
+        for rep in range(15):
+            r = capi.rng_new(seed)
+            got = ctx.verify_device(d_kp.data_ptr(), nq, d_cloud.data_ptr(), 480, 640, d_c.data_ptr(), d_m.data_ptr(), d_x.data_ptr(), k,
+                                    sc["spans"], 8, 600, 0.01, r)
+            g_rounds = [key(t) for t in ctx.verify_trace() if not (t.iterations == 0 and t.draws_after == t.draws_before)]
+            assert g_rounds == o_rounds and r.draws == rng_o.draws and len(got) == len(want), (seed, rep)

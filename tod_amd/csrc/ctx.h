@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../include/todhip.h"
@@ -37,6 +38,10 @@ struct DevBuf {
     size_t want = bytes + bytes / 4 + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
+    // diagnostics (tests/test_verify_gpu.py's poisoned run): fresh allocations start as 0xCD bytes instead of whatever the
+    // allocator hands back, so that a read of memory nobody wrote shows up on every run, not on one in five
+    static const bool poison = getenv("TODHIP_POISON_ALLOC") != nullptr;
+    if (e == hipSuccess && poison) { e = hipMemset(p, 0xCD, want); if (e == hipSuccess) e = hipDeviceSynchronize(); }
     return e;
   }
   void release() {
@@ -59,6 +64,8 @@ struct HostBuf {
     size_t want = bytes + bytes / 4 + 256;
     hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
     if (e == hipSuccess) cap = want;
+    static const bool poison = getenv("TODHIP_POISON_ALLOC") != nullptr;   // as DevBuf
+    if (e == hipSuccess && poison) std::memset(p, 0xCD, want);
     return e;
   }
   void release() {

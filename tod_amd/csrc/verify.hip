@@ -1941,12 +1941,16 @@ __global__ __launch_bounds__(256) void cluster_frame_kernel(Slots<ClusterArgs> S
     const bool have = f < n_all;
     const uint32_t o = have ? a.obj_of[f] : 0xFFFFFFFFu;
     s_o[tid] = o;
+    // the object's matches in earlier chunks: read by EVERY thread before any thread of this chunk updates it (the barrier below) --
+    // the last match of an object in the chunk may sit in a wave that runs ahead of the waves holding its earlier ones, and a count
+    // read after that update sends the earlier matches to the wrong places (found as one batch result in five differing from the
+    // frame-by-frame call: tools/verify_repeat_frame.py)
+    const uint32_t seen = have ? a.cnt[o] : 0u;
     __syncthreads();
     if (have) {
       uint32_t before = 0, after = 0;
       for (uint32_t u = 0; u < tid; ++u) before += s_o[u] == o;
       for (uint32_t u = tid + 1u; u < 256u; ++u) after += s_o[u] == o;
-      const uint32_t seen = a.cnt[o];                       // (written by the chunk before, behind a barrier)
       const uint32_t d = a.goff[o] + seen + before;
       const uint32_t t = a.src[f], q = t / k;
       for (int c = 0; c < 3; ++c) { a.train[3 * d + c] = a.mxyz[(size_t)t * 3 + c]; a.query[3 * d + c] = a.qpt[3 * q + c]; }
@@ -2167,6 +2171,12 @@ struct RoundState {                                       // computeModel (ransa
   uint32_t s_floor = 0;                                   // grows x4 whenever a window ran out before the request was served
 };
 
+// TODHIP_SPRINT_MARGIN=n (diagnostics): the first look-ahead of a sprint, so that tests can put the stream's end -- and with it the
+// kernel's stop-and-resume path -- anywhere in a frame's rounds (default 2^17 draws; it quadruples on every stop)
+inline uint64_t sprint_margin0() {
+  static const uint64_t v = [] { const char* e = getenv("TODHIP_SPRINT_MARGIN"); const long long x = e ? atoll(e) : 0; return x > 0 ? (uint64_t)x : (uint64_t)(1u << 17); }();
+  return v;
+}
 struct Slot {
   VerifyWs* ws = nullptr;
   // inputs (device-resident form)
@@ -2193,7 +2203,7 @@ struct Slot {
   // first window sized for a healthy object (576) made each of them crawl through three windows = three ticks
   uint32_t s_hint = 0;
   std::vector<size_t> sprint_members;                      // indices into objs of the sprint in flight (sprint_kernel)
-  uint64_t sprint_margin = 1u << 17;                       // rand() words the device copy of the stream reaches beyond the sprint's start
+  uint64_t sprint_margin = sprint_margin0();               // rand() words the device copy of the stream reaches beyond the sprint's start
   todhip_round_trace tr = {};
   RoundState r;
 };
