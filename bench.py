@@ -404,18 +404,18 @@ def run_chained(torch, capi, device, args):
     pipe.close()
     # the matcher's DB pass at the HEADLINE's launch shape (32 frames = 32 000 queries per pass) on this block's DB and descriptors --
     # the data it will see: biased, correlated rBRIEF bits and self-similar textures -- alone on the GPU, on an unpartitioned stream
-    if B * 2 * nq == 32000 and R >= 2:
+    if B * nq in (16000, 32000) and R >= 2:
         fctx = capi.Context(device)
         fctx.set_matcher_engine(args.engine)
         fctx.db_load(desc, pts, off)
-        de32 = torch.cat([orb_ring[0]["desc"], orb_ring[1]["desc"]]).contiguous()
-        n32 = 2 * B * nq
+        de32 = (orb_ring[0]["desc"] if B * nq == 32000 else torch.cat([orb_ring[0]["desc"], orb_ring[1]["desc"]])).contiguous()
+        n32 = 32000
         c32 = torch.zeros(n32, dtype=torch.int32, device="cuda"); m32 = torch.zeros((n32 * k, 4), dtype=torch.int32, device="cuda")
         x32 = torch.zeros((n32 * k, 3), dtype=torch.float32, device="cuda")
         call32 = lambda: fctx.match_device(de32.data_ptr(), n32, k, radius, c32.data_ptr(), m32.data_ptr(), x32.data_ptr())
-        for _ in range(2):
-            call32()
-        fctx.synchronize(); fctx.set_kernel_timing(True); f0 = fctx.counters()
+        for _ in range(6):                                                  # (a fresh context walks the block forms from the launches' reports:
+            call32(); fctx.synchronize()                                     # settled after three launches whose reports it has seen)
+        fctx.set_kernel_timing(True); f0 = fctx.counters()
         for _ in range(6):
             call32()
         fctx.synchronize(); ms32, n32l = launch_ms(f0, fctx.counters()); fctx.set_kernel_timing(False)
@@ -426,6 +426,7 @@ def run_chained(torch, capi, device, args):
             walks = json.load(open(wp)).get("chained_db", {}).get("walk_fraction")
         out["matcher_at_headline_shape"] = {"what": "32 000 of this block's ORB descriptors x its %d-row trained DB per launch, alone" % int(off[-1]),
                                             "launch_ms": ms32, "launches": n32l, "TFLOPs": tf32, "frac": tf32 / MFMA_FP4_PEAK_TFLOPS,
+                                            "block_form": {4: "whole blocks", 3: "split after 3 of 4 MFMAs", 2: "split after 2 of 4 MFMAs"}.get(int(fctx.counters().last_block_split), "?") + " (chosen by the context from its launches' reports)",
                                             "blocks_that_walked_rows": walks,
                                             "blocks_source": "profiles/r03_k4x_on_chained_db.json (diagnostics build, tools/k4x_walks.sh)" if walks is not None else None}
         fctx.close()
