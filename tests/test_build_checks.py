@@ -26,13 +26,35 @@ def _sgprs(text):
     return regs
 
 
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_k4_prefetched_sgprs_are_untouched_until_their_wait():
+@pytest.fixture(scope="module")
+def match_asm():
+    """match.hip as gfx950 assembly, compiled once for the module (same compiler, same flags as the Makefile)"""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "match.s")
         subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only",
                         "-o", out, os.path.join(ROOT, "tod_amd", "csrc", "match.hip")], check=True, stderr=subprocess.DEVNULL)
-        asm = open(out).read()
+        return open(out).read()
+
+
+def test_k4x_waves_leave_room_in_the_register_file(match_asm):
+    """The matrix-core matcher's default launch (six query blocks per wave, k <= 2) must stay at <= 224 registers per wave: two
+    waves then leave >= 64 of a SIMD's 512 free and ORB's and the verifier's kernels start beside them instead of waiting for a
+    matcher workgroup to retire (ORB's stage 1.2 ms against 1.8-1.9). A harmless-looking change of the hot loop once took
+    the kernel to 243 registers and the pipeline lost that silently -- only the generated code can tell. No spills either."""
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(\S*hamming_topk_mfmaILi([12])ELi6ELi([0-3])ELb\d\S*)", match_asm):
+        blk = match_asm[m.start():m.start() + 1500]
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+        assert vgpr <= 224 and scratch == 0, "hamming_topk_mfma<%s, 6, %s>: %d registers, %d bytes of scratch" % (m.group(2), m.group(3), vgpr, scratch)
+        seen += 1
+    assert seen == 8, "expected the four block forms of hamming_topk_mfma<1 / 2, 6, ...>"
+
+
+def test_k4_prefetched_sgprs_are_untouched_until_their_wait(match_asm):
+    asm = match_asm
     kernels, cur = [], None                                            # (name, [instruction lines]) per instantiation
     for line in asm.split("\n"):
         m = re.match(r"^(_ZN\S*hamming_topk_tiles\S*):", line)

@@ -388,23 +388,22 @@ __device__ __forceinline__ mfma_f32x16 dot_part0(const Fp4Row& a, const Fp4Row& 
 // and SPLIT 3 is the form that prunes (d192 ~ 75 +- 9.5). Needs thr - (256 - P) >= 0 for the integer maximum (limits up to 64 for
 // SPLIT 2, up to 96 for SPLIT 3; thresholds only tighten). rows / q: the fragments the block's first part was computed from.
 template <int K, int SPLIT>
-__device__ __forceinline__ bool mfma_block_test_part(mfma_f32x16& acc, const Fp4Row& rows, const Fp4Row& q, float& thr_part, uint32_t r_lane,
+__device__ __forceinline__ bool mfma_block_test_part(mfma_f32x16& acc, const Fp4Row& rows, const Fp4Row& q, float& thr, uint32_t r_lane,
                                                      uint32_t n_lim, uint32_t (&best)[K]) {
   // the 16-way maximum as a tree (5 independent max3, then 2 + 1): in this form the kernel is bound by vector issue, not by the matrix
   // pipe (tools/mfma_valu_overlap.hip: 2 MFMAs + chain + expansion 113 cycles per block and SIMD, + tree 103), and the tree's
-  // independent operations fill the issue slots a chain leaves to its own latency
+  // independent operations fill the issue slots a chain leaves to its own latency. (Keeping the thresholds in their part form,
+  // thr - 64 (4 - SPLIT), to spare the subtraction below was tried: one instruction less per block, but the six-block kernel went
+  // from 218 to 243 registers -- and lost the room in the register file that lets the other stages' kernels start beside the
+  // matcher's waves (launch_topk_mfma), which is worth far more to the pipeline: ORB's stage 1.2 -> 1.8 ms.)
   int g[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) g[j] = max(max(__float_as_int(acc[3 * j]), __float_as_int(acc[3 * j + 1])), __float_as_int(acc[3 * j + 2]));
   const int m = max(max(max(g[0], g[1]), g[2]), max(max(g[3], g[4]), __float_as_int(acc[15])));
-  // thr_part = the lane's threshold minus what the missing positions could still add (kept in that form by the kernel's main loop:
-  // one vector operation less per block, and the kernel is bound by those)
-  if (__builtin_amdgcn_ballot_w64(m > __float_as_int(thr_part)) == 0ull) return false;
+  if (__builtin_amdgcn_ballot_w64(m > __float_as_int(thr - 64.f * (float)(4 - SPLIT))) == 0ull) return false;
 #pragma unroll
   for (int s = SPLIT; s < 4; ++s) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rows.s[s], q.s[s], acc, 4, 4, 0, 0, 0, 0);
-  float thr = thr_part + 64.f * (float)(4 - SPLIT);
   mfma_block_test<K, false, true>(acc, thr, r_lane, n_lim, best);
-  thr_part = thr - 64.f * (float)(4 - SPLIT);
   return true;
 }
 
@@ -469,7 +468,6 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   static_assert(QT % 2 == 0 && QT >= 2, "two query blocks share a 64-query flag byte");
   constexpr bool IMAX = MODE >= 1;
   constexpr int HALF = (MODE >= 2 && QT >= 4) ? MODE : 0;           // the split (0: whole blocks)
-  constexpr float kPartOff = HALF ? 64.f * (float)(4 - HALF) : 0.f;   // what the positions behind the split can still add to a dot product
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   uint32_t tile, qw;
   if (tiles_per_xcd) {
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
 #pragma unroll
     for (int j = 0; j < K; ++j) best[t][j] = 0xFFFFFFFFu;
     // cut = radius + 1: a row beyond the radius is dropped by the truncation (DescriptorMatcher.cpp:212-220) whatever its rank
-    thr[t] = thr_of_limit(cut) - kPartOff;                        // split blocks: the main loop keeps the part thresholds
+    thr[t] = thr_of_limit(cut);
   }
 
   const uint32_t row0 = tile * rows_per_tile;
@@ -559,7 +557,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
         const uint32_t worst_d = best[t][K - 1] >> kLocalBits;
         if (worst_d < (0xFFFFFFFFu >> kLocalBits) && worst_d < seen[t]) atomicMin(my_bound, worst_d);
         // a foreign bound is applied with <=: a smaller row index elsewhere may still win a tie
-        if (seen[t] != 0xFFFFFFFFu) thr[t] = fmaxf(thr[t], thr_of_limit(seen[t] + 1u) - kPartOff);
+        if (seen[t] != 0xFFFFFFFFu) thr[t] = fmaxf(thr[t], thr_of_limit(seen[t] + 1u));
         seen[t] = __hip_atomic_load(my_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -571,10 +569,6 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc_odd[i] = -4096.f;
     if (lane == 0 && half_stats) { atomicAdd(half_stats, n_pass); atomicAdd(half_stats + 1, step * (uint32_t)QT); }
-  }
-  if (HALF) {
-#pragma unroll
-    for (int t = 0; t < QT; ++t) thr[t] += kPartOff;               // whole thresholds from here on
   }
   // at most one full and one partial step are left: the masked form serves both
   for (; step < n_steps; ++step) {
