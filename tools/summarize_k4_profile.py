@@ -8,7 +8,9 @@ log = open(os.path.join(out, "prof_k4_trace.log")).read()
 bench = json.loads(re.findall(r"^\{.*\}$", log, re.M)[-1])
 mfma = bench["roofline"]["kernel"] == "hamming_topk_mfma"
 name = "k4x" if mfma else "k4"
-stats = glob.glob(os.path.join(out, "prof_k4_trace", "**", "*kernel_stats.csv"), recursive=True)
+# gpurun merges a call's outputs into gpurun_out/ without removing older ones: take the NEWEST file of every directory
+newest = lambda files: sorted(files, key=os.path.getmtime)[-1:]
+stats = newest(glob.glob(os.path.join(out, "prof_k4_trace", "**", "*kernel_stats.csv"), recursive=True))
 assert stats, "no kernel_stats.csv"
 shutil.copy(stats[0], os.path.join(root, "profiles", "%s_%s_kernel_stats.csv" % (tag, name)))
 # the timed launches = the instantiation of the engine's kernel with the most calls (k = 2, radius 35; which query-block count
@@ -22,7 +24,7 @@ assert avg_ns, "matcher kernel not in the trace"
 
 pmc = {}
 for d in sorted(glob.glob(os.path.join(out, "prof_k4_pmc*"))):
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         acc, n = {}, {}
         for row in csv.DictReader(open(f)):
             if KERNEL not in row["Kernel_Name"]:
