@@ -920,17 +920,19 @@ def main():
                         "measured_mfma_roof": pmc.get("measured_mfma_roof"),
                         "note": "exact 256-bit Hamming distances as fp4 (+-1) dot products on the matrix cores: 512 flop per (query, row) "
                                 "pair, v_mfma_f32_32x32x64_f8f6f4. `achieved` counts those ALGORITHMIC flops (SURVEY 8(d)); since round 3 a "
-                                "32 x 32 block only executes its second 128 bit positions when its first 128 leave a pair inside the "
-                                "limit (partial-distance elimination, exact for any data; `half_blocks`), so on this workload about half "
+                                "32 x 32 block only executes the rest of its 256 bit positions when its first 128 (or 192) leave a pair inside the "
+                                "limit (partial-distance elimination, exact for any data, the form adapts to it; `half_blocks`), so on this workload about half "
                                 "of them are executed and `frac` measures the pass against the roof of the arithmetic it replaces, not "
                                 "matrix-pipe occupancy. launch_ms = HIP events around the launch on its own stream, averaged over the "
                                 "timed regions"}
             hc = sp.ctx.counters()
             if hc.k4x_half_blocks:
                 done = hc.k4x_half_blocks_completed / hc.k4x_half_blocks
-                roofline["half_blocks"] = {"blocks_started_as_halves": int(hc.k4x_half_blocks), "fraction_completed": done,
-                                           "executed_over_algorithmic_flops": 0.5 + 0.5 * done,
-                                           "executed_TFLOPs": tflops * (0.5 + 0.5 * done), "executed_frac_of_peak": tflops * (0.5 + 0.5 * done) / MFMA_FP4_PEAK_TFLOPS}
+                first = {2: 0.5, 3: 0.75}.get(int(hc.last_block_split), 1.0)   # the block form the context has settled on (todhip_set_matcher_block_split: adaptive)
+                executed = first + (1.0 - first) * done if first < 1.0 else 1.0
+                roofline["half_blocks"] = {"split_after_mfmas_of_4": int(hc.last_block_split), "blocks_started_as_parts": int(hc.k4x_half_blocks),
+                                           "fraction_completed": done, "executed_over_algorithmic_flops": executed,
+                                           "executed_TFLOPs": tflops * executed, "executed_frac_of_peak": tflops * executed / MFMA_FP4_PEAK_TFLOPS}
         else:
             laneops = float(pmc.get("valu_insts_per_row_and_wave", LANEOPS_DENSE)) if traffic is not None else float(LANEOPS_DENSE)
             valu_rate = laneops * pairs / (k4_ms * 1e-3) if k4_ms > 0 else 0.0
