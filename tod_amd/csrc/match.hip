@@ -388,22 +388,24 @@ __device__ __forceinline__ mfma_f32x16 dot_part0(const Fp4Row& a, const Fp4Row& 
 // and SPLIT 3 is the form that prunes (d192 ~ 75 +- 9.5). Needs thr - (256 - P) >= 0 for the integer maximum (limits up to 64 for
 // SPLIT 2, up to 96 for SPLIT 3; thresholds only tighten). rows / q: the fragments the block's first part was computed from.
 template <int K, int SPLIT>
-__device__ __forceinline__ bool mfma_block_test_part(mfma_f32x16& acc, const Fp4Row& rows, const Fp4Row& q, float& thr, uint32_t r_lane,
-                                                     uint32_t n_lim, uint32_t (&best)[K]) {
+__device__ __forceinline__ bool mfma_block_test_part(mfma_f32x16& acc, const Fp4Row& rows, const Fp4Row& q, float& thr, float& thrp,
+                                                     uint32_t r_lane, uint32_t n_lim, uint32_t (&best)[K]) {
   // the 16-way maximum as a tree (5 independent max3, then 2 + 1): in this form the kernel is bound by vector issue, not by the matrix
   // pipe (tools/mfma_valu_overlap.hip: 2 MFMAs + chain + expansion 113 cycles per block and SIMD, + tree 103), and the tree's
-  // independent operations fill the issue slots a chain leaves to its own latency. (Keeping the thresholds in their part form,
-  // thr - 64 (4 - SPLIT), to spare the subtraction below was tried: one instruction less per block, but the six-block kernel went
-  // from 218 to 243 registers -- and lost the room in the register file that lets the other stages' kernels start beside the
-  // matcher's waves (launch_topk_mfma), which is worth far more to the pipeline: ORB's stage 1.2 -> 1.8 ms.)
+  // independent operations fill the issue slots a chain leaves to its own latency. The part thresholds (thrp = thr - 64 (4 - SPLIT))
+  // live in registers of their own beside the whole ones: one instruction less per block (1.82 -> 1.73 ms in the pipeline) for six
+  // registers, 218 -> 224, still inside the budget that lets the other stages' kernels start beside the matcher's waves
+  // (launch_topk_mfma; tests/test_build_checks.py holds the line). Keeping ONLY the part form -- no extra registers on paper -- made
+  // hipcc allocate 243.
   int g[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) g[j] = max(max(__float_as_int(acc[3 * j]), __float_as_int(acc[3 * j + 1])), __float_as_int(acc[3 * j + 2]));
   const int m = max(max(max(g[0], g[1]), g[2]), max(max(g[3], g[4]), __float_as_int(acc[15])));
-  if (__builtin_amdgcn_ballot_w64(m > __float_as_int(thr - 64.f * (float)(4 - SPLIT))) == 0ull) return false;
+  if (__builtin_amdgcn_ballot_w64(m > __float_as_int(thrp)) == 0ull) return false;
 #pragma unroll
   for (int s = SPLIT; s < 4; ++s) acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rows.s[s], q.s[s], acc, 4, 4, 0, 0, 0, 0);
   mfma_block_test<K, false, true>(acc, thr, r_lane, n_lim, best);
+  thrp = thr - 64.f * (float)(4 - SPLIT);
   return true;
 }
 
@@ -416,7 +418,7 @@ __device__ __forceinline__ bool mfma_block_test_part(mfma_f32x16& acc, const Fp4
 // a_next's registers 2 and 3 until this step's expansion overwrites them at t == 2, 3.
 template <int K, int QT, bool MASK, bool IMAX, int SPLIT = 0>
 __device__ __forceinline__ uint32_t mfma_step(const Fp4Row& a, Fp4Row& a_next, const uint4& p_next, const Fp4Row (&qb)[QT],
-                                              float (&thr)[QT], uint32_t (&best)[QT][K], mfma_f32x16& acc_even,
+                                              float (&thr)[QT], float (&thrp)[QT], uint32_t (&best)[QT][K], mfma_f32x16& acc_even,
                                               mfma_f32x16& acc_odd, uint32_t r_lane, uint32_t n_lim, const Fp4Consts& kc) {
   constexpr bool HALF = SPLIT != 0;
   uint32_t n_pass = 0;                                     // SPLIT: blocks that went on to their second part (wave-uniform)
@@ -443,8 +445,8 @@ __device__ __forceinline__ uint32_t mfma_step(const Fp4Row& a, Fp4Row& a_next, c
     if (t == 0) asm volatile("" :: "v"(acc_odd)); else if (t & 1) asm volatile("" :: "v"(acc_even)); else asm volatile("" :: "v"(acc_odd));
 #else
     if (HALF) {
-      if (t == 0) n_pass += mfma_block_test_part<K, HALF ? SPLIT : 2>(acc_odd, a_next, qb[QT - 1], thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]) ? 1u : 0u;   // previous step's last block, its rows
-      else n_pass += mfma_block_test_part<K, HALF ? SPLIT : 2>((t & 1) ? acc_even : acc_odd, a, qb[t - 1], thr[t - 1], r_lane, n_lim, best[t - 1]) ? 1u : 0u;
+      if (t == 0) n_pass += mfma_block_test_part<K, HALF ? SPLIT : 2>(acc_odd, a_next, qb[QT - 1], thr[QT - 1], thrp[QT - 1], r_lane - 32u, n_lim, best[QT - 1]) ? 1u : 0u;   // previous step's last block, its rows
+      else n_pass += mfma_block_test_part<K, HALF ? SPLIT : 2>((t & 1) ? acc_even : acc_odd, a, qb[t - 1], thr[t - 1], thrp[t - 1], r_lane, n_lim, best[t - 1]) ? 1u : 0u;
     } else {
       if (t == 0) mfma_block_test<K, MASK, IMAX>(acc_odd, thr[QT - 1], r_lane - 32u, n_lim, best[QT - 1]);   // previous step's last block
       else mfma_block_test<K, MASK, IMAX>((t & 1) ? acc_even : acc_odd, thr[t - 1], r_lane, n_lim, best[t - 1]);
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   static_assert(QT % 2 == 0 && QT >= 2, "two query blocks share a 64-query flag byte");
   constexpr bool IMAX = MODE >= 1;
   constexpr int HALF = (MODE >= 2 && QT >= 4) ? MODE : 0;           // the split (0: whole blocks)
+  constexpr float kPartOff = HALF ? 64.f * (float)(4 - HALF) : 0.f;   // what the positions behind the split can still add to a dot product
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   uint32_t tile, qw;
   if (tiles_per_xcd) {
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   // query blocks beyond nq repeat the last query: their results are never stored
   Fp4Row qb[QT];
   uint32_t best[QT][K];
-  float thr[QT];
+  float thr[QT], thrp[QT];                                         // thrp: the part thresholds of the split blocks (mfma_block_test_part)
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     const uint32_t qi = q0 + 32u * t + c;
@@ -497,6 +500,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
     for (int j = 0; j < K; ++j) best[t][j] = 0xFFFFFFFFu;
     // cut = radius + 1: a row beyond the radius is dropped by the truncation (DescriptorMatcher.cpp:212-220) whatever its rank
     thr[t] = thr_of_limit(cut);
+    thrp[t] = thr[t] - kPartOff;
   }
 
   const uint32_t row0 = tile * rows_per_tile;
@@ -536,14 +540,14 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   uint32_t n_pass = 0;
   for (; step + 2u <= n_full; step += 2u) {
     // two steps per trip: the expanded rows ping-pong between a0 and a1, the packed ones between pa and pb
-    n_pass += mfma_step<K, QT, false, IMAX, HALF>(a0, a1, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 4u * h, n_local, kc);
+    n_pass += mfma_step<K, QT, false, IMAX, HALF>(a0, a1, pa, qb, thr, thrp, best, acc_even, acc_odd, 32u * step + 4u * h, n_local, kc);
     if (PF2) {
       pa = load_step(step + 3u);
-      n_pass += mfma_step<K, QT, false, IMAX, HALF>(a1, a0, pb, qb, thr, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
+      n_pass += mfma_step<K, QT, false, IMAX, HALF>(a1, a0, pb, qb, thr, thrp, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
       pb = load_step(step + 4u);
     } else {
       pa = load_step(step + 2u);
-      n_pass += mfma_step<K, QT, false, IMAX, HALF>(a1, a0, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
+      n_pass += mfma_step<K, QT, false, IMAX, HALF>(a1, a0, pa, qb, thr, thrp, best, acc_even, acc_odd, 32u * step + 32u + 4u * h, n_local, kc);
       pa = load_step(step + 3u);
     }
     if (step + 2u >= next_share) {                                  // wave-uniform
@@ -557,7 +561,7 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
         const uint32_t worst_d = best[t][K - 1] >> kLocalBits;
         if (worst_d < (0xFFFFFFFFu >> kLocalBits) && worst_d < seen[t]) atomicMin(my_bound, worst_d);
         // a foreign bound is applied with <=: a smaller row index elsewhere may still win a tie
-        if (seen[t] != 0xFFFFFFFFu) thr[t] = fmaxf(thr[t], thr_of_limit(seen[t] + 1u));
+        if (seen[t] != 0xFFFFFFFFu) { thr[t] = fmaxf(thr[t], thr_of_limit(seen[t] + 1u)); thrp[t] = thr[t] - kPartOff; }
         seen[t] = __hip_atomic_load(my_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -565,14 +569,14 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   // the last unmasked step's last block is still a half: it completes here, with that step's rows (a1: the second step of the
   // loop's last trip ran on them) -- the masked steps and the drain below work on whole blocks
   if (HALF && step > 0u) {
-    n_pass += mfma_block_test_part<K, HALF ? HALF : 2>(acc_odd, a1, qb[QT - 1], thr[QT - 1], 32u * (step - 1u) + 4u * h, n_local, best[QT - 1]) ? 1u : 0u;
+    n_pass += mfma_block_test_part<K, HALF ? HALF : 2>(acc_odd, a1, qb[QT - 1], thr[QT - 1], thrp[QT - 1], 32u * (step - 1u) + 4u * h, n_local, best[QT - 1]) ? 1u : 0u;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc_odd[i] = -4096.f;
     if (lane == 0 && half_stats) { atomicAdd(half_stats, n_pass); atomicAdd(half_stats + 1, step * (uint32_t)QT); }
   }
   // at most one full and one partial step are left: the masked form serves both
   for (; step < n_steps; ++step) {
-    mfma_step<K, QT, true, IMAX>(a0, a1, pa, qb, thr, best, acc_even, acc_odd, 32u * step + 4u * h, n_local, kc);
+    mfma_step<K, QT, true, IMAX>(a0, a1, pa, qb, thr, thrp, best, acc_even, acc_odd, 32u * step + 4u * h, n_local, kc);
     a0 = a1;
     pa = PF2 ? pb : load_step(step + 2u);
   }
