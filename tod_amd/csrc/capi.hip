@@ -237,7 +237,7 @@ static int db_load_impl(todhip_ctx* ctx, const todhip_object* objs, uint32_t n_o
   ctx->counters.db_objects = n_objs;
 
   TOD_HIP(hipStreamSynchronize(ctx->stream));
-  TOD_HIP(ctx->db_desc.reserve((size_t)ctx->shard_rows * desc_bytes + 256));
+  TOD_HIP(ctx->db_desc.reserve((size_t)ctx->shard_rows * desc_bytes + kDbSlackBytes));   // (the matrix-core matcher's last step reads into the slack)
   TOD_HIP(ctx->db_pts.reserve((size_t)total * 3 * sizeof(float) + 16));
   TOD_HIP(ctx->db_obj_off.reserve((size_t)(n_objs + 1) * sizeof(uint32_t)));
   size_t row = 0;

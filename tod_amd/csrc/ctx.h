@@ -27,6 +27,9 @@
 #endif
 #define TOD_LATENCY_PRIO() __builtin_amdgcn_s_setprio(TOD_LATENCY_PRIO_LEVEL)
 
+// bytes todhip_db_load allocates behind the last descriptor row: hamming_topk_mfma loads whole 32-row steps without a per-lane clamp
+constexpr size_t kDbSlackBytes = 2048;
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;

@@ -507,14 +507,18 @@ __global__ __launch_bounds__(kBlock, 2) void hamming_topk_mfma(const uint32_t* _
   const uint32_t row_end = min(n_rows, row0 + rows_per_tile);
   const uint32_t n_local = row_end - row0;                          // > 0: tile < n_tiles
   const uint32_t n_full = n_local / 32u, n_steps = (n_local + 31u) / 32u;   // the DB's last step may be partial
-  const uint32_t last_row = n_rows - 1u;
-  // this lane's 16 bytes of DB row (row0 + 32 step + c), clamped into the DB (rows past the end are masked, not used)
+  // this lane's 16 bytes of DB row (row0 + 32 step + c). No per-lane clamp: the DB's last step may reach up to 31 rows past its end
+  // -- into the slack todhip_db_load leaves behind the descriptors (kDbSlackBytes), rows that are masked, never used -- and the
+  // address stays a wave-uniform base plus a constant lane offset (no vector instruction per load: the kernel is bound by those)
+  const uint32_t lane_off = (c * kWords + 4u * h) * 4u;              // bytes from the step's first row
   auto load_step = [&](uint32_t step) -> uint4 {
-    const uint32_t r = min(row0 + 32u * min(step, n_steps - 1u) + c, last_row);
+    const uint32_t first = row0 + 32u * min(step, n_steps - 1u);    // wave-uniform
 #if defined(TOD_K4X_ABLATE) && TOD_K4X_ABLATE == 1           // diagnostics build only (tools/k4x_ablate.sh): no DB loads
+    const uint32_t r = first + c;
     return uint4{r * 2654435761u, r ^ step, r + h, r * 40503u};
 #else
-    return *reinterpret_cast<const uint4*>(db + (size_t)r * kWords + 4u * h);
+    const char* base = reinterpret_cast<const char*>(db) + (size_t)first * (kWords * 4u);
+    return *reinterpret_cast<const uint4*>(base + lane_off);
 #endif
   };
   Fp4Row a0, a1;
