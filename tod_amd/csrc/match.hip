@@ -339,11 +339,11 @@ __device__ __forceinline__ void mfma_block_test(const mfma_f32x16& acc, float& t
 #endif
   if (!MASK) {
     bool any;
-    if (IMAX) {
-      int m = max(max(__float_as_int(acc[0]), __float_as_int(acc[1])), __float_as_int(acc[2]));
+    if (IMAX) {                                            // (a tree: see mfma_block_test_part)
+      int g[5];
 #pragma unroll
-      for (int i = 3; i < 15; i += 2) m = max(max(m, __float_as_int(acc[i])), __float_as_int(acc[i + 1]));
-      m = max(m, __float_as_int(acc[15]));
+      for (int j = 0; j < 5; ++j) g[j] = max(max(__float_as_int(acc[3 * j]), __float_as_int(acc[3 * j + 1])), __float_as_int(acc[3 * j + 2]));
+      const int m = max(max(max(g[0], g[1]), g[2]), max(max(g[3], g[4]), __float_as_int(acc[15])));
       any = m > __float_as_int(thr);
     } else {
       float m = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
@@ -905,7 +905,7 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
   // split pays is a property of the DATA (independent bits: 2; this library's ORB descriptors of rendered views: 3, since nearly
   // every block survives 128 positions there and the 2-split then costs +30 %), so the launch adapts: a split launch counts the blocks
   // that went on to their second part, the merge kernel behind it leaves the totals in pinned memory, and the context moves one
-  // level up (2 -> 3 -> whole blocks) when more than a quarter (2) / half (3) went on, and probes one level down every k4x_hold_len
+  // level up (2 -> 3 -> whole blocks) when more than a quarter of the blocks went on, and probes one level down every k4x_hold_len
   // launches (32, doubling to 256 while the probes keep failing). todhip_set_matcher_block_split, or TODHIP_K4X_HALF=0 / 2 / 3 as the
   // process's default: never / always that split (1 = 2).
   static const int env_default = getenv("TODHIP_K4X_HALF") ? atoi(getenv("TODHIP_K4X_HALF")) : -1;
@@ -932,7 +932,7 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
         if (!blocks) continue;
         ctx->k4x_last[2 * (m - 2)] += pass; ctx->k4x_last[2 * (m - 2) + 1] += blocks;
         ctx->counters.k4x_half_blocks += blocks; ctx->counters.k4x_half_blocks_completed += pass;
-        const bool pays = m == 2 ? (uint64_t)pass * 4u <= blocks : (uint64_t)pass * 2u <= blocks;
+        const bool pays = (uint64_t)pass * 4u <= blocks;     // (measured on the rendered-view DB: 48 % going on at split 3 = 2.71 ms, whole blocks 2.60)
         if (dbg) fprintf(stderr, "[todhip] K4x blocks split after %u MFMAs: %u of %u went on (%.3f)%s, split in use %u\n", m, pass, blocks,
                          (double)pass / blocks, pays ? "" : ": does not pay", ctx->k4x_split);
         if (!adaptive) continue;
