@@ -1011,8 +1011,8 @@ int launch_topk_mfma(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint32_t
   // Query blocks of 32 per wave (QT): the registers hold 8 beside the k-entry lists for k <= 2, 6 for k <= 5 (the reference's k,
   // DescriptorMatcher.cpp:211), 4 beyond. Six is the default even where eight fit: with eight a wave takes 256 registers, two waves
   // fill a SIMD's file, and every kernel of the other stages (ORB, verifier) then waits for a matcher workgroup to retire before
-  // one of its own can start -- a quarter of a DB pass, 25 dependent launches per ORB batch. With six (216 registers) 80 per SIMD
-  // stay free and those kernels run beside the matcher's waves: alone the pass is 2 % slower (2.36 vs 2.32 ms whole blocks), in the
+  // one of its own can start -- a quarter of a DB pass, 25 dependent launches per ORB batch. With six (213-221 registers, allocated
+  // in eights: 64-80 of a SIMD's 512 stay free) those kernels run beside the matcher's waves: alone the pass is 2 % slower (2.36 vs 2.32 ms whole blocks), in the
   // pipeline ORB's stage falls from 1.9 to 1.2 ms, the verifier's from 2.05 to 1.5, and the matcher's own launch is no slower
   // (tools/ab_k4x_residency.sh: headline 16.2k -> 16.6k frames/s, chained 8.7k -> 9.9k). Among the candidates the one that pads nq
   // the least wins when that saves more than 3 % (a wave computes all its blocks; 1000 queries are 4 x 256 but 6 x 192).
