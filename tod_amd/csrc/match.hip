@@ -745,6 +745,50 @@ __global__ __launch_bounds__(kBlock) void merge_tiles_kernel(const uint32_t* __r
   for (int j = 0; j < K; ++j) keys[((size_t)grp * nq + qi) * K + j] = best[j];
 }
 
+// K4m for a handful of queries (the <= 32-query regime: 8192 tiles, and merge_tiles_kernel's 16 queries x 16 groups = 256 threads walk
+// 512 tiles each, 71 us behind a 217 us DB pass): one WAVE per (query, group), the group's tiles spread over its lanes, the lanes'
+// lists merged by a butterfly of shuffles. Same keys, same output layout.
+template <int K>
+__global__ __launch_bounds__(kBlock) void merge_tiles_wave_kernel(const uint32_t* __restrict__ part, uint32_t nq, uint32_t nq_pad,
+                                                                  uint32_t n_tiles, uint32_t rows_per_tile, uint64_t first_global_row,
+                                                                  uint32_t n_groups, const uint8_t* __restrict__ stored, uint32_t n_qw,
+                                                                  uint64_t* __restrict__ keys) {
+  TOD_LATENCY_PRIO();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t qi = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), grp = blockIdx.y;
+  if (qi >= nq) return;                                     // (wave-uniform)
+  uint64_t best[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) best[j] = ~0ull;
+  for (uint32_t t = grp + n_groups * lane; t < n_tiles; t += n_groups * 64u) {
+    if (stored[(size_t)t * n_qw + (qi >> 6)] != 0) continue;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const uint32_t pk = part[((size_t)t * K + j) * nq_pad + qi];
+      uint64_t key = pk == 0xFFFFFFFFu ? ~0ull
+                                       : (((uint64_t)(pk >> kLocalBits) << 32) | (first_global_row + (uint64_t)t * rows_per_tile + (pk & kLocalMask)));
+#pragma unroll
+      for (int s2 = 0; s2 < K; ++s2) { const uint64_t lo = key < best[s2] ? key : best[s2]; key = key < best[s2] ? best[s2] : key; best[s2] = lo; }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    uint64_t other[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) other[j] = __shfl_xor(best[j], off);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      uint64_t key = other[j];
+#pragma unroll
+      for (int s2 = 0; s2 < K; ++s2) { const uint64_t lo = key < best[s2] ? key : best[s2]; key = key < best[s2] ? best[s2] : key; best[s2] = lo; }
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) keys[((size_t)grp * nq + qi) * K + j] = best[j];
+  }
+}
+
 // K4s: per query, the k smallest of n_lists ascending lists (layout [list][nq][k]) -> keys[nq][k].
 __global__ __launch_bounds__(kBlock) void select_keys_kernel(const uint64_t* __restrict__ lists, uint32_t n_lists,
                                                              uint32_t nq, uint32_t k, uint64_t* __restrict__ keys) {
@@ -995,7 +1039,7 @@ int launch_topk_mfma_q32(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint
                      ctx->db_desc.as<uint32_t>(), d_q, n_rows, nq, nq_pad, rows_per_tile, n_tiles, n_qw64, cut,
                      (uint32_t)std::max(4, env_share), ctx->m_part.as<uint32_t>(), ctx->m_bound.as<uint32_t>(), d_stored);
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
-  hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
+  hipLaunchKernelGGL(merge_tiles_wave_kernel<K>, dim3((nq + kWavesPerBlock - 1) / kWavesPerBlock, groups), dim3(kBlock), 0, ctx->stream,
                      ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
                      d_stored, n_qw64, d_lists);
   TOD_HIP(hipGetLastError());
