@@ -1006,10 +1006,14 @@ int launch_topk_mfma_qt(todhip_ctx* ctx, const uint32_t* d_q, uint32_t nq, uint3
                      ctx->m_bound.as<uint32_t>(), d_stored, d_stats ? d_stats + 2u * (split - 2u) : nullptr);
   if (slot >= 0) { int rc = tod_timing_end(ctx, slot); if (rc != TODHIP_OK) return rc; }
   if (d_stats) ++ctx->k4x_seq_sent;
-  hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
-                     ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
-                     d_stored, n_qw64, d_lists, (const uint32_t*)d_stats, d_stats ? ctx->k4x_stats_host.as<uint32_t>() : (uint32_t*)nullptr,
-                     ctx->k4x_seq_sent);
+  if (nq <= 64u && !d_stats && n_tiles >= 256u)              // a handful of queries over thousands of tiles: a wave per (query, group)
+    hipLaunchKernelGGL(merge_tiles_wave_kernel<K>, dim3((nq + kWavesPerBlock - 1) / kWavesPerBlock, groups), dim3(kBlock), 0, ctx->stream,
+                       ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups, d_stored, n_qw64, d_lists);
+  else
+    hipLaunchKernelGGL(merge_tiles_kernel<K>, dim3((nq + kBlock - 1) / kBlock, groups), dim3(kBlock), 0, ctx->stream,
+                       ctx->m_part.as<uint32_t>(), nq, nq_pad, n_tiles, rows_per_tile, ctx->shard_first, groups,
+                       d_stored, n_qw64, d_lists, (const uint32_t*)d_stats, d_stats ? ctx->k4x_stats_host.as<uint32_t>() : (uint32_t*)nullptr,
+                       ctx->k4x_seq_sent);
   TOD_HIP(hipGetLastError());
   *n_lists = groups;
   return TODHIP_OK;
