@@ -323,7 +323,9 @@ def run_chained(torch, capi, device, args):
     vctxs = [capi.Context(device, s.cuda_stream) for s in vstreams]
     mctx.set_matcher_engine(args.engine)
     spans = mctx.db_load(desc, pts, off)
-    D, P = max(3, NV + 1), len(batches)
+    # ring depth: the matcher of step i waits for verify(i - D); with 2 workers at ~5.4 ms per batch and a 3 ms step, D = 3 leaves no
+    # slack for jitter (9.6-9.9k frames/s), D = 4 does (9.9-10.0k on the same box)
+    D, P = max(int(os.environ.get("TOD_BENCH_CHAINED_DEPTH", "4")), NV + 1), len(batches)
     R = 2 * D                                                             # ORB output ring: ORB runs D ahead of the matcher, the verifier D behind
     orb_ring = [dict(kp=torch.zeros((B, nq, 2), device="cuda"), aux=torch.zeros((B, nq, 4), device="cuda"),
                      desc=torch.zeros((B, nq, 32), dtype=torch.uint8, device="cuda"), n=[nq] * B) for _ in range(R)]
