@@ -477,3 +477,13 @@ def test_block_split_adapts_to_the_data():
         cnt = c.counters()
         assert cnt.k4x_half_blocks > 0 and cnt.k4x_half_blocks_completed <= cnt.k4x_half_blocks
         c.close()
+
+
+def test_block_split_setter_takes_only_its_four_values():
+    c = capi.Context(0)
+    for ok in (-1, 0, 2, 3, -1):
+        c.set_matcher_block_split(ok)
+    for bad in (1, 4, -2, 64):
+        with pytest.raises(Exception):
+            c.set_matcher_block_split(bad)
+    c.close()
