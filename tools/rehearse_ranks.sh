@@ -14,3 +14,5 @@ TOD_BENCH_FORCE_DIST=1 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 
 TOD_BENCH_BACKEND=gloo TOD_BENCH_ONE_DEVICE=1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err && show $OUT/bench_gloo2.json || { tail -15 $OUT/bench_gloo2.err; exit 1; }
 TOD_BENCH_BACKEND=gloo TOD_BENCH_ONE_DEVICE=1 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29542 bench.py --gpus 3 --steps 4 --warmup 2 --no-cpu-baseline --exchange all_gather --serial-exchange > $OUT/bench_gloo3.json 2> $OUT/bench_gloo3.err && show $OUT/bench_gloo3.json || { tail -15 $OUT/bench_gloo3.err; exit 1; }
 TOD_BENCH_BACKEND=gloo TOD_BENCH_ONE_DEVICE=1 timeout -k 10 400 python3 bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline --replicas > $OUT/bench_spawn2.json 2> $OUT/bench_spawn2.err && show $OUT/bench_spawn2.json || { tail -15 $OUT/bench_spawn2.err; exit 1; }
+# four ranks (the per-rank launch shape of a 4-GPU job: 128 000 queries x a 250k-row shard), gloo, all on device 0
+TOD_BENCH_BACKEND=gloo TOD_BENCH_ONE_DEVICE=1 timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 4 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_gloo4.json 2> $OUT/bench_gloo4.err && show $OUT/bench_gloo4.json || { tail -15 $OUT/bench_gloo4.err; exit 1; }
