@@ -3,9 +3,12 @@
 #   full       the default bench.py command without extras (the matcher launch average must agree with roofline.launch_ms)
 #   chained    the verifier on one 16-frame data-chained batch, twice (tools/chained_ticks.py child 16)
 #   l2         the float matcher at the C4 shape (tools/time_l2.py) + its FETCH_SIZE pass
+#   pipeline   bench.py's chained block (the data-chained pipeline: whole-block matcher on the trained DB, ORB, the verifier's kernels)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-rm -rf $OUT/prof_full $OUT/prof_cv $OUT/prof_l2 $OUT/prof_l2_f
+rm -rf $OUT/prof_full $OUT/prof_cv $OUT/prof_l2 $OUT/prof_l2_f $OUT/prof_cp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cp -- python3 bench.py --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --stages match --extras chained > $OUT/prof_cp.log 2>&1 || { tail -5 $OUT/prof_cp.log; exit 1; }
+find $OUT/prof_cp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/r03_chained_pipeline_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_full -- python3 bench.py --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --extras= > $OUT/prof_full.log 2>&1 || { tail -5 $OUT/prof_full.log; exit 1; }
 find $OUT/prof_full -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/r03_full_kernel_stats.csv
 tail -c 400 $OUT/prof_full.log | head -c 400; echo
